@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star chain on MI355X: cf32 IQ -> 127-tap FIR, decimate by 5 -> 1024-pt FFT.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the fused chain kernel (redio_chain_enqueue) over one resident buffer of
+2^28 synthetic cf32 samples per GPU (BASELINE.json configs[1]).  Inputs are generated on the device
+by the integer hash of SURVEY.md 8d before the timed region.  For N > 1 the driver starts one process
+per GPU (torch.distributed.run); the stream is time-sliced, every rank owns its own 2^28-sample slice
+(with the 126-sample FIR halo inside the slice), there is no data-path collective, and value is the
+samples of all ranks over the slowest rank's time ("weak" scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant (only) kernel, chain_fir_fft1k_kernel:
+algorithmic bytes = 9.6 B per input sample (8 B read + 8/5 B written) over the kernel's
+mean duration measured with HIP events on the launch stream.  `cpu_baseline` is the CPU oracle
+(oracle/, a port of the reference's algorithm) timed on this host on a bounded prefix.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NTAPS, DECIM, NFFT, FC = 127, 5, 1024, 0.08
+ALG_BYTES_PER_SAMPLE = 8.0 + 8.0 / DECIM  # cf32 in once + decimated cf32 spectra out once
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED = 0x5EED0002                         # 0x5EED0000 + config id
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (default 2^28 = 2 GiB)")
+    ap.add_argument("--unfused", action="store_true", help="run FIR and FFT as two kernels (12.8 B/sample)")
+    ap.add_argument("--exact", action="store_true", help="reference rounding (mul+add) instead of fmaf in the FIR")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2-samples", type=int, default=25)
+    ap.add_argument("--traffic-json", default=None, help="file with {'traffic': bytes_per_launch} from the PMC passes")
+    return ap.parse_args()
+
+
+def cpu_baseline(log2n):
+    """The oracle port of the reference path, one thread, on a bounded prefix of the same workload."""
+    import numpy as np
+    import oracle as O
+    n = 1 << log2n
+    x = O.synth_iq(SEED, 0, n)
+    taps = O.lpf_corrected(NTAPS, FC)
+    O.chain_fir_fft(x[: 8192 * DECIM + NTAPS], taps, DECIM, NFFT)  # page in / warm
+    t0 = time.perf_counter()
+    out = O.chain_fir_fft(x, taps, DECIM, NFFT, fused=False)
+    dt = time.perf_counter() - t0
+    used = out.shape[0] * NFFT * DECIM
+    return {"value": used / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
+            "sample": f"first 2^{log2n} samples of the same hash-generated stream, oracle/ C port "
+                      f"(scalar, strict-order FIR + kissfft restatement), {dt:.2f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    a = parse()
+    import torch
+    import libredio_amd as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (libredio has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = R.lib()
+    n = 1 << a.log2_samples
+    taps = R.dsputils.lpf_corrected(NTAPS, FC)
+    chain = R.Chain(taps, DECIM, NFFT, fused=not a.exact)
+    if a.unfused:
+        chain.set_unfused(True)
+    nblk = chain.nblocks(n)
+    used = nblk * NFFT * DECIM  # input samples that contribute to a spectrum
+    # rank r owns the slice that starts at decimated block r*nblk of the global stream
+    first = rank * nblk * NFFT * DECIM
+    x = R.synth_iq(SEED, first, n)
+    out = torch.empty((nblk, NFFT), dtype=torch.complex64, device="cuda")
+    stream = R.current_stream()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        chain(x, out)
+    # HIP events around every timed launch, on the launch stream
+    evs = []
+    for _ in range(a.steps + 1):
+        e = C.c_void_p()
+        R.check(lib.redio_event_create(C.byref(e)))
+        evs.append(e)
+    barrier()
+    t0 = time.perf_counter()
+    R.check(lib.redio_event_record(evs[0], stream))
+    for k in range(a.steps):
+        chain(x, out)
+        R.check(lib.redio_event_record(evs[k + 1], stream))
+    barrier()
+    dt = time.perf_counter() - t0
+    kms = []
+    for k in range(a.steps):
+        ms = C.c_float()
+        R.check(lib.redio_event_elapsed_ms(evs[k], evs[k + 1], C.byref(ms)))
+        kms.append(ms.value)
+    for e in evs:
+        lib.redio_event_destroy(e)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
+        alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
+        ach = alg_bytes / kavg / 1e9
+        traffic = None
+        if a.traffic_json and os.path.exists(a.traffic_json):
+            traffic = json.load(open(a.traffic_json)).get("traffic")
+        rec = {
+            "metric": "MSamples/s through FIR+FFT chain (127-tap FIR decimate-by-5 -> 1024-pt FFT, cf32 IQ)",
+            "value": world * used * a.steps / dt / 1e6,
+            "unit": "MSamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: single f32 IQ stream, 1024-pt FFT + 127-tap FIR decimate-by-5",
+                       "samples_per_gpu": n, "ntaps": NTAPS, "decim": DECIM, "nfft": NFFT,
+                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else "chain_fir_fft1k_kernel (fused)",
+                       "fir_rounding": "mul+add (reference)" if a.exact else "fmaf, reference order",
+                       "parallelism": f"time-sliced replicas x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": kavg * 1e3,
+                         "frac_of_measured_copy_6290": ach / 6290.0},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(a.cpu_log2_samples)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+/*
+ * redio.h -- C ABI of libredio.so, the MI355X (gfx950) engine for LibRedio's per-sample DSP blocks.
+ *
+ * This is the drop-in boundary of SURVEY.md 8(b): plain pointers and sizes, no C++/torch types.
+ * Paths below are relative to the reference tree (ade-ma/LibRedio).
+ *
+ * Two families of entry points share the same kernels:
+ *   (1) host-buffer, synchronous calls that replace what the reference computes per message
+ *       (redio_convolve_f32 for dsputils::convolve; kiss_fft.h / samplerate.h for the C symbols the
+ *       reference's Rust already binds);
+ *   (2) device-resident plans (redio_fir_*, redio_fft_*, redio_chain_*, ...) that take device
+ *       pointers and a HIP stream, allocate nothing and never synchronise inside *_enqueue, so a
+ *       graph of blocks can keep its streams in HBM.  Throughput numbers use (2).
+ *
+ * Every function returns REDIO_OK (0) or a negative redio error / positive HIP error code mapped by
+ * redio_strerror(); nothing aborts or panics (the reference's unwrap()/assert!/panic! sites become
+ * error returns -- SURVEY.md 5 "failure detection").
+ * Thread safety: distinct handles may be used concurrently from distinct threads; each call binds
+ * the handle's device first (the reference runs one OS thread per block, src/ratpak.rs:60-185).
+ */
+#ifndef REDIO_H
+#define REDIO_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- errors ---- */
+enum {
+    REDIO_OK = 0,
+    REDIO_ERR_ARG = -1,         /* NULL pointer / zero taps / zero decimation / bad size */
+    REDIO_ERR_NOMEM = -2,
+    REDIO_ERR_UNSUPPORTED = -3, /* shape has no kernel (documented per function) */
+    REDIO_ERR_NO_DEVICE = -4,   /* no HIP device: the product path never falls back to the CPU */
+    REDIO_ERR_ASSERT = -5,      /* an assert!() of the reference would have fired (e.g. fc >= 0.5) */
+    REDIO_ERR_HIP_BASE = -1000  /* -(1000 + hipError_t) */
+};
+const char *redio_strerror(int code);
+const char *redio_version(void);
+
+/* ---- device / memory / stream / event helpers (thin, so non-torch hosts can drive plans) ---- */
+int redio_device_count(int *count);
+int redio_set_device(int device);
+int redio_malloc(void **dptr, size_t bytes);
+int redio_free(void *dptr);
+int redio_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int redio_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int redio_stream_create(void **stream);
+int redio_stream_destroy(void *stream);
+int redio_stream_sync(void *stream); /* NULL = default stream */
+int redio_event_create(void **event);
+int redio_event_destroy(void *event);
+int redio_event_record(void *event, void *stream);
+int redio_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+
+/* ---- tap generators: src/dsputils/src/dsputils.rs:38-94 (host side, run once per filter) ----
+ * Quirk-faithful to the reference as written (window() returns m+1 values, lpf()[1] is NaN, ...);
+ * redio_lpf_corrected is the documented-deviation designer used for benchmark taps. */
+int redio_window(size_t m, float *out /* m+1 */);                 /* :38-51 */
+int redio_sinc(size_t m, float fc, float *out /* m */);           /* :53-63; fc>=0.5 -> REDIO_ERR_ASSERT */
+int redio_lpf(size_t m, float fc, float *out);                    /* :66-71 */
+int redio_hpf(size_t m, float fc, float *out);                    /* :74-79; m<2 -> REDIO_ERR_ASSERT */
+int redio_bsf(size_t m, float fc1, float fc2, float *out);        /* :82-88 */
+int redio_bpf(size_t m, float fc1, float fc2, float *out);        /* :91-94 */
+int redio_lpf_corrected(size_t m, float fc, float *out);
+
+/* ---- A1: dsputils::convolve, src/dsputils/src/dsputils.rs:30-32 ----
+ * Host buffers in/out, synchronous: out[i] = sum_j u[i+j]*v[j] folded left to right from 0.0 with a
+ * separately rounded multiply and add (bit-exact with the reference fold).  *nout = nu-nv+1, or 0
+ * when nu < nv (windows() yields nothing); nv == 0 -> REDIO_ERR_ASSERT (windows(0) panics). */
+int redio_convolve_f32(const float *u, size_t nu, const float *v, size_t nv, float *out, size_t *nout);
+
+/* ---- device-resident FIR plan (A1 extended: complex input x real taps, decimation) ---- */
+enum {
+    REDIO_FIR_COMPLEX = 1u, /* input/output are interleaved cf32 {re, im}; taps stay real */
+    REDIO_FIR_FUSED = 2u    /* acc = fmaf(x, h, acc) instead of acc + x*h: faster, still strict order */
+};
+typedef struct redio_fir redio_fir;
+int redio_fir_create(redio_fir **h, const float *taps_host, size_t ntaps, size_t decim, unsigned flags);
+int redio_fir_destroy(redio_fir *h);
+/* number of outputs for n_in inputs: 0 if n_in < ntaps, else (n_in - ntaps)/decim + 1 */
+size_t redio_fir_nout(const redio_fir *h, size_t n_in);
+/* valid-mode over one device buffer; d_out must hold redio_fir_nout() samples; in != out */
+int redio_fir_enqueue(redio_fir *h, const void *d_in, size_t n_in, void *d_out, void *stream);
+
+/* ---- A5: kissfft::fft block, src/kissfft/src/kissfft.rs:18-31 (device-resident, batched) ----
+ * nbatch consecutive messages of exactly nfft cf32 samples; unnormalised; inverse!=0 flips the sign
+ * of the exponent.  Arithmetic order of the published kissfft butterflies (bit-exact with
+ * oracle/oracle_kiss.c).  d_in == d_out is allowed. */
+typedef struct redio_fft redio_fft;
+int redio_fft_create(redio_fft **h, int nfft, int inverse);
+int redio_fft_destroy(redio_fft *h);
+int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, void *stream);
+
+/* ---- C2 chain: FIR (ntaps, decimate decim) -> nfft-point forward FFT of consecutive blocks ----
+ * Fused single kernel for (ntaps, decim, nfft) = (127, 5, 1024); other shapes run the FIR and FFT
+ * kernels back to back through a plan-owned intermediate buffer (same results).  Trailing decimated
+ * samples that do not fill a block are dropped, as kpn::shaper would (src/kpn/src/kpn.rs:278-282). */
+typedef struct redio_chain redio_chain;
+int redio_chain_create(redio_chain **h, const float *taps_host, size_t ntaps, size_t decim, int nfft, unsigned flags);
+int redio_chain_destroy(redio_chain *h);
+size_t redio_chain_nblocks(const redio_chain *h, size_t n_in);
+int redio_chain_is_fused(const redio_chain *h);
+/* force the two-kernel path (for measurement): 0 = fused when available, 1 = never fused */
+int redio_chain_set_unfused(redio_chain *h, int unfused);
+int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
+
+/* ---- synthetic input: hash-generated cf32 / f32 in [-1, 1), device side ---- */
+int redio_synth_iq(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);
+int redio_synth_f32(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REDIO_H */

@@ -1,0 +1,123 @@
+"""libredio_amd -- host-side mirror of LibRedio's DSP-block interface over libredio.so (gfx950).
+
+The product is the C-ABI library built from libredio_amd/csrc (include/redio.h, include/kiss_fft.h).
+This package is the thin Python host layer used by tests and bench.py: it loads the library with
+ctypes and mirrors the reference's names -- dsputils.convolve / window / sinc / lpf / hpf / bsf / bpf
+(src/dsputils/src/dsputils.rs), kissfft.fft (src/kissfft/src/kissfft.rs:18-31) -- plus the
+device-resident plans.  There is NO CPU fallback: if the library is missing the import of `lib()`
+raises, and every compute entry point needs a HIP device.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+LIBREDIO = os.path.join(_BUILD, "libredio.so")
+LIBKISSFFT = os.path.join(_BUILD, "libkissfft.so")
+
+REDIO_FIR_COMPLEX = 1
+REDIO_FIR_FUSED = 2
+
+
+class RedioError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().redio_strerror(code).decode() if _lib is not None else str(code)
+        super().__init__(f"{what}: redio error {code}: {msg}")
+
+
+def build(verbose=False):
+    """Compile every HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIBREDIO
+
+
+_lib = None
+_kiss = None
+
+
+def _sig(f, res, *args):
+    f.restype = res
+    f.argtypes = list(args)
+
+
+def lib():
+    """The loaded libredio.so (raises if it was not built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBREDIO):
+        raise ImportError(f"{LIBREDIO} is missing: run libredio_amd.build() / make -C libredio_amd/csrc")
+    L = C.CDLL(LIBREDIO, mode=C.RTLD_GLOBAL)
+    vp, sz, i, u, f = C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_float
+    pf = C.POINTER(C.c_float)
+    _sig(L.redio_strerror, C.c_char_p, i)
+    _sig(L.redio_version, C.c_char_p)
+    _sig(L.redio_device_count, i, C.POINTER(i))
+    _sig(L.redio_set_device, i, i)
+    _sig(L.redio_malloc, i, C.POINTER(vp), sz)
+    _sig(L.redio_free, i, vp)
+    _sig(L.redio_upload, i, vp, vp, sz, vp)
+    _sig(L.redio_download, i, vp, vp, sz, vp)
+    _sig(L.redio_stream_create, i, C.POINTER(vp))
+    _sig(L.redio_stream_destroy, i, vp)
+    _sig(L.redio_stream_sync, i, vp)
+    _sig(L.redio_event_create, i, C.POINTER(vp))
+    _sig(L.redio_event_destroy, i, vp)
+    _sig(L.redio_event_record, i, vp, vp)
+    _sig(L.redio_event_elapsed_ms, i, vp, vp, C.POINTER(f))
+    _sig(L.redio_window, i, sz, pf)
+    for n in ("redio_sinc", "redio_lpf", "redio_hpf", "redio_lpf_corrected"):
+        _sig(getattr(L, n), i, sz, f, pf)
+    for n in ("redio_bsf", "redio_bpf"):
+        _sig(getattr(L, n), i, sz, f, f, pf)
+    _sig(L.redio_convolve_f32, i, pf, sz, pf, sz, pf, C.POINTER(sz))
+    _sig(L.redio_fir_create, i, C.POINTER(vp), pf, sz, sz, u)
+    _sig(L.redio_fir_destroy, i, vp)
+    _sig(L.redio_fir_nout, sz, vp, sz)
+    _sig(L.redio_fir_enqueue, i, vp, vp, sz, vp, vp)
+    _sig(L.redio_fft_create, i, C.POINTER(vp), i, i)
+    _sig(L.redio_fft_destroy, i, vp)
+    _sig(L.redio_fft_enqueue, i, vp, vp, vp, sz, vp)
+    _sig(L.redio_chain_create, i, C.POINTER(vp), pf, sz, sz, i, u)
+    _sig(L.redio_chain_destroy, i, vp)
+    _sig(L.redio_chain_nblocks, sz, vp, sz)
+    _sig(L.redio_chain_is_fused, i, vp)
+    _sig(L.redio_chain_set_unfused, i, vp, i)
+    _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
+    _sig(L.redio_synth_iq, i, vp, C.c_uint32, C.c_uint64, sz, vp)
+    _sig(L.redio_synth_f32, i, vp, C.c_uint32, C.c_uint64, sz, vp)
+    _lib = L
+    return L
+
+
+def kisslib():
+    """The loaded libkissfft.so drop-in (kiss_fft_alloc / kiss_fft / kiss_fft_cleanup)."""
+    global _kiss
+    if _kiss is not None:
+        return _kiss
+    lib()
+    if not os.path.exists(LIBKISSFFT):
+        raise ImportError(f"{LIBKISSFFT} is missing: run libredio_amd.build()")
+    K = C.CDLL(LIBKISSFFT)
+    _sig(K.kiss_fft_alloc, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t))
+    _sig(K.kiss_fft, None, C.c_void_p, C.c_void_p, C.c_void_p)
+    _sig(K.kiss_fft_stride, None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+    _sig(K.kiss_fft_cleanup, None)
+    _sig(K.kiss_fft_next_fast_size, C.c_int, C.c_int)
+    _sig(K.kiss_fft_free, None, C.c_void_p)
+    _kiss = K
+    return K
+
+
+def check(code, what="redio"):
+    if code != 0:
+        raise RedioError(code, what)
+
+
+from . import dsputils, kissfft, plans  # noqa: E402,F401
+from .plans import Chain, Fft, Fir, current_stream, synth_f32, synth_iq  # noqa: E402,F401

@@ -1,0 +1,246 @@
+// fft_core.h -- butterfly arithmetic and lane/LDS index maps of the gfx950 FFT kernels.
+//
+// Arithmetic contract: kissfft::fft (src/kissfft/src/kissfft.rs:18-31) hands each block to
+// kiss_fft(), whose published algorithm (kissfft 1.3.0 kiss_fft.c) is decimation in time over the
+// factor list "4s, then 2s, then 3, 5, odd primes" with a float twiddle table.  The butterflies
+// below keep that operation order, one rounding per multiply/add and no FMA contraction, so a
+// transform is bit-identical to the CPU algorithm; only the data movement is redesigned for a
+// 64-lane wavefront and LDS.
+//
+// Host-compilable (tests/emu runs the same lane programs on the CPU, one lane at a time).
+#pragma once
+#include "redio_device.h"
+#include <math.h>
+
+namespace redio {
+
+// ---- radix-4 butterfly (kf_bfly4 order) ------------------------------------------------------
+template <bool INV>
+RD_HD void bfly4(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 t1, float2 t2, float2 t3)
+{
+    float2 s0 = cmul_rn(a1, t1);
+    float2 s1 = cmul_rn(a2, t2);
+    float2 s2 = cmul_rn(a3, t3);
+    float2 s5 = csub_rn(a0, s1);
+    a0 = cadd_rn(a0, s1);
+    float2 s3 = cadd_rn(s0, s2);
+    float2 s4 = csub_rn(s0, s2);
+    a2 = csub_rn(a0, s3);
+    a0 = cadd_rn(a0, s3);
+    if (INV) {
+        a1 = make_float2(sub_rn(s5.x, s4.y), add_rn(s5.y, s4.x));
+        a3 = make_float2(add_rn(s5.x, s4.y), sub_rn(s5.y, s4.x));
+    } else {
+        a1 = make_float2(add_rn(s5.x, s4.y), sub_rn(s5.y, s4.x));
+        a3 = make_float2(sub_rn(s5.x, s4.y), add_rn(s5.y, s4.x));
+    }
+}
+
+// ---- radix-2 butterfly (kf_bfly2 order) ------------------------------------------------------
+RD_HD void bfly2(float2 &a0, float2 &a1, float2 t1)
+{
+    float2 t = cmul_rn(a1, t1);
+    a1 = csub_rn(a0, t);
+    a0 = cadd_rn(a0, t);
+}
+
+// ---- radix-3 butterfly (kf_bfly3 order; HALF_OF multiplies by a double literal) ---------------
+RD_HD void bfly3(float2 &a0, float2 &a1, float2 &a2, float2 t1, float2 t2, float2 epi3)
+{
+    float2 s1 = cmul_rn(a1, t1);
+    float2 s2 = cmul_rn(a2, t2);
+    float2 s3 = cadd_rn(s1, s2);
+    float2 s0 = csub_rn(s1, s2);
+    a1.x = (float)((double)a0.x - (double)s3.x * .5);
+    a1.y = (float)((double)a0.y - (double)s3.y * .5);
+    s0.x = mul_rn(s0.x, epi3.y);
+    s0.y = mul_rn(s0.y, epi3.y);
+    a0 = cadd_rn(a0, s3);
+    a2.x = add_rn(a1.x, s0.y);
+    a2.y = sub_rn(a1.y, s0.x);
+    a1.x = sub_rn(a1.x, s0.y);
+    a1.y = add_rn(a1.y, s0.x);
+}
+
+// ---- radix-5 butterfly (kf_bfly5 order) ------------------------------------------------------
+RD_HD void bfly5(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 &a4, float2 t1, float2 t2,
+                 float2 t3, float2 t4, float2 ya, float2 yb)
+{
+    float2 s0 = a0;
+    float2 s1 = cmul_rn(a1, t1);
+    float2 s2 = cmul_rn(a2, t2);
+    float2 s3 = cmul_rn(a3, t3);
+    float2 s4 = cmul_rn(a4, t4);
+    float2 s7 = cadd_rn(s1, s4), s10 = csub_rn(s1, s4);
+    float2 s8 = cadd_rn(s2, s3), s9 = csub_rn(s2, s3);
+    a0.x = add_rn(a0.x, add_rn(s7.x, s8.x));
+    a0.y = add_rn(a0.y, add_rn(s7.y, s8.y));
+    float2 s5, s6, s11, s12;
+    s5.x = add_rn(add_rn(s0.x, mul_rn(s7.x, ya.x)), mul_rn(s8.x, yb.x));
+    s5.y = add_rn(add_rn(s0.y, mul_rn(s7.y, ya.x)), mul_rn(s8.y, yb.x));
+    s6.x = add_rn(mul_rn(s10.y, ya.y), mul_rn(s9.y, yb.y));
+    s6.y = sub_rn(-mul_rn(s10.x, ya.y), mul_rn(s9.x, yb.y));
+    a1 = csub_rn(s5, s6);
+    a4 = cadd_rn(s5, s6);
+    s11.x = add_rn(add_rn(s0.x, mul_rn(s7.x, yb.x)), mul_rn(s8.x, ya.x));
+    s11.y = add_rn(add_rn(s0.y, mul_rn(s7.y, yb.x)), mul_rn(s8.y, ya.x));
+    s12.x = add_rn(-mul_rn(s10.y, yb.y), mul_rn(s9.y, ya.y));
+    s12.y = sub_rn(mul_rn(s10.x, yb.y), mul_rn(s9.x, ya.y));
+    a2 = cadd_rn(s11, s12);
+    a3 = csub_rn(s11, s12);
+}
+
+// ============================================================================================
+// 1024-point transform by ONE wavefront: 64 lanes x 16 points, three register passes
+// (stages m=1,4 | m=16,64 | m=256 of the 4^5 factorisation) with two LDS exchanges.
+//
+// Input index n = d0 + 4 d1 + 16 d2 + 64 d3 + 256 d4.  Stage s (m = 4^s) transforms digit d(4-s)
+// into output digit k(4-s) of weight 4^s, so X[k4 + 4 k3 + 16 k2 + 64 k1 + 256 k0].
+//
+// LDS image (one per transform, 16 rows x FFT1K_ROW float2 = 8704 B; the 4-float2 row pad makes
+// every exchange conflict-free for ds_write_b64 16-lane groups and ds_read_b64 32-lane groups):
+//   L1 (after pass A):  row = d1 + 4 d2,   col = d0 + 4 k4 + 16 k3
+//   L2 (after pass B):  row = 4 k1 + d0,   col = k4 + 4 k3 + 16 k2
+// ============================================================================================
+constexpr int FFT1K_ROW = 68;
+constexpr int FFT1K_LDS = 16 * FFT1K_ROW; // float2 elements per transform
+
+// Pass A.  lane = d0 + 4 d1 + 16 d2 holds v[t] = x[lane + 64 t], t = d3 + 4 d4.
+// tw points at the 1024-entry table of the plan (forward or inverse).
+template <bool INV, typename TwPtr>
+RD_HD void fft1k_passA(float2 (&v)[16], TwPtr tw)
+{
+    const float2 one = tw[0];
+#pragma unroll
+    for (int d3 = 0; d3 < 4; ++d3) // stage m=1 (fstride 256): k = 0, every twiddle is tw[0]
+        bfly4<INV>(v[d3], v[d3 + 4], v[d3 + 8], v[d3 + 12], one, one, one);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) // stage m=4 (fstride 64): k = k4
+        bfly4<INV>(v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3], tw[64 * k4], tw[128 * k4], tw[192 * k4]);
+    // now v[k3 + 4 k4]
+}
+RD_HD int fft1k_A_store(int lane, int k3, int k4) { return (lane & 3) + 4 * k4 + 16 * k3 + FFT1K_ROW * (lane >> 2); }
+
+// Pass B.  lane = d0 + 4 k4 + 16 k3 (the L1 column) holds u[e], e = d1 + 4 d2 (the L1 row).
+RD_HD int fft1k_B_load(int lane, int e) { return lane + FFT1K_ROW * e; }
+template <bool INV, typename TwPtr>
+RD_HD void fft1k_passB(float2 (&u)[16], int lane, TwPtr tw)
+{
+    const int k = lane >> 2; // k4 + 4 k3
+    {
+        const float2 t1 = tw[16 * k], t2 = tw[32 * k], t3 = tw[48 * k]; // stage m=16, fstride 16
+#pragma unroll
+        for (int d1 = 0; d1 < 4; ++d1) bfly4<INV>(u[d1], u[d1 + 4], u[d1 + 8], u[d1 + 12], t1, t2, t3);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) { // stage m=64, fstride 4: k = k4 + 4 k3 + 16 k2
+        const int kk = k + 16 * k2;
+        bfly4<INV>(u[4 * k2], u[4 * k2 + 1], u[4 * k2 + 2], u[4 * k2 + 3], tw[4 * kk], tw[8 * kk], tw[12 * kk]);
+    }
+    // now u[k1 + 4 k2]
+}
+RD_HD int fft1k_B_store(int lane, int k1, int k2) { return (lane >> 2) + 16 * k2 + FFT1K_ROW * (4 * k1 + (lane & 3)); }
+
+// Pass C.  lane = k4 + 4 k3 + 16 k2 (the L2 column) holds w[4 q + j], q = k1, j = d0 (the L2 row).
+RD_HD int fft1k_C_load(int lane, int q, int j) { return lane + FFT1K_ROW * (4 * q + j); }
+template <bool INV, typename TwPtr>
+RD_HD void fft1k_passC(float2 (&w)[16], int lane, TwPtr tw)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { // stage m=256, fstride 1: k = lane + 64 q
+        const int k = lane + 64 * q;
+        bfly4<INV>(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3], tw[k], tw[2 * k], tw[3 * k]);
+    }
+    // w[4 q + j] is X[lane + 64 q + 256 j]
+}
+
+// ============================================================================================
+// Generic mixed-radix stage (any nfft): butterfly b of the stage with radix p, sub-length m and
+// twiddle stride fstride, operating in place on F (LDS or global).  Positions g*p*m + k + j*m.
+// Radix > 5 is done out of place (src -> dst) because kf_bfly_generic needs all p inputs.
+// ============================================================================================
+struct FftStage { int p, m, fstride; };
+
+// position P of the decimation-in-time leaf copy holds input index n: digits of P over (m_s) map to
+// digits of n over (fstride_s)
+RD_HD int fft_leaf_source(int P, const FftStage *st, int nstages)
+{
+    int n = 0;
+    for (int s = 0; s < nstages; ++s) {
+        int d = P / st[s].m;
+        P -= d * st[s].m;
+        n += d * st[s].fstride;
+    }
+    return n;
+}
+
+// Stage list of a plan: the factor order of the published kissfft (4s, then 2s, then 3, 5, 7, ...;
+// a trial factor above floor(sqrt(n)) is replaced by what is left).  Host side; returns the number
+// of stages or -1 when max_stages is too small.
+inline int fft_plan_stages(int n, FftStage *st, int max_stages)
+{
+    int p = 4, cnt = 0, fstride = 1;
+    const double floor_sqrt = floor(sqrt((double)n));
+    do {
+        while (n % p) {
+            switch (p) {
+            case 4: p = 2; break;
+            case 2: p = 3; break;
+            default: p += 2; break;
+            }
+            if (p > floor_sqrt) p = n;
+        }
+        n /= p;
+        if (cnt >= max_stages) return -1;
+        st[cnt].p = p; st[cnt].m = n; st[cnt].fstride = fstride;
+        fstride *= p;
+        ++cnt;
+    } while (n > 1);
+    return cnt;
+}
+
+template <bool INV, typename Ptr, typename TwPtr>
+RD_HD void fft_stage_butterfly(Ptr F, TwPtr tw, FftStage s, int b)
+{
+    const int g = b / s.m, k = b - g * s.m;
+    const int base = g * s.p * s.m + k;
+    const int m = s.m, fs = s.fstride;
+    if (s.p == 4) {
+        float2 a0 = F[base], a1 = F[base + m], a2 = F[base + 2 * m], a3 = F[base + 3 * m];
+        bfly4<INV>(a0, a1, a2, a3, tw[k * fs], tw[2 * k * fs], tw[3 * k * fs]);
+        F[base] = a0; F[base + m] = a1; F[base + 2 * m] = a2; F[base + 3 * m] = a3;
+    } else if (s.p == 2) {
+        float2 a0 = F[base], a1 = F[base + m];
+        bfly2(a0, a1, tw[k * fs]);
+        F[base] = a0; F[base + m] = a1;
+    } else if (s.p == 3) {
+        float2 a0 = F[base], a1 = F[base + m], a2 = F[base + 2 * m];
+        bfly3(a0, a1, a2, tw[k * fs], tw[2 * k * fs], tw[fs * m]);
+        F[base] = a0; F[base + m] = a1; F[base + 2 * m] = a2;
+    } else { // p == 5
+        float2 a0 = F[base], a1 = F[base + m], a2 = F[base + 2 * m], a3 = F[base + 3 * m], a4 = F[base + 4 * m];
+        bfly5(a0, a1, a2, a3, a4, tw[k * fs], tw[2 * k * fs], tw[3 * k * fs], tw[4 * k * fs], tw[fs * m], tw[fs * 2 * m]);
+        F[base] = a0; F[base + m] = a1; F[base + 2 * m] = a2; F[base + 3 * m] = a3; F[base + 4 * m] = a4;
+    }
+}
+
+// kf_bfly_generic, one OUTPUT element per call: out position base + q1*m of butterfly (g,u).
+// Fout[k] = scratch[0] + sum_{q=1}^{p-1} scratch[q] * tw[(q * fstride * k) mod nfft], accumulated
+// in that order with the running twidx of the published code.
+template <typename SrcPtr, typename TwPtr>
+RD_HD float2 fft_generic_output(SrcPtr src, TwPtr tw, FftStage s, int nfft, int g, int u, int q1)
+{
+    const int base = g * s.p * s.m;
+    const int k = u + q1 * s.m; // index inside this sub-transform, as in the published loop
+    float2 acc = src[base + u];
+    int twidx = 0;
+    for (int q = 1; q < s.p; ++q) {
+        twidx += s.fstride * k;
+        if (twidx >= nfft) twidx -= nfft;
+        float2 t = cmul_rn(src[base + u + q * s.m], tw[twidx]);
+        acc = cadd_rn(acc, t);
+    }
+    return acc;
+}
+
+} // namespace redio

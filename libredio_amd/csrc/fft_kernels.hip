@@ -1,0 +1,123 @@
+// fft_kernels.hip -- gfx950 kernels behind kissfft::fft (src/kissfft/src/kissfft.rs:18-31) and the
+// kiss_fft_* C symbols it binds (:11-16).  Unnormalised in both directions, interleaved cf32,
+// natural-order output; arithmetic order of the published kissfft butterflies (fft_core.h).
+//
+// Bound: HBM (16 B per sample, 5 log2 N flop per sample).  Three data-movement strategies:
+//   fft1k_wave_kernel   N = 1024: one wavefront per transform, 16 points per lane in registers,
+//                       two padded LDS exchanges, no workgroup barrier at all.
+//   fft_lds_kernel      any N that fits LDS: one workgroup per transform, in-place stages in LDS.
+//   fft_global_*        larger N: digit-reversal copy + one launch per stage in global memory.
+#include "redio_internal.h"
+#include "fft_wave.h"
+
+namespace redio {
+
+template <bool INV>
+__global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float2 *out,
+                                                         const float2 *__restrict__ tw, long nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
+    const long b = (long)blockIdx.x * 4 + wave;
+    if (b >= nbatch) return; // wave-uniform
+    fft1k_wave<INV>(in + b * 1024, out + b * 1024, ex, tw, lane);
+}
+
+// ---- any N that fits LDS: one workgroup per transform ----------------------------------------
+template <bool INV>
+__global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2 *in,
+                                                      float2 *out, int two_buffers)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    float2 *B = A + p.nfft;
+    const int n = p.nfft, tid = threadIdx.x, nt = blockDim.x;
+    const float2 *src = in + (long)blockIdx.x * n;
+    float2 *dst = out + (long)blockIdx.x * n;
+    for (int P = tid; P < n; P += nt) A[P] = src[p.leaf_src[P]];
+    __syncthreads();
+    for (int s = p.nstages - 1; s >= 0; --s) {
+        const FftStage st = p.st[s];
+        if (st.p <= 5) {
+            const int nb = n / st.p;
+            for (int b = tid; b < nb; b += nt) fft_stage_butterfly<INV>(A, p.tw, st, b);
+            __syncthreads();
+        } else {
+            // one output element per thread iteration: e = g*p*m + u + q1*m
+            const int pm = st.p * st.m;
+            for (int e = tid; e < n; e += nt) {
+                const int g = e / pm, r = e - g * pm, q1 = r / st.m, u = r - q1 * st.m;
+                B[e] = fft_generic_output(A, p.tw, st, n, g, u, q1);
+            }
+            __syncthreads();
+            float2 *t = A; A = B; B = t;
+        }
+    }
+    (void)two_buffers;
+    for (int P = tid; P < n; P += nt) dst[P] = A[P];
+}
+
+// ---- large N: global-memory stages -----------------------------------------------------------
+__global__ __launch_bounds__(256) void fft_global_leaf_kernel(FftPlanDev p, const float2 *__restrict__ in,
+                                                              float2 *__restrict__ out, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / p.nfft;
+    const int P = (int)(i - b * p.nfft);
+    out[i] = in[b * p.nfft + p.leaf_src[P]];
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256) void fft_global_stage_kernel(FftPlanDev p, int s, float2 *data, long total_bfly)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_bfly) return;
+    const FftStage st = p.st[s];
+    const int nb = p.nfft / st.p;
+    const long b = i / nb;
+    const int bf = (int)(i - b * nb);
+    fft_stage_butterfly<INV>(data + b * p.nfft, p.tw, st, bf);
+}
+
+hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s)
+{
+    if (nbatch <= 0) return hipSuccess;
+    const bool inv = p.inverse != 0;
+    if (p.nfft == 1024) {
+        const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
+        const unsigned grid = (unsigned)((nbatch + 3) / 4);
+        if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch);
+        else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch);
+        return hipGetLastError();
+    }
+    bool generic = false;
+    for (int i = 0; i < p.nstages; ++i) generic |= p.st[i].p > 5;
+    const size_t lds = (size_t)p.nfft * sizeof(float2) * (generic ? 2 : 1);
+    if (lds <= 128 * 1024) {
+        auto kf = fft_lds_kernel<false>;
+        auto ki = fft_lds_kernel<true>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki : kf),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        const int nt = p.nfft >= 1024 ? 256 : (p.nfft >= 256 ? 128 : 64);
+        if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, (int)generic);
+        else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, (int)generic);
+        return hipGetLastError();
+    }
+    if (generic || in == out) return hipErrorNotSupported; // the C-ABI layer routes in-place calls through a temporary
+    const long total = nbatch * p.nfft;
+    hipLaunchKernelGGL(fft_global_leaf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, in, out, total);
+    for (int st = p.nstages - 1; st >= 0; --st) {
+        const long nb = nbatch * (p.nfft / p.st[st].p);
+        const unsigned grid = (unsigned)((nb + 255) / 256);
+        if (inv) hipLaunchKernelGGL(fft_global_stage_kernel<true>, dim3(grid), dim3(256), 0, s, p, st, out, nb);
+        else hipLaunchKernelGGL(fft_global_stage_kernel<false>, dim3(grid), dim3(256), 0, s, p, st, out, nb);
+    }
+    return hipGetLastError();
+}
+
+} // namespace redio

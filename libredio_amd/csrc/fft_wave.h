@@ -1,0 +1,53 @@
+// fft_wave.h -- the one-wavefront 1024-point transform (device only; shared by the batched FFT
+// kernel and the fused FIR->FFT chain kernel).  Index maps and butterflies: fft_core.h.
+#pragma once
+#include "fft_core.h"
+
+namespace redio {
+
+// Orders this wave's LDS accesses as written.  LDS operations of one wavefront execute in issue
+// order, so cross-lane exchange inside a wave needs no s_barrier -- only a compiler fence.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One 1024-point transform by the calling wavefront.  src: natural-order input (global or LDS, may
+// alias ex), ex: FFT1K_LDS float2 of LDS owned by this wave, dst: natural-order output (global).
+template <bool INV, typename SrcPtr>
+__device__ __forceinline__ void fft1k_wave(SrcPtr src, float2 *dst, float2 *ex,
+                                           const float2 *__restrict__ tw, int lane)
+{
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = src[lane + 64 * t];
+    fft1k_passA<INV>(v, tw);
+    wave_lds_fence(); // every lane has read its inputs before anyone overwrites ex
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; ++k3) ex[fft1k_A_store(lane, k3, k4)] = v[k3 + 4 * k4];
+    wave_lds_fence();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = ex[fft1k_B_load(lane, e)];
+    wave_lds_fence();
+    fft1k_passB<INV>(v, lane, tw);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) ex[fft1k_B_store(lane, k1, k2)] = v[k1 + 4 * k2];
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * q + j] = ex[fft1k_C_load(lane, q, j)];
+    fft1k_passC<INV>(v, lane, tw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[lane + 64 * q + 256 * j] = v[4 * q + j];
+}
+
+} // namespace redio

@@ -1,0 +1,50 @@
+// fir_core.h -- register-blocked valid-mode FIR (cross-correlation) for one lane.
+//
+// Arithmetic contract: dsputils::convolve, src/dsputils/src/dsputils.rs:30-32:
+//   out[i] = fold(0.0, +) over j of u[i+j]*v[j]  -- taps NOT reversed, strict left-to-right order.
+// Each accumulator below receives its products in ascending tap order j, so with FUSED=false
+// (separate rounded multiply and add) a result is bit-identical to the reference fold, and with
+// FUSED=true it is bit-identical to the same fold written with fmaf.  Decimation keeps out[D*i].
+//
+// Work split: a lane owns R consecutive kept outputs and walks its (R-1)*D+K input samples once;
+// sample m feeds accumulator r with tap j = m - r*D.  The walk is fully unrolled so every tap index
+// is a compile-time constant (taps are wave-uniform and live in SGPRs), and one LDS read feeds up to
+// min(R, ceil(K/D)) multiply-adds.
+//
+// Host-compilable (tests/emu).
+#pragma once
+#include "redio_device.h"
+
+namespace redio {
+
+template <int K, int D, int R>
+struct FirGeom {
+    static constexpr int LSTR = R * D;             // input samples between neighbouring lanes
+    static constexpr int SPAN = (R - 1) * D + K;   // input samples one lane touches
+    static constexpr bool PAD = (LSTR % 2) == 0;   // LDS lane stride must be odd (in elements) so
+                                                   // that 32 lanes hit 32 different bank pairs
+    // LDS element index of tile-relative input sample n
+    RD_HD static constexpr int lds_index(int n) { return PAD ? n + n / LSTR : n; }
+    RD_HD static constexpr int tile_in(int tile_out) { return (tile_out - 1) * D + K; }
+    RD_HD static constexpr int lds_elems(int tile_out) { return lds_index(tile_in(tile_out) - 1) + 1; }
+};
+
+// lane_first = tile-relative index of the first input sample of this lane's first output
+// (= lane_slot * R * D).  xs is the LDS image written with FirGeom::lds_index.
+template <typename T, int K, int D, int R, bool FUSED, typename LdsPtr, typename TapPtr>
+RD_HD void fir_lane(LdsPtr xs, int lane_slot, TapPtr h, T (&acc)[R])
+{
+    using G = FirGeom<K, D, R>;
+    const int base = lane_slot * (G::LSTR + (G::PAD ? 1 : 0)); // lds_index(lane_slot*LSTR)
+#pragma unroll
+    for (int m = 0; m < G::SPAN; ++m) {
+        const T xv = xs[base + G::lds_index(m)];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = m - r * D;
+            if (j >= 0 && j < K) acc[r] = mac<FUSED>(xv, h[j], acc[r]);
+        }
+    }
+}
+
+} // namespace redio

@@ -1,0 +1,90 @@
+// kissfft_shim.cpp -- libkissfft.so: the C symbols of src/kissfft/src/kissfft.rs:11-16 on top of
+// the redio FFT plan.  See include/kiss_fft.h for the contract.
+#include "../../include/kiss_fft.h"
+#include "../../include/redio.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct kiss_fft_state {
+    int nfft;
+    int inverse;
+    int on_heap;
+    redio_fft *plan;
+    void *d_buf;   // nfft complex on the device
+    void *stream;
+    kiss_fft_cpx *gather; // host scratch for strided input
+};
+
+extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, size_t *lenmem)
+{
+    const size_t need = sizeof(kiss_fft_state);
+    kiss_fft_state *st = NULL;
+    if (lenmem == NULL) {
+        st = (kiss_fft_state *)malloc(need);
+        if (st) st->on_heap = 1;
+    } else {
+        if (mem != NULL && *lenmem >= need) { st = (kiss_fft_state *)mem; st->on_heap = 0; }
+        *lenmem = need;
+    }
+    if (!st) return NULL;
+    st->nfft = nfft; st->inverse = inverse_fft; st->plan = NULL; st->d_buf = NULL; st->stream = NULL; st->gather = NULL;
+    if (nfft <= 0) { if (st->on_heap) free(st); return NULL; }
+    int rc = redio_fft_create(&st->plan, nfft, inverse_fft);
+    if (rc == REDIO_OK) rc = redio_malloc(&st->d_buf, (size_t)nfft * sizeof(kiss_fft_cpx));
+    if (rc == REDIO_OK) rc = redio_stream_create(&st->stream);
+    if (rc != REDIO_OK) {
+        fprintf(stderr, "kiss_fft_alloc(%d): %s\n", nfft, redio_strerror(rc));
+        redio_fft_destroy(st->plan);
+        redio_free(st->d_buf);
+        if (st->on_heap) free(st);
+        return NULL;
+    }
+    return st;
+}
+
+extern "C" void kiss_fft_stride(kiss_fft_cfg st, const kiss_fft_cpx *fin, kiss_fft_cpx *fout, int in_stride)
+{
+    if (!st || !fin || !fout) return;
+    const size_t bytes = (size_t)st->nfft * sizeof(kiss_fft_cpx);
+    const kiss_fft_cpx *src = fin;
+    if (in_stride != 1) {
+        if (!st->gather) st->gather = (kiss_fft_cpx *)malloc(bytes);
+        for (int i = 0; i < st->nfft; ++i) st->gather[i] = fin[(size_t)i * in_stride];
+        src = st->gather;
+    }
+    int rc = redio_upload(st->d_buf, src, bytes, st->stream);
+    if (rc == REDIO_OK) rc = redio_fft_enqueue(st->plan, st->d_buf, st->d_buf, 1, st->stream);
+    if (rc == REDIO_OK) rc = redio_download(fout, st->d_buf, bytes, st->stream);
+    if (rc == REDIO_OK) rc = redio_stream_sync(st->stream);
+    if (rc != REDIO_OK) {
+        fprintf(stderr, "kiss_fft: %s\n", redio_strerror(rc));
+        for (int i = 0; i < st->nfft; ++i) fout[i].r = fout[i].i = NAN;
+    }
+}
+
+extern "C" void kiss_fft(kiss_fft_cfg cfg, const kiss_fft_cpx *fin, kiss_fft_cpx *fout) { kiss_fft_stride(cfg, fin, fout, 1); }
+extern "C" void kiss_fft_cleanup(void) {}
+
+extern "C" int kiss_fft_next_fast_size(int n)
+{
+    for (;; ++n) {
+        int m = n;
+        while ((m % 2) == 0) m /= 2;
+        while ((m % 3) == 0) m /= 3;
+        while ((m % 5) == 0) m /= 5;
+        if (m <= 1) break;
+    }
+    return n;
+}
+
+extern "C" void kiss_fft_free(kiss_fft_cfg st)
+{
+    if (!st) return;
+    redio_fft_destroy(st->plan);
+    redio_free(st->d_buf);
+    redio_stream_destroy(st->stream);
+    free(st->gather);
+    if (st->on_heap) free(st);
+}

@@ -1,0 +1,351 @@
+// redio_api.hip -- host runtime behind include/redio.h: handles, plans, error mapping.  No compute
+// happens on the host: every arithmetic entry point launches a gfx950 kernel or fails.
+#include "../../include/redio.h"
+#include "redio_internal.h"
+#include <math.h>
+#include <mutex>
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace redio;
+
+// ---------------------------------------------------------------- errors
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : REDIO_ERR_HIP_BASE - (int)e; }
+#define RD_TRY(expr)                         \
+    do {                                     \
+        hipError_t _e = (expr);              \
+        if (_e != hipSuccess) return hip_rc(_e); \
+    } while (0)
+
+extern "C" const char *redio_strerror(int code)
+{
+    switch (code) {
+    case REDIO_OK: return "ok";
+    case REDIO_ERR_ARG: return "invalid argument";
+    case REDIO_ERR_NOMEM: return "out of memory";
+    case REDIO_ERR_UNSUPPORTED: return "shape not supported by any kernel";
+    case REDIO_ERR_NO_DEVICE: return "no HIP device available (libredio has no CPU fallback)";
+    case REDIO_ERR_ASSERT: return "the reference would have panicked on this input";
+    default: break;
+    }
+    if (code <= REDIO_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(REDIO_ERR_HIP_BASE - code));
+    return "unknown redio error";
+}
+extern "C" const char *redio_version(void) { return "libredio 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------- device helpers
+extern "C" int redio_device_count(int *count)
+{
+    if (!count) return REDIO_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return REDIO_ERR_NO_DEVICE; }
+    *count = n;
+    return REDIO_OK;
+}
+extern "C" int redio_set_device(int device) { return hip_rc(hipSetDevice(device)); }
+extern "C" int redio_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return REDIO_ERR_ARG;
+    return hip_rc(hipMalloc(dptr, bytes ? bytes : 1));
+}
+extern "C" int redio_free(void *dptr) { return dptr ? hip_rc(hipFree(dptr)) : REDIO_OK; }
+extern "C" int redio_upload(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return REDIO_OK;
+    if (!dst || !src) return REDIO_ERR_ARG;
+    return hip_rc(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+}
+extern "C" int redio_download(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return REDIO_OK;
+    if (!dst || !src) return REDIO_ERR_ARG;
+    return hip_rc(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+}
+extern "C" int redio_stream_create(void **stream)
+{
+    if (!stream) return REDIO_ERR_ARG;
+    hipStream_t s;
+    RD_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return REDIO_OK;
+}
+extern "C" int redio_stream_destroy(void *stream) { return stream ? hip_rc(hipStreamDestroy((hipStream_t)stream)) : REDIO_OK; }
+extern "C" int redio_stream_sync(void *stream) { return hip_rc(hipStreamSynchronize((hipStream_t)stream)); }
+extern "C" int redio_event_create(void **event)
+{
+    if (!event) return REDIO_ERR_ARG;
+    hipEvent_t e;
+    RD_TRY(hipEventCreate(&e));
+    *event = e;
+    return REDIO_OK;
+}
+extern "C" int redio_event_destroy(void *event) { return event ? hip_rc(hipEventDestroy((hipEvent_t)event)) : REDIO_OK; }
+extern "C" int redio_event_record(void *event, void *stream) { return hip_rc(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); }
+extern "C" int redio_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!ms) return REDIO_ERR_ARG;
+    RD_TRY(hipEventSynchronize((hipEvent_t)stop));
+    return hip_rc(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+}
+
+static int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
+
+// ---------------------------------------------------------------- FIR plan
+struct redio_fir {
+    int device;
+    size_t ntaps, decim;
+    unsigned flags;
+    float *d_taps;
+};
+
+extern "C" int redio_fir_create(redio_fir **h, const float *taps, size_t ntaps, size_t decim, unsigned flags)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    if (!taps) return REDIO_ERR_ARG;
+    if (ntaps == 0 || decim == 0) return REDIO_ERR_ASSERT; // windows(0) panics in the reference
+    if (ntaps > (1u << 24)) return REDIO_ERR_UNSUPPORTED;
+    int dev = current_device();
+    if (dev < 0) return REDIO_ERR_NO_DEVICE;
+    redio_fir *p = new (std::nothrow) redio_fir();
+    if (!p) return REDIO_ERR_NOMEM;
+    p->device = dev; p->ntaps = ntaps; p->decim = decim; p->flags = flags; p->d_taps = nullptr;
+    // pad the tap table to a multiple of 16 floats so wide scalar loads never run off the end
+    size_t padded = (ntaps + 15) & ~(size_t)15;
+    std::vector<float> tmp(padded, 0.0f);
+    memcpy(tmp.data(), taps, ntaps * sizeof(float));
+    hipError_t e = hipMalloc((void **)&p->d_taps, padded * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_taps, tmp.data(), padded * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (p->d_taps) hipFree(p->d_taps); delete p; return hip_rc(e); }
+    *h = p;
+    return REDIO_OK;
+}
+extern "C" int redio_fir_destroy(redio_fir *h)
+{
+    if (!h) return REDIO_OK;
+    hipFree(h->d_taps);
+    delete h;
+    return REDIO_OK;
+}
+extern "C" size_t redio_fir_nout(const redio_fir *h, size_t n_in)
+{
+    if (!h || n_in < h->ntaps) return 0;
+    return (n_in - h->ntaps) / h->decim + 1;
+}
+extern "C" int redio_fir_enqueue(redio_fir *h, const void *d_in, size_t n_in, void *d_out, void *stream)
+{
+    if (!h) return REDIO_ERR_ARG;
+    size_t nout = redio_fir_nout(h, n_in);
+    if (nout == 0) return REDIO_OK;
+    if (!d_in || !d_out || d_in == d_out) return REDIO_ERR_ARG;
+    RD_TRY(hipSetDevice(h->device));
+    return hip_rc(launch_fir(d_in, (long)n_in, h->d_taps, (int)h->ntaps, (long)h->decim, d_out, (long)nout,
+                             (h->flags & REDIO_FIR_COMPLEX) != 0, (h->flags & REDIO_FIR_FUSED) != 0, (hipStream_t)stream));
+}
+
+// ---------------------------------------------------------------- A1 host drop-in
+extern "C" int redio_convolve_f32(const float *u, size_t nu, const float *v, size_t nv, float *out, size_t *nout)
+{
+    if (nout) *nout = 0;
+    if (nv == 0) return REDIO_ERR_ASSERT;
+    if (nu < nv) return REDIO_OK;
+    if (!u || !v || !out) return REDIO_ERR_ARG;
+    redio_fir *h = nullptr;
+    int rc = redio_fir_create(&h, v, nv, 1, 0);
+    if (rc) return rc;
+    size_t n = nu - nv + 1;
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, nu * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, u, nu * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = redio_fir_enqueue(h, d_in, nu, d_out, nullptr);
+        if (rc == REDIO_OK) e = hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost); // syncs
+    }
+    if (d_in) hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    redio_fir_destroy(h);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_rc(e);
+    if (nout) *nout = n;
+    return REDIO_OK;
+}
+
+// ---------------------------------------------------------------- FFT plan
+struct redio_fft {
+    int device;
+    FftPlanDev dev;
+    float2 *d_tw;
+    int *d_leaf;
+    float2 *d_tmp; // for in-place calls on the global-memory path
+    size_t tmp_elems;
+};
+
+extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    if (nfft <= 0) return REDIO_ERR_ARG;
+    if (nfft > (1 << 26)) return REDIO_ERR_UNSUPPORTED;
+    int dev = current_device();
+    if (dev < 0) return REDIO_ERR_NO_DEVICE;
+    redio_fft *p = new (std::nothrow) redio_fft();
+    if (!p) return REDIO_ERR_NOMEM;
+    memset(&p->dev, 0, sizeof(p->dev));
+    p->device = dev; p->d_tw = nullptr; p->d_leaf = nullptr; p->d_tmp = nullptr; p->tmp_elems = 0;
+    p->dev.nfft = nfft; p->dev.inverse = inverse ? 1 : 0;
+    p->dev.nstages = fft_plan_stages(nfft, p->dev.st, FFT_MAX_STAGES);
+    if (p->dev.nstages < 0) { delete p; return REDIO_ERR_UNSUPPORTED; }
+    // twiddles evaluated in double and rounded once, phase = -+ 2 pi i / nfft (kiss_fft_alloc)
+    std::vector<float2> tw((size_t)nfft);
+    const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+    for (int i = 0; i < nfft; ++i) {
+        double phase = -2 * pi * i / nfft;
+        if (inverse) phase *= -1;
+        tw[i] = make_float2((float)cos(phase), (float)sin(phase));
+    }
+    std::vector<int> leaf((size_t)nfft);
+    for (int P = 0; P < nfft; ++P) leaf[P] = fft_leaf_source(P, p->dev.st, p->dev.nstages);
+    hipError_t e = hipMalloc((void **)&p->d_tw, (size_t)nfft * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_leaf, (size_t)nfft * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), (size_t)nfft * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_leaf, leaf.data(), (size_t)nfft * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->d_tw) hipFree(p->d_tw);
+        if (p->d_leaf) hipFree(p->d_leaf);
+        delete p;
+        return hip_rc(e);
+    }
+    p->dev.tw = p->d_tw;
+    p->dev.leaf_src = p->d_leaf;
+    *h = p;
+    return REDIO_OK;
+}
+extern "C" int redio_fft_destroy(redio_fft *h)
+{
+    if (!h) return REDIO_OK;
+    hipFree(h->d_tw);
+    hipFree(h->d_leaf);
+    if (h->d_tmp) hipFree(h->d_tmp);
+    delete h;
+    return REDIO_OK;
+}
+extern "C" int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, void *stream)
+{
+    if (!h) return REDIO_ERR_ARG;
+    if (nbatch == 0) return REDIO_OK;
+    if (!d_in || !d_out) return REDIO_ERR_ARG;
+    RD_TRY(hipSetDevice(h->device));
+    hipError_t e = launch_fft(h->dev, (const float2 *)d_in, (float2 *)d_out, (long)nbatch, (hipStream_t)stream);
+    if (e == hipErrorNotSupported && d_in == d_out) {
+        // global-memory path, in place: stage through a plan-owned temporary (grown outside of any
+        // capture; a caller that needs graph capture passes distinct buffers)
+        size_t need = nbatch * (size_t)h->dev.nfft;
+        if (need > h->tmp_elems) {
+            if (h->d_tmp) hipFree(h->d_tmp);
+            h->d_tmp = nullptr; h->tmp_elems = 0;
+            RD_TRY(hipMalloc((void **)&h->d_tmp, need * sizeof(float2)));
+            h->tmp_elems = need;
+        }
+        RD_TRY(hipMemcpyAsync(h->d_tmp, d_in, need * sizeof(float2), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        e = launch_fft(h->dev, h->d_tmp, (float2 *)d_out, (long)nbatch, (hipStream_t)stream);
+    }
+    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
+    return hip_rc(e);
+}
+
+// ---------------------------------------------------------------- chain plan
+struct redio_chain {
+    redio_fir *fir;
+    redio_fft *fft;
+    int nfft;
+    int fused_ok;
+    int force_unfused;
+    float2 *d_mid; // intermediate for the two-kernel path
+    size_t mid_elems;
+};
+
+extern "C" int redio_chain_create(redio_chain **h, const float *taps, size_t ntaps, size_t decim, int nfft, unsigned flags)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    redio_chain *c = new (std::nothrow) redio_chain();
+    if (!c) return REDIO_ERR_NOMEM;
+    memset(c, 0, sizeof(*c));
+    int rc = redio_fir_create(&c->fir, taps, ntaps, decim, flags | REDIO_FIR_COMPLEX);
+    if (rc == REDIO_OK) rc = redio_fft_create(&c->fft, nfft, 0);
+    if (rc) { redio_fir_destroy(c->fir); redio_fft_destroy(c->fft); delete c; return rc; }
+    c->nfft = nfft;
+    c->fused_ok = chain_supported((int)ntaps, (long)decim, nfft) ? 1 : 0;
+    *h = c;
+    return REDIO_OK;
+}
+extern "C" int redio_chain_destroy(redio_chain *h)
+{
+    if (!h) return REDIO_OK;
+    redio_fir_destroy(h->fir);
+    redio_fft_destroy(h->fft);
+    if (h->d_mid) hipFree(h->d_mid);
+    delete h;
+    return REDIO_OK;
+}
+extern "C" size_t redio_chain_nblocks(const redio_chain *h, size_t n_in)
+{
+    if (!h) return 0;
+    return redio_fir_nout(h->fir, n_in) / (size_t)h->nfft;
+}
+extern "C" int redio_chain_is_fused(const redio_chain *h) { return h && h->fused_ok && !h->force_unfused; }
+extern "C" int redio_chain_set_unfused(redio_chain *h, int unfused)
+{
+    if (!h) return REDIO_ERR_ARG;
+    h->force_unfused = unfused ? 1 : 0;
+    return REDIO_OK;
+}
+extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream)
+{
+    if (!h) return REDIO_ERR_ARG;
+    size_t nblk = redio_chain_nblocks(h, n_in);
+    if (nblk == 0) return REDIO_OK;
+    if (!d_in || !d_out || d_in == d_out) return REDIO_ERR_ARG;
+    RD_TRY(hipSetDevice(h->fir->device));
+    const bool fused_math = (h->fir->flags & REDIO_FIR_FUSED) != 0;
+    if (redio_chain_is_fused(h)) {
+        return hip_rc(launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
+                                   (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, (hipStream_t)stream));
+    }
+    // two kernels through a plan-owned intermediate (allocated on first use / growth)
+    size_t ny = nblk * (size_t)h->nfft;
+    if (ny > h->mid_elems) {
+        if (h->d_mid) hipFree(h->d_mid);
+        h->d_mid = nullptr; h->mid_elems = 0;
+        RD_TRY(hipMalloc((void **)&h->d_mid, ny * sizeof(float2)));
+        h->mid_elems = ny;
+    }
+    size_t need_in = (ny - 1) * h->fir->decim + h->fir->ntaps; // inputs feeding the kept blocks
+    RD_TRY(launch_fir(d_in, (long)need_in, h->fir->d_taps, (int)h->fir->ntaps, (long)h->fir->decim, h->d_mid, (long)ny,
+                      true, fused_math, (hipStream_t)stream));
+    hipError_t e = launch_fft(h->fft->dev, h->d_mid, (float2 *)d_out, (long)nblk, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
+    return hip_rc(e);
+}
+
+// ---------------------------------------------------------------- synthetic input
+extern "C" int redio_synth_iq(void *d_out, uint32_t seed, uint64_t first, size_t n, void *stream)
+{
+    if (n && !d_out) return REDIO_ERR_ARG;
+    return hip_rc(launch_synth_iq((float2 *)d_out, seed, first, (long)n, (hipStream_t)stream));
+}
+extern "C" int redio_synth_f32(void *d_out, uint32_t seed, uint64_t first, size_t n, void *stream)
+{
+    if (n && !d_out) return REDIO_ERR_ARG;
+    return hip_rc(launch_synth_f32((float *)d_out, seed, first, (long)n, (hipStream_t)stream));
+}

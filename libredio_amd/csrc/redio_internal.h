@@ -1,0 +1,37 @@
+// redio_internal.h -- launch entry points shared between the kernel files and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "fft_core.h"
+
+namespace redio {
+
+// fir_kernels.hip
+hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D, void *y, long n_out,
+                      bool cplx, bool fused, hipStream_t s);
+
+// fft_kernels.hip
+constexpr int FFT_MAX_STAGES = 32;
+struct FftPlanDev {
+    int nfft;
+    int inverse;
+    int nstages;
+    FftStage st[FFT_MAX_STAGES];
+    const float2 *tw;     // device twiddle table, nfft entries
+    const int *leaf_src;  // device table: leaf position -> input index (digit reversal), nfft entries
+};
+// in != out required unless work is given; work (nfft*nbatch float2) is used for in-place calls and
+// by the global-memory path
+hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s);
+
+// chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
+bool chain_supported(int K, long D, int nfft);
+hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
+                        float2 *out, long nblocks, bool fused, hipStream_t s);
+
+// misc_kernels.hip
+hipError_t launch_synth_iq(float2 *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
+hipError_t launch_synth_f32(float *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
+
+} // namespace redio

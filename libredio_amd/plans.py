@@ -1,0 +1,129 @@
+"""Device-resident plans of include/redio.h driven from torch tensors (torch = device memory and
+streams only).  Inputs/outputs are torch CUDA tensors; kernels are enqueued on torch's current
+stream, nothing synchronises."""
+import ctypes as C
+
+import numpy as np
+
+from . import REDIO_FIR_COMPLEX, REDIO_FIR_FUSED, check, lib
+
+_pf = C.POINTER(C.c_float)
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_ptr(t):
+    assert t.is_cuda and t.is_contiguous(), "device-resident, contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def _taps(taps):
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    return t, t.ctypes.data_as(_pf)
+
+
+class Fir:
+    """redio_fir_*: valid-mode FIR with the fold order of dsputils::convolve (dsputils.rs:30-32),
+    optional decimation, real (float32) or interleaved complex (complex64) streams."""
+
+    def __init__(self, taps, decim=1, complex_input=True, fused=False):
+        t, p = _taps(taps)
+        self.ntaps, self.decim, self.complex_input = len(t), int(decim), complex_input
+        flags = (REDIO_FIR_COMPLEX if complex_input else 0) | (REDIO_FIR_FUSED if fused else 0)
+        self._h = C.c_void_p()
+        check(lib().redio_fir_create(C.byref(self._h), p, len(t), self.decim, flags), "fir_create")
+
+    def nout(self, n_in):
+        return lib().redio_fir_nout(self._h, n_in)
+
+    def __call__(self, x, out=None):
+        import torch
+        want = torch.complex64 if self.complex_input else torch.float32
+        assert x.dtype == want, f"expected {want}"
+        n = self.nout(x.numel())
+        if out is None:
+            out = torch.empty(n, dtype=want, device=x.device)
+        assert out.numel() >= n
+        check(lib().redio_fir_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "fir_enqueue")
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().redio_fir_destroy(self._h)
+            self._h = None
+
+
+class Fft:
+    """redio_fft_*: batched kissfft::fft blocks (kissfft.rs:18-31), unnormalised."""
+
+    def __init__(self, nfft, inverse=False):
+        self.nfft = int(nfft)
+        self._h = C.c_void_p()
+        check(lib().redio_fft_create(C.byref(self._h), self.nfft, int(bool(inverse))), "fft_create")
+
+    def __call__(self, x, out=None):
+        import torch
+        assert x.dtype == torch.complex64 and x.numel() % self.nfft == 0, "messages of exactly nfft samples"
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib().redio_fft_enqueue(self._h, _dev_ptr(x), _dev_ptr(out), x.numel() // self.nfft, current_stream()), "fft_enqueue")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().redio_fft_destroy(self._h)
+            self._h = None
+
+
+class Chain:
+    """redio_chain_*: FIR(ntaps, decimate) -> nfft-point forward FFT over consecutive blocks."""
+
+    def __init__(self, taps, decim, nfft, fused=True):
+        t, p = _taps(taps)
+        self.ntaps, self.decim, self.nfft = len(t), int(decim), int(nfft)
+        self._h = C.c_void_p()
+        check(lib().redio_chain_create(C.byref(self._h), p, len(t), self.decim, self.nfft,
+                                       REDIO_FIR_FUSED if fused else 0), "chain_create")
+
+    def nblocks(self, n_in):
+        return lib().redio_chain_nblocks(self._h, n_in)
+
+    @property
+    def is_fused(self):
+        return bool(lib().redio_chain_is_fused(self._h))
+
+    def set_unfused(self, unfused):
+        check(lib().redio_chain_set_unfused(self._h, int(bool(unfused))), "chain_set_unfused")
+
+    def __call__(self, x, out=None):
+        import torch
+        assert x.dtype == torch.complex64
+        nb = self.nblocks(x.numel())
+        if out is None:
+            out = torch.empty((nb, self.nfft), dtype=torch.complex64, device=x.device)
+        assert out.numel() >= nb * self.nfft
+        check(lib().redio_chain_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "chain_enqueue")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().redio_chain_destroy(self._h)
+            self._h = None
+
+
+def synth_iq(seed, first, n, device="cuda"):
+    """Hash-generated cf32 IQ in [-1,1), generated on the device."""
+    import torch
+    out = torch.empty(n, dtype=torch.complex64, device=device)
+    check(lib().redio_synth_iq(_dev_ptr(out), seed, first, n, current_stream()), "synth_iq")
+    return out
+
+
+def synth_f32(seed, first, n, device="cuda"):
+    import torch
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(lib().redio_synth_f32(_dev_ptr(out), seed, first, n, current_stream()), "synth_f32")
+    return out

@@ -1,0 +1,178 @@
+// emu_kernels.cpp -- CPU emulation of the lane programs in libredio_amd/csrc/{fir,fft}_core.h.
+// There is no GPU in the build container, so the index maps (lane <-> sample, LDS padding, digit
+// order of the three-pass 1024-point transform, generic mixed-radix stages) are exercised here with
+// the very same headers, one lane at a time, against the oracle.  g++ -ffp-contract=off.
+#include "../../libredio_amd/csrc/fft_core.h"
+#include "../../libredio_amd/csrc/fir_core.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace redio;
+
+static std::vector<float2> make_tw(int n, int inverse)
+{
+    std::vector<float2> tw((size_t)n);
+    const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+    for (int i = 0; i < n; ++i) {
+        double phase = -2 * pi * i / n;
+        if (inverse) phase *= -1;
+        tw[i] = make_float2((float)cos(phase), (float)sin(phase));
+    }
+    return tw;
+}
+
+template <bool INV>
+static void emu_fft1k_t(const float2 *in, float2 *out)
+{
+    std::vector<float2> tw = make_tw(1024, INV);
+    std::vector<float2> ex(FFT1K_LDS), ex2(FFT1K_LDS);
+    float2 v[16];
+    for (int lane = 0; lane < 64; ++lane) { // pass A, every lane
+        for (int t = 0; t < 16; ++t) v[t] = in[lane + 64 * t];
+        fft1k_passA<INV>(v, tw.data());
+        for (int k4 = 0; k4 < 4; ++k4)
+            for (int k3 = 0; k3 < 4; ++k3) ex[fft1k_A_store(lane, k3, k4)] = v[k3 + 4 * k4];
+    }
+    for (int lane = 0; lane < 64; ++lane) { // pass B
+        for (int e = 0; e < 16; ++e) v[e] = ex[fft1k_B_load(lane, e)];
+        fft1k_passB<INV>(v, lane, tw.data());
+        for (int k2 = 0; k2 < 4; ++k2)
+            for (int k1 = 0; k1 < 4; ++k1) ex2[fft1k_B_store(lane, k1, k2)] = v[k1 + 4 * k2];
+    }
+    for (int lane = 0; lane < 64; ++lane) { // pass C
+        for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < 4; ++j) v[4 * q + j] = ex2[fft1k_C_load(lane, q, j)];
+        fft1k_passC<INV>(v, lane, tw.data());
+        for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < 4; ++j) out[lane + 64 * q + 256 * j] = v[4 * q + j];
+    }
+}
+
+extern "C" void emu_fft1k(const float2 *in, float2 *out, int inverse)
+{
+    if (inverse) emu_fft1k_t<true>(in, out);
+    else emu_fft1k_t<false>(in, out);
+}
+
+// LDS bank check of the 1024-point exchanges: returns the worst number of distinct addresses that
+// share a bank inside one lane group (1 = conflict free).  group = 16 lanes for ds_write_b64,
+// 32 lanes for ds_read_b64; bank of an 8-byte access = (dword address / 2) % 32 pairs.
+extern "C" int emu_fft1k_bank_conflicts(void)
+{
+    int worst = 1;
+    auto check = [&](int (*addr)(int, int), int nacc, int group) {
+        for (int a = 0; a < nacc; ++a)
+            for (int g0 = 0; g0 < 64; g0 += group) {
+                int cnt[32] = {0};
+                for (int l = g0; l < g0 + group; ++l) cnt[addr(l, a) % 32]++;
+                for (int b = 0; b < 32; ++b) if (cnt[b] > worst) worst = cnt[b];
+            }
+    };
+    check([](int l, int a) { return fft1k_A_store(l, a & 3, a >> 2); }, 16, 16);
+    check([](int l, int a) { return fft1k_B_load(l, a); }, 16, 32);
+    check([](int l, int a) { return fft1k_B_store(l, a & 3, a >> 2); }, 16, 16);
+    check([](int l, int a) { return fft1k_C_load(l, a >> 2, a & 3); }, 16, 32);
+    return worst;
+}
+
+extern "C" int emu_fft_generic(int n, int inverse, const float2 *in, float2 *out)
+{
+    FftStage st[32];
+    int ns = fft_plan_stages(n, st, 32);
+    if (ns < 0) return -1;
+    std::vector<float2> tw = make_tw(n, inverse);
+    std::vector<float2> A((size_t)n), B((size_t)n);
+    for (int P = 0; P < n; ++P) A[P] = in[fft_leaf_source(P, st, ns)];
+    for (int s = ns - 1; s >= 0; --s) {
+        if (st[s].p <= 5) {
+            for (int b = 0; b < n / st[s].p; ++b) {
+                if (inverse) fft_stage_butterfly<true>(A.data(), tw.data(), st[s], b);
+                else fft_stage_butterfly<false>(A.data(), tw.data(), st[s], b);
+            }
+        } else {
+            const int pm = st[s].p * st[s].m;
+            for (int e = 0; e < n; ++e) {
+                const int g = e / pm, r = e - g * pm, q1 = r / st[s].m, u = r - q1 * st[s].m;
+                B[e] = fft_generic_output(A.data(), tw.data(), st[s], n, g, u, q1);
+            }
+            A.swap(B);
+        }
+    }
+    memcpy(out, A.data(), (size_t)n * sizeof(float2));
+    return ns;
+}
+
+// one workgroup tile of the tiled FIR kernel: padded LDS image + fir_lane per thread
+template <typename T, int K, int D, int R, bool FUSED>
+static long emu_fir_tiles(const T *x, long n_in, const float *taps, T *y)
+{
+    using G = FirGeom<K, D, R>;
+    constexpr int NT = 256, TILE_OUT = NT * R, TILE_IN = G::tile_in(TILE_OUT);
+    const long n_out = n_in < K ? 0 : (n_in - K) / D + 1;
+    std::vector<T> xs((size_t)G::lds_elems(TILE_OUT));
+    for (long tile = 0; tile * TILE_OUT < n_out; ++tile) {
+        const long in0 = tile * (long)TILE_OUT * D;
+        for (int n = 0; n < TILE_IN; ++n) {
+            T v{};
+            if (in0 + n < n_in) v = x[in0 + n];
+            xs[(size_t)G::lds_index(n)] = v;
+        }
+        for (int tid = 0; tid < NT; ++tid) {
+            T acc[R];
+            for (int r = 0; r < R; ++r) acc[r] = T{};
+            fir_lane<T, K, D, R, FUSED>(xs.data(), tid, taps, acc);
+            for (int r = 0; r < R; ++r) {
+                const long o = tile * (long)TILE_OUT + (long)tid * R + r;
+                if (o < n_out) y[o] = acc[r];
+            }
+        }
+    }
+    return n_out;
+}
+
+extern "C" long emu_fir_c32(const float2 *x, long n_in, const float *taps, int K, int D, int fused, float2 *y)
+{
+    if (K == 127 && D == 5) return fused ? emu_fir_tiles<float2, 127, 5, 4, true>(x, n_in, taps, y) : emu_fir_tiles<float2, 127, 5, 4, false>(x, n_in, taps, y);
+    if (K == 127 && D == 1) return fused ? emu_fir_tiles<float2, 127, 1, 8, true>(x, n_in, taps, y) : emu_fir_tiles<float2, 127, 1, 8, false>(x, n_in, taps, y);
+    if (K == 63 && D == 1) return fused ? emu_fir_tiles<float2, 63, 1, 8, true>(x, n_in, taps, y) : emu_fir_tiles<float2, 63, 1, 8, false>(x, n_in, taps, y);
+    if (K == 63 && D == 5) return fused ? emu_fir_tiles<float2, 63, 5, 4, true>(x, n_in, taps, y) : emu_fir_tiles<float2, 63, 5, 4, false>(x, n_in, taps, y);
+    return -1;
+}
+
+extern "C" long emu_fir_f32(const float *x, long n_in, const float *taps, int K, int D, int fused, float *y)
+{
+    if (K == 127 && D == 5) return fused ? emu_fir_tiles<float, 127, 5, 4, true>(x, n_in, taps, y) : emu_fir_tiles<float, 127, 5, 4, false>(x, n_in, taps, y);
+    if (K == 63 && D == 1) return fused ? emu_fir_tiles<float, 63, 1, 8, true>(x, n_in, taps, y) : emu_fir_tiles<float, 63, 1, 8, false>(x, n_in, taps, y);
+    return -1;
+}
+
+// FIR LDS bank check: 32 lanes reading sample m of their window must hit 32 different banks
+// (ds_read_b64 over 64 banks for float2, ds_read_b32 over 32 banks for float)
+template <int K, int D, int R>
+static int fir_banks(int elem_dwords)
+{
+    using G = FirGeom<K, D, R>;
+    int worst = 1;
+    const int nb = 64 / elem_dwords; // distinct element slots per bank row (b64: 32; b32 uses 32 banks)
+    for (int m = 0; m < G::SPAN; ++m) {
+        int cnt[64] = {0};
+        for (int l = 0; l < 32; ++l) {
+            int idx = l * (G::LSTR + (G::PAD ? 1 : 0)) + G::lds_index(m);
+            cnt[idx % (elem_dwords == 2 ? nb : 32)]++;
+        }
+        for (int b = 0; b < 64; ++b) if (cnt[b] > worst) worst = cnt[b];
+    }
+    return worst;
+}
+extern "C" int emu_fir_bank_conflicts(void)
+{
+    int w = 1, t;
+    if ((t = fir_banks<127, 5, 4>(2)) > w) w = t;
+    if ((t = fir_banks<127, 1, 8>(2)) > w) w = t;
+    if ((t = fir_banks<63, 1, 8>(2)) > w) w = t;
+    if ((t = fir_banks<63, 5, 4>(2)) > w) w = t;
+    if ((t = fir_banks<127, 5, 4>(1)) > w) w = t;
+    if ((t = fir_banks<63, 1, 8>(1)) > w) w = t;
+    return w;
+}

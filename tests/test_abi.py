@@ -1,0 +1,64 @@
+"""The C-ABI libraries load without a GPU and export every symbol include/*.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b((?:redio_|kiss_fft|src_)[a-z0-9_]*)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_redio_h_symbols(redio):
+    L = C.CDLL(redio.LIBREDIO)
+    names = declared("redio.h")
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(L, n), f"libredio.so does not export {n}"
+
+
+def test_kiss_fft_h_symbols(redio):
+    K = redio.kisslib()
+    names = [n for n in declared("kiss_fft.h") if n.startswith("kiss_fft")]
+    assert {"kiss_fft_alloc", "kiss_fft", "kiss_fft_cleanup"} <= set(names)  # kissfft.rs:13-15
+    for n in names:
+        assert hasattr(K, n), f"libkissfft.so does not export {n}"
+
+
+def test_no_cpu_fallback_without_device(redio):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    n = C.c_int(-1)
+    assert redio.lib().redio_device_count(C.byref(n)) == -4 and n.value == 0
+    with pytest.raises(redio.RedioError):
+        redio.dsputils.convolve([1.0, 2.0, 3.0], [1.0])
+    assert redio.kisslib().kiss_fft_alloc(64, 0, None, None) is None
+
+
+def test_errors_have_text(redio):
+    for code in (0, -1, -2, -3, -4, -5, -1001):
+        assert redio.lib().redio_strerror(code)
+
+
+def test_host_tap_generators_match_oracle(redio, oracle):
+    import numpy as np
+    for m in (4, 63, 64, 127):
+        for a, b in ((redio.dsputils.window(m), oracle.window(m)),
+                     (redio.dsputils.sinc(m, 0.1), oracle.sinc(m, 0.1)),
+                     (redio.dsputils.lpf(m, 0.1), oracle.lpf(m, 0.1)),
+                     (redio.dsputils.hpf(m, 0.2), oracle.hpf(m, 0.2)),
+                     (redio.dsputils.bsf(m, 0.1, 0.2), oracle.bsf(m, 0.1, 0.2)),
+                     (redio.dsputils.bpf(m, 0.1, 0.2), oracle.bpf(m, 0.1, 0.2)),
+                     (redio.dsputils.lpf_corrected(m, 0.08), oracle.lpf_corrected(m, 0.08))):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # NaN-aware: compare bits
+    with pytest.raises(redio.RedioError):
+        redio.dsputils.sinc(8, 0.5)
+    with pytest.raises(redio.RedioError):
+        redio.dsputils.hpf(1, 0.1)

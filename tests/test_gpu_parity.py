@@ -1,0 +1,222 @@
+"""Parity of the HIP path (through the C ABI) against the oracle -- the parity tests proper.
+
+Bar: bit-exact.  The FIR kernels accumulate in the reference's tap order (dsputils.rs:31); in
+reference rounding (mul, add) they must equal the oracle's fold bit for bit, in fused rounding they
+must equal the same fold written with fmaf.  The FFT kernels keep the published kissfft butterfly
+order, so spectra must equal oracle_kiss.c bit for bit.  Tolerance vs float64 numpy is also checked
+and written down where it is used.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+# ---------------------------------------------------------------- synthetic input
+def test_synth_matches_host_hash(gpu, redio, oracle):
+    for first, n in ((0, 1000), (12345, 4097), ((1 << 32) - 5, 64)):
+        assert same_bits(redio.synth_iq(0x5EED0002, first, n).cpu().numpy(), oracle.synth_iq(0x5EED0002, first, n))
+        assert same_bits(redio.synth_f32(7, first, n).cpu().numpy(), oracle.synth_f32(7, first, n))
+
+
+# ---------------------------------------------------------------- A1 convolve (host drop-in)
+@pytest.mark.parametrize("nu,nv", [(1, 1), (63, 63), (64, 63), (1024, 63), (1024, 127), (5000, 3), (4096, 200), (10, 11)])
+def test_convolve_host_bit_exact(gpu, redio, oracle, nu, nv):
+    u = oracle.synth_f32(1, 0, nu)
+    v = oracle.synth_f32(2, 0, nv)
+    got = redio.dsputils.convolve(u, v)
+    want = oracle.convolve(u, v)
+    assert same_bits(got, want)
+
+
+def test_convolve_empty_taps_is_the_reference_panic(gpu, redio):
+    with pytest.raises(redio.RedioError) as e:
+        redio.dsputils.convolve([1.0, 2.0], [])
+    assert e.value.code == -5  # REDIO_ERR_ASSERT: windows(0) panics in the reference
+
+
+def test_convolve_with_quirk_lpf_taps_nan_position(gpu, redio, oracle):
+    # lpf() as written has NaN at tap 1: every output that touches it is NaN
+    taps = redio.dsputils.lpf(63, 0.1)
+    assert np.isnan(taps[1]) and np.isnan(taps).sum() == 1
+    u = oracle.synth_f32(3, 0, 300)
+    got, want = redio.dsputils.convolve(u, taps), oracle.convolve(u, oracle.lpf(63, 0.1))
+    assert np.isnan(got).all() and np.isnan(want).all() and len(got) == len(want)
+
+
+# ---------------------------------------------------------------- device FIR
+FIR_CASES = [(127, 5), (127, 1), (63, 1), (63, 5), (3, 1), (33, 2), (200, 7), (1, 1)]
+
+
+@pytest.mark.parametrize("k,d", FIR_CASES)
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_fir_bit_exact(gpu, redio, oracle, k, d, fused, cplx):
+    taps = oracle.synth_f32(11, 0, k) if k not in (63, 127) else oracle.lpf_corrected(k, 0.08)
+    for n in (k, k + 1, 4096 * d + k - 1, 20000, 33333):
+        x = oracle.synth_iq(5, 0, n) if cplx else oracle.synth_f32(5, 0, n)
+        plan = redio.Fir(taps, d, complex_input=cplx, fused=fused)
+        got = plan(gpu.from_numpy(x).cuda()).cpu().numpy()
+        want = oracle.fir(x, taps, d, fused)
+        assert same_bits(got, want), (k, d, fused, cplx, n)
+
+
+def test_fir_short_input_is_empty(gpu, redio, oracle):
+    plan = redio.Fir(oracle.lpf_corrected(63, 0.1), 1)
+    assert plan.nout(62) == 0 and plan.nout(63) == 1
+    assert plan(gpu.zeros(10, dtype=gpu.complex64, device="cuda")).numel() == 0
+
+
+def test_fir_fused_vs_reference_rounding_tolerance(gpu, redio, oracle):
+    # fused (fmaf) deviates from the reference fold by at most K * eps * sum|x*h| per output
+    taps = oracle.lpf_corrected(127, 0.08)
+    x = oracle.synth_iq(9, 0, 50000)
+    a = redio.Fir(taps, 5, fused=True)(gpu.from_numpy(x).cuda()).cpu().numpy()
+    b = oracle.fir(x, taps, 5, fused=False)
+    bound = 127 * 2.0 ** -24 * np.abs(taps).sum()  # |x| < 1
+    assert np.abs(a - b).max() <= bound
+    ref = np.correlate(x.astype(np.complex128), taps.astype(np.float64), "valid")[::5]
+    assert np.abs(a - ref).max() <= bound
+
+
+def test_fir_decimate_is_stride_of_full(gpu, redio, oracle):
+    taps = oracle.lpf_corrected(127, 0.08)
+    x = gpu.from_numpy(oracle.synth_iq(4, 0, 30000)).cuda()
+    full = redio.Fir(taps, 1)(x).cpu().numpy()
+    dec = redio.Fir(taps, 5)(x).cpu().numpy()
+    assert same_bits(dec, full[::5][: len(dec)])
+
+
+# ---------------------------------------------------------------- FFT
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 30, 64, 100, 128, 243, 256, 1000, 1024, 2048, 4096, 8192, 11, 221])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_bit_exact(gpu, redio, oracle, n, inverse):
+    nb = 5
+    x = oracle.synth_iq(n, 0, n * nb)
+    got = redio.Fft(n, inverse)(gpu.from_numpy(x).cuda()).cpu().numpy()
+    want = oracle.fft(x, n, inverse)
+    assert same_bits(got, want), (n, inverse)
+
+
+@pytest.mark.parametrize("n", [16384, 65536])
+def test_fft_large_global_path(gpu, redio, oracle, n):
+    x = oracle.synth_iq(n, 0, n * 2)
+    d = gpu.from_numpy(x).cuda()
+    got = redio.Fft(n, False)(d).cpu().numpy()
+    assert same_bits(got, oracle.fft(x, n, False))
+    # tolerance vs float64: relative L2 <= 2e-6
+    ref = np.fft.fft(x.astype(np.complex128).reshape(2, n), axis=1).reshape(-1)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 2e-6
+    # in place
+    redio.Fft(n, False)(d, out=d)
+    assert same_bits(d.cpu().numpy(), got)
+
+
+def test_fft1024_many_blocks_and_inplace(gpu, redio, oracle):
+    x = oracle.synth_iq(77, 0, 1024 * 37)
+    d = gpu.from_numpy(x).cuda()
+    plan = redio.Fft(1024)
+    want = oracle.fft(x, 1024)
+    assert same_bits(plan(d).cpu().numpy(), want)
+    plan(d, out=d)
+    assert same_bits(d.cpu().numpy(), want)
+
+
+def test_fft_roundtrip_is_n_times_identity(gpu, redio, oracle):
+    # kissfft is unnormalised in both directions: ifft(fft(x)) = N x
+    x = oracle.synth_iq(8, 0, 1024 * 4)
+    d = gpu.from_numpy(x).cuda()
+    y = redio.Fft(1024, True)(redio.Fft(1024, False)(d)).cpu().numpy()
+    assert np.abs(y / 1024 - x).max() <= 1e-5
+
+
+def test_kiss_fft_dropin_symbols(gpu, redio, oracle):
+    # the three C symbols the reference's Rust binds (kissfft.rs:13-15), host buffers, synchronous
+    from libredio_amd import kissfft
+    for n, inv in ((1024, 0), (64, 1), (30, 0)):
+        cfg = kissfft.Cfg(n, inv)
+        x = oracle.synth_iq(n + inv, 0, n)
+        assert same_bits(cfg(x), oracle.fft(x, n, bool(inv)))
+        # in place (fin == fout)
+        buf = x.copy()
+        redio.kisslib().kiss_fft(cfg._cfg, buf.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p))
+        assert same_bits(buf, oracle.fft(x, n, bool(inv)))
+        cfg.close()
+    redio.kisslib().kiss_fft_cleanup()
+
+
+def test_kissfft_block_function(gpu, redio, oracle):
+    import queue
+    import threading
+    from libredio_amd import kissfft
+    pin, cout = queue.Queue(), queue.Queue()
+    t = threading.Thread(target=kissfft.fft, args=(pin, cout, 256, 0))
+    t.start()
+    msgs = [oracle.synth_iq(i, 0, 256) for i in range(4)]
+    for m in msgs:
+        pin.put(m)
+    pin.put(None)
+    t.join()
+    for m in msgs:
+        assert same_bits(cout.get(), oracle.fft(m, 256))
+
+
+# ---------------------------------------------------------------- C2 chain
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("nblocks", [1, 3, 4, 5, 9])
+def test_chain_bit_exact(gpu, redio, oracle, fused, nblocks):
+    taps = oracle.lpf_corrected(127, 0.08)
+    n = nblocks * 1024 * 5 + 126 + 3  # a few samples that do not complete a block are dropped
+    x = oracle.synth_iq(0x5EED0002, 0, n)
+    d = gpu.from_numpy(x).cuda()
+    chain = redio.Chain(taps, 5, 1024, fused=fused)
+    assert chain.is_fused and chain.nblocks(n) == nblocks
+    want = oracle.chain_fir_fft(x, taps, 5, 1024, fused=fused)
+    got = chain(d).cpu().numpy()
+    assert same_bits(got, want)
+    chain.set_unfused(True)  # FIR kernel + FFT kernel through an intermediate: same bits
+    assert same_bits(chain(d).cpu().numpy(), want)
+
+
+def test_chain_other_shape_runs_unfused(gpu, redio, oracle):
+    taps = oracle.lpf_corrected(63, 0.1)
+    x = oracle.synth_iq(3, 0, 64 * 2 * 10 + 62)
+    chain = redio.Chain(taps, 2, 64, fused=False)
+    assert not chain.is_fused
+    got = chain(gpu.from_numpy(x).cuda()).cpu().numpy()
+    assert same_bits(got, oracle.chain_fir_fft(x, taps, 2, 64, fused=False))
+
+
+def test_chain_full_size_properties(gpu, redio, oracle):
+    """BASELINE.json configs[1] at full size (2^28 samples): size-independent properties.
+    (a) the first and last blocks equal the oracle on just their own input window (tile independence);
+    (b) linearity: chain(a*x) == a*chain(x) exactly for a power of two;
+    (c) a checksum of checksums is reproducible run to run."""
+    taps = oracle.lpf_corrected(127, 0.08)
+    n = 1 << 28
+    x = redio.synth_iq(0x5EED0002, 0, n)
+    chain = redio.Chain(taps, 5, 1024, fused=True)
+    nb = chain.nblocks(n)
+    assert nb == ((n - 127) // 5 + 1) // 1024
+    out = chain(x)
+    for b in (0, 1, nb // 2, nb - 1):
+        lo = b * 5120
+        xw = oracle.synth_iq(0x5EED0002, lo, 5120 + 126)
+        want = oracle.chain_fir_fft(xw, taps, 5, 1024, fused=True)[0]
+        assert same_bits(out[b].cpu().numpy(), want), b
+    s1 = gpu.view_as_real(out).view(gpu.int32).sum(dtype=gpu.int64).item()
+    out2 = chain(x * 4.0)
+    assert gpu.equal(out2, out * 4.0)
+    out3 = chain(x)
+    s3 = gpu.view_as_real(out3).view(gpu.int32).sum(dtype=gpu.int64).item()
+    assert s1 == s3
