@@ -45,21 +45,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(log2n):
-    """The oracle port of the reference path, one thread, on a bounded prefix of the same workload."""
-    import numpy as np
+def cpu_baseline(log2n, min_seconds=12.0, max_chunks=256):
+    """The oracle port of the reference path, one thread, on a bounded prefix of the same workload:
+    consecutive 2^log2n-sample slices (each with its FIR halo) until ~min_seconds of CPU work."""
     import oracle as O
     n = 1 << log2n
-    x = O.synth_iq(SEED, 0, n)
     taps = O.lpf_corrected(NTAPS, FC)
-    O.chain_fir_fft(x[: 8192 * DECIM + NTAPS], taps, DECIM, NFFT)  # page in / warm
-    t0 = time.perf_counter()
-    out = O.chain_fir_fft(x, taps, DECIM, NFFT, fused=False)
-    dt = time.perf_counter() - t0
-    used = out.shape[0] * NFFT * DECIM
-    return {"value": used / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
-            "sample": f"first 2^{log2n} samples of the same hash-generated stream, oracle/ C port "
-                      f"(scalar, strict-order FIR + kissfft restatement), {dt:.2f} s on 1 of {os.cpu_count()} host cores"}
+    O.chain_fir_fft(O.synth_iq(SEED, 0, 8192 * DECIM + NTAPS), taps, DECIM, NFFT)  # page in / warm
+    used, busy, chunks = 0, 0.0, 0
+    while busy < min_seconds and chunks < max_chunks:
+        x = O.synth_iq(SEED, used, n)  # generation is not timed
+        t0 = time.perf_counter()
+        out = O.chain_fir_fft(x, taps, DECIM, NFFT, fused=False)
+        busy += time.perf_counter() - t0
+        used += out.shape[0] * NFFT * DECIM
+        chunks += 1
+    return {"value": used / busy / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
+            "sample": f"first {used} samples ({chunks} x 2^{log2n}) of the same hash-generated stream through the "
+                      f"oracle/ C port (scalar strict-order FIR + kissfft restatement, gcc -O2, no FMA), "
+                      f"{busy:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
 def main():
