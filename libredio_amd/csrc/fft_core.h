@@ -217,11 +217,11 @@ RD_HD void fft_stage_butterfly(Ptr F, TwPtr tw, FftStage s, int b)
         float2 a0 = F[base], a1 = F[base + m], a2 = F[base + 2 * m];
         bfly3(a0, a1, a2, tw[k * fs], tw[2 * k * fs], tw[fs * m]);
         F[base] = a0; F[base + m] = a1; F[base + 2 * m] = a2;
-    } else { // p == 5
+    } else if (s.p == 5) {
         float2 a0 = F[base], a1 = F[base + m], a2 = F[base + 2 * m], a3 = F[base + 3 * m], a4 = F[base + 4 * m];
         bfly5(a0, a1, a2, a3, a4, tw[k * fs], tw[2 * k * fs], tw[3 * k * fs], tw[4 * k * fs], tw[fs * m], tw[fs * 2 * m]);
         F[base] = a0; F[base + m] = a1; F[base + 2 * m] = a2; F[base + 3 * m] = a3; F[base + 4 * m] = a4;
-    }
+    } // p == 1 (nfft == 1): kf_bfly_generic with one input is the identity
 }
 
 // kf_bfly_generic, one OUTPUT element per call: out position base + q1*m of butterfly (g,u).
