@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (default 2^28 = 2 GiB)")
     ap.add_argument("--unfused", action="store_true", help="run FIR and FFT as two kernels (12.8 B/sample)")
     ap.add_argument("--exact", action="store_true", help="reference rounding (mul+add) instead of fmaf in the FIR")
+    ap.add_argument("--variant", type=int, default=0, help="fused kernel generation (0 = current, 1 = first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2-samples", type=int, default=25)
     ap.add_argument("--traffic-json", default=None, help="file with {'traffic': bytes_per_launch} from the PMC passes")
@@ -92,6 +93,7 @@ def main():
     chain = R.Chain(taps, DECIM, NFFT, fused=not a.exact)
     if a.unfused:
         chain.set_unfused(True)
+    chain.set_variant(a.variant)
     nblk = chain.nblocks(n)
     used = nblk * NFFT * DECIM  # input samples that contribute to a spectrum
     # rank r owns the slice that starts at decimated block r*nblk of the global stream
@@ -151,7 +153,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single f32 IQ stream, 1024-pt FFT + 127-tap FIR decimate-by-5",
                        "samples_per_gpu": n, "ntaps": NTAPS, "decim": DECIM, "nfft": NFFT,
-                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else "chain_fir_fft1k_kernel (fused)",
+                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else ("chain_v2_kernel (fused)" if a.variant == 0 else "chain_fir_fft1k_kernel (fused, first generation)"),
                        "fir_rounding": "mul+add (reference)" if a.exact else "fmaf, reference order",
                        "parallelism": f"time-sliced replicas x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -88,6 +88,7 @@ def lib():
     _sig(L.redio_chain_nblocks, sz, vp, sz)
     _sig(L.redio_chain_is_fused, i, vp)
     _sig(L.redio_chain_set_unfused, i, vp, i)
+    _sig(L.redio_chain_set_variant, i, vp, i)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
     _sig(L.redio_synth_iq, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _sig(L.redio_synth_f32, i, vp, C.c_uint32, C.c_uint64, sz, vp)

@@ -10,6 +10,7 @@
 #include "fir_tile.h"
 #include "fft_wave.h"
 #include "redio_internal.h"
+#include <type_traits>
 
 namespace redio {
 
@@ -52,7 +53,151 @@ __global__ __launch_bounds__(256) void chain_fir_fft1k_kernel(const float2 *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2: wave-autonomous FIR + persistent grid.
+//   * Each wavefront owns a private LDS image of the 1402 input samples behind its 256 outputs of a
+//     block (the four waves of a workgroup split a 1024-sample block), so the FIR phase has no
+//     workgroup barrier: load -> wave fence -> compute.
+//   * The next sub-tile is fetched into registers (11 x 16 B per lane) BEFORE the current one is
+//     computed and written to LDS after it, so HBM latency hides behind the 508 packed FMAs.
+//   * Windows are read with ds_read_b128 (two samples per read; FirGeomV lane stride 22 float2).
+//   * A workgroup walks groups of four blocks with a grid stride; after four FIR tiles two adjacent
+//     barriers hand the four blocks to the four waves, one 1024-point transform each, with the
+//     wave's own (now idle) input image as exchange scratch.  The fourth block is parked in the idle
+//     input images instead of a fourth block buffer, which is what lets two workgroups share a CU.
+// ---------------------------------------------------------------------------------------------
+// native 16-byte vector: struct-typed float4 copies lower to memcpy and keep arrays in scratch
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int K, int D, bool FUSED>
+__global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
+                                                          const float2 *__restrict__ tw, float2 *__restrict__ out,
+                                                          long nblocks)
+{
+    constexpr int R = 4;
+    using G = FirGeomV<K, D, R>;
+    constexpr int SUB_OUT = 64 * R;               // outputs per wave per block
+    constexpr int SUB_IN = G::tile_in(SUB_OUT);   // input samples behind them
+    static_assert(SUB_IN % 2 == 0 && 4 * SUB_OUT == 1024, "geometry");
+    constexpr int SUB_V = SUB_IN / 2;             // float4 loads per sub-tile
+    constexpr int NLD = (SUB_V + 63) / 64;        // per lane
+    constexpr int XS4 = (G::lds_elems(SUB_OUT) > FFT1K_LDS ? G::lds_elems(SUB_OUT) : FFT1K_LDS) / 2; // float4 per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4f *xs_all = reinterpret_cast<v4f *>(smem);            // [4][XS4]
+    float2 *yb = reinterpret_cast<float2 *>(xs_all + 4 * XS4);    // [3][1024]
+
+    // wave index as a scalar: every block-dependent address becomes SGPR base + lane offset
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    v4f *xs4 = xs_all + wave * XS4;
+    const long ngroups = (nblocks + 3) >> 2;
+    long g = blockIdx.x;
+    if (g >= ngroups) return; // whole workgroup
+
+    v4f pre[NLD];
+    auto fetch = [&](long blk) {
+        const v4f *src = reinterpret_cast<const v4f *>(x + (blk * 1024 + wave * SUB_OUT) * (long)D) + lane;
+        static_for<NLD - 1>([&](auto I) { pre[I.value] = src[64 * I.value]; });
+        if (lane + 64 * (NLD - 1) < SUB_V) pre[NLD - 1] = src[64 * (NLD - 1)];
+    };
+    auto park = [&]() { // registers -> this wave's LDS image
+        static_for<NLD - 1>([&](auto I) { xs4[G::lds_index(2 * (lane + 64 * I.value)) / 2] = pre[I.value]; });
+        if (lane + 64 * (NLD - 1) < SUB_V) xs4[G::lds_index(2 * (lane + 64 * (NLD - 1))) / 2] = pre[NLD - 1];
+    };
+
+    fetch(4 * g); // the first block of a group always exists
+    park();
+    wave_lds_fence();
+    for (; g < ngroups; g += gridDim.x) {
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            const long blk = 4 * g + t;
+            const long nxt = (t < 3) ? blk + 1 : 4 * (g + gridDim.x);
+            if (nxt < nblocks) fetch(nxt);
+            if (blk < nblocks) {
+                float2 acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+                fir_lane_v<K, D, R, FUSED>(xs4, lane, taps, acc);
+                wave_lds_fence(); // window reads done before the image is reused
+                v4f *yt = (t < 3) ? reinterpret_cast<v4f *>(yb + t * 1024 + wave * SUB_OUT) + 2 * lane
+                                  : xs4 + 2 * lane; // block 3 lives in the idle input images
+                yt[0] = v4f{acc[0].x, acc[0].y, acc[1].x, acc[1].y};
+                yt[1] = v4f{acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+            }
+            if (t < 3) {
+                if (nxt < nblocks) park();
+                wave_lds_fence();
+            }
+        }
+        __syncthreads(); // the group's four blocks are complete
+        const long blk = 4 * g + wave;
+        float2 v[16];
+        if (blk < nblocks) {
+            if (wave < 3) {
+                const float2 *src = yb + wave * 1024;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = src[lane + 64 * q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    v[q] = reinterpret_cast<const float2 *>(xs_all + (q >> 2) * XS4)[lane + 64 * (q & 3)];
+            }
+        }
+        __syncthreads(); // every block is in registers: images and block buffers are free again
+        // the 27 per-lane twiddles are re-read (L1/L2 hits) every group: hoisting them out of the
+        // persistent loop would pin 54 VGPRs across the FIR phase and spill
+        const float2 *twg = tw;
+        asm volatile("" : "+s"(twg));
+        if (blk < nblocks) fft1k_wave_regs<false>(v, out + blk * 1024, reinterpret_cast<float2 *>(xs4), twg, lane);
+        wave_lds_fence();
+        if (4 * (g + gridDim.x) < nblocks) park();
+        wave_lds_fence();
+    }
+}
+
 bool chain_supported(int K, long D, int nfft) { return nfft == 1024 && K == 127 && D == 5; }
+
+static int num_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int K, int D>
+static hipError_t launch_chain_v2(const FftPlanDev &p, const float2 *x, const float *taps, float2 *out,
+                                  long nblocks, bool fused, hipStream_t s)
+{
+    using G = FirGeomV<K, D, 4>;
+    constexpr int XS4 = (G::lds_elems(256) > FFT1K_LDS ? G::lds_elems(256) : FFT1K_LDS) / 2;
+    constexpr size_t LDS = (size_t)4 * XS4 * sizeof(float4) + 3 * 1024 * sizeof(float2);
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    auto kf = chain_v2_kernel<K, D, true>;
+    auto ke = chain_v2_kernel<K, D, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused ? kf : ke),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return e;
+    const long ngroups = (nblocks + 3) / 4;
+    long grid = 2L * num_cus();
+    if (grid > ngroups) grid = ngroups;
+    if (fused) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), LDS, s, x, taps, p.tw, out, nblocks);
+    else hipLaunchKernelGGL(ke, dim3((unsigned)grid), dim3(256), LDS, s, x, taps, p.tw, out, nblocks);
+    return hipGetLastError();
+}
 
 template <int K, int D>
 static hipError_t launch_chain_t(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, float2 *out,
@@ -75,11 +220,15 @@ static hipError_t launch_chain_t(const FftPlanDev &p, const float2 *x, long n_in
 }
 
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
-                        float2 *out, long nblocks, bool fused, hipStream_t s)
+                        float2 *out, long nblocks, bool fused, int variant, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    if (p.nfft == 1024 && !p.inverse && K == 127 && D == 5)
+    if (p.nfft == 1024 && !p.inverse && K == 127 && D == 5) {
+        // v2 needs 16-byte aligned input (every sub-tile starts on an even sample)
+        if (variant != 1 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+            return launch_chain_v2<127, 5>(p, x, taps, out, nblocks, fused, s);
         return launch_chain_t<127, 5>(p, x, n_in, taps, out, nblocks, fused, s);
+    }
     return hipErrorNotSupported;
 }
 

@@ -14,15 +14,13 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One 1024-point transform by the calling wavefront.  src: natural-order input (global or LDS, may
-// alias ex), ex: FFT1K_LDS float2 of LDS owned by this wave, dst: natural-order output (global).
-template <bool INV, typename SrcPtr>
-__device__ __forceinline__ void fft1k_wave(SrcPtr src, float2 *dst, float2 *ex,
-                                           const float2 *__restrict__ tw, int lane)
+// Everything after the input load of a 1024-point transform by the calling wavefront: v[t] holds
+// x[lane + 64 t] on entry.  ex: FFT1K_LDS float2 of LDS owned by this wave; dst: natural-order
+// output in global memory.
+template <bool INV>
+__device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], float2 *dst, float2 *ex,
+                                                const float2 *__restrict__ tw, int lane)
 {
-    float2 v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = src[lane + 64 * t];
     fft1k_passA<INV>(v, tw);
     wave_lds_fence(); // every lane has read its inputs before anyone overwrites ex
 #pragma unroll
@@ -48,6 +46,18 @@ __device__ __forceinline__ void fft1k_wave(SrcPtr src, float2 *dst, float2 *ex,
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[lane + 64 * q + 256 * j] = v[4 * q + j];
+}
+
+// One 1024-point transform by the calling wavefront.  src: natural-order input (global or LDS, may
+// alias ex).
+template <bool INV, typename SrcPtr>
+__device__ __forceinline__ void fft1k_wave(SrcPtr src, float2 *dst, float2 *ex,
+                                           const float2 *__restrict__ tw, int lane)
+{
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = src[lane + 64 * t];
+    fft1k_wave_regs<INV>(v, dst, ex, tw, lane);
 }
 
 } // namespace redio

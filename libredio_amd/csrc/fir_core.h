@@ -48,3 +48,44 @@ RD_HD void fir_lane(LdsPtr xs, int lane_slot, TapPtr h, T (&acc)[R])
 }
 
 } // namespace redio
+
+// ---------------------------------------------------------------------------------------------
+// Variant for interleaved cf32 with 16-byte LDS reads: a lane's window is read two samples at a time
+// (ds_read_b128), which needs every lane base 16-byte aligned and, for the four 16-lane groups of
+// ds_read_b128 to be conflict-free, a lane stride S (in float2) with S/2 odd.
+// ---------------------------------------------------------------------------------------------
+namespace redio {
+
+template <int K, int D, int R>
+struct FirGeomV {
+    static constexpr int LSTR = R * D;
+    static_assert(LSTR % 2 == 0, "16-byte windows need an even lane stride");
+    static constexpr int SPAN = (R - 1) * D + K;
+    static constexpr int PADN = ((LSTR / 2) % 2 == 1) ? 0 : 2; // make (LSTR+PADN)/2 odd
+    static constexpr int LANE_STRIDE = LSTR + PADN;
+    RD_HD static constexpr int lds_index(int n) { return n + PADN * (n / LSTR); }
+    RD_HD static constexpr int tile_in(int tile_out) { return (tile_out - 1) * D + K; }
+    // float2 elements, rounded up to an even count (whole float4s)
+    RD_HD static constexpr int lds_elems(int tile_out) { return (lds_index(tile_in(tile_out) - 1) + 2) & ~1; }
+};
+
+// xs4: the LDS image viewed as float4 (two cf32 samples each), written with FirGeomV::lds_index.
+template <int K, int D, int R, bool FUSED, typename Lds4Ptr, typename TapPtr>
+RD_HD void fir_lane_v(Lds4Ptr xs4, int lane_slot, TapPtr h, float2 (&acc)[R])
+{
+    using G = FirGeomV<K, D, R>;
+    const int base4 = lane_slot * (G::LANE_STRIDE / 2);
+#pragma unroll
+    for (int m = 0; m < G::SPAN; m += 2) {
+        const auto q = xs4[base4 + G::lds_index(m) / 2]; // any 4-float type with .x .y .z .w
+        const float2 x0 = make_float2(q.x, q.y), x1 = make_float2(q.z, q.w);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j0 = m - r * D, j1 = m + 1 - r * D;
+            if (j0 >= 0 && j0 < K) acc[r] = mac<FUSED>(x0, h[j0], acc[r]);
+            if (j1 >= 0 && j1 < K && m + 1 < G::SPAN) acc[r] = mac<FUSED>(x1, h[j1], acc[r]);
+        }
+    }
+}
+
+} // namespace redio

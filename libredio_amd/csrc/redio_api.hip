@@ -270,6 +270,7 @@ struct redio_chain {
     int nfft;
     int fused_ok;
     int force_unfused;
+    int variant; // 0 = best fused kernel, 1 = first-generation fused kernel (kept for A/B runs)
     float2 *d_mid; // intermediate for the two-kernel path
     size_t mid_elems;
 };
@@ -310,6 +311,12 @@ extern "C" int redio_chain_set_unfused(redio_chain *h, int unfused)
     h->force_unfused = unfused ? 1 : 0;
     return REDIO_OK;
 }
+extern "C" int redio_chain_set_variant(redio_chain *h, int variant)
+{
+    if (!h || variant < 0 || variant > 1) return REDIO_ERR_ARG;
+    h->variant = variant;
+    return REDIO_OK;
+}
 extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream)
 {
     if (!h) return REDIO_ERR_ARG;
@@ -320,7 +327,7 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     const bool fused_math = (h->fir->flags & REDIO_FIR_FUSED) != 0;
     if (redio_chain_is_fused(h)) {
         return hip_rc(launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
-                                   (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, (hipStream_t)stream));
+                                   (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, h->variant, (hipStream_t)stream));
     }
     // two kernels through a plan-owned intermediate (allocated on first use / growth)
     size_t ny = nblk * (size_t)h->nfft;

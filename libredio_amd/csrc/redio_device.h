@@ -19,6 +19,7 @@
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
 #endif
 
 namespace redio {

@@ -98,6 +98,10 @@ class Chain:
     def set_unfused(self, unfused):
         check(lib().redio_chain_set_unfused(self._h, int(bool(unfused))), "chain_set_unfused")
 
+    def set_variant(self, variant):
+        """Kernel generation of the fused path (A/B measurement): 0 = current, 1 = first."""
+        check(lib().redio_chain_set_variant(self._h, int(variant)), "chain_set_variant")
+
     def __call__(self, x, out=None):
         import torch
         assert x.dtype == torch.complex64

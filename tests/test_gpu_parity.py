@@ -173,7 +173,7 @@ def test_kissfft_block_function(gpu, redio, oracle):
 
 # ---------------------------------------------------------------- C2 chain
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("nblocks", [1, 3, 4, 5, 9])
+@pytest.mark.parametrize("nblocks", [1, 3, 4, 5, 9, 2051])
 def test_chain_bit_exact(gpu, redio, oracle, fused, nblocks):
     taps = oracle.lpf_corrected(127, 0.08)
     n = nblocks * 1024 * 5 + 126 + 3  # a few samples that do not complete a block are dropped
@@ -184,6 +184,9 @@ def test_chain_bit_exact(gpu, redio, oracle, fused, nblocks):
     want = oracle.chain_fir_fft(x, taps, 5, 1024, fused=fused)
     got = chain(d).cpu().numpy()
     assert same_bits(got, want)
+    chain.set_variant(1)  # first-generation fused kernel
+    assert same_bits(chain(d).cpu().numpy(), want)
+    chain.set_variant(0)
     chain.set_unfused(True)  # FIR kernel + FFT kernel through an intermediate: same bits
     assert same_bits(chain(d).cpu().numpy(), want)
 
