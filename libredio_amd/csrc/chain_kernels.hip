@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
                 float2 acc[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
-                fir_lane_v<K, D, R, FUSED>(xs4, lane, taps, acc);
+                int lf = lane; // opaque per tile: keeps LDS address arithmetic out of the persistent loop's live set
+                asm volatile("" : "+v"(lf));
+                fir_lane_v<K, D, R, FUSED>(xs4, lf, taps, acc);
                 wave_lds_fence(); // window reads done before the image is reused
                 v4f *yt = (t < 3) ? reinterpret_cast<v4f *>(yb + t * 1024 + wave * SUB_OUT) + 2 * lane
                                   : xs4 + 2 * lane; // block 3 lives in the idle input images
@@ -141,15 +143,17 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
         __syncthreads(); // the group's four blocks are complete
         const long blk = 4 * g + wave;
         float2 v[16];
+        int ln = lane; // opaque per group, same reason
+        asm volatile("" : "+v"(ln));
         if (blk < nblocks) {
             if (wave < 3) {
                 const float2 *src = yb + wave * 1024;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = src[lane + 64 * q];
+                for (int q = 0; q < 16; ++q) v[q] = src[ln + 64 * q];
             } else {
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    v[q] = reinterpret_cast<const float2 *>(xs_all + (q >> 2) * XS4)[lane + 64 * (q & 3)];
+                    v[q] = reinterpret_cast<const float2 *>(xs_all + (q >> 2) * XS4)[ln + 64 * (q & 3)];
             }
         }
         __syncthreads(); // every block is in registers: images and block buffers are free again
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
         // persistent loop would pin 54 VGPRs across the FIR phase and spill
         const float2 *twg = tw;
         asm volatile("" : "+s"(twg));
-        if (blk < nblocks) fft1k_wave_regs<false>(v, out + blk * 1024, reinterpret_cast<float2 *>(xs4), twg, lane);
+        if (blk < nblocks) fft1k_wave_regs<false>(v, out + blk * 1024, reinterpret_cast<float2 *>(xs4), twg, ln);
         wave_lds_fence();
         if (4 * (g + gridDim.x) < nblocks) park();
         wave_lds_fence();

@@ -14,6 +14,7 @@
 // Host-compilable (tests/emu).
 #pragma once
 #include "redio_device.h"
+#include <type_traits>
 
 namespace redio {
 
@@ -69,23 +70,67 @@ struct FirGeomV {
     RD_HD static constexpr int lds_elems(int tile_out) { return (lds_index(tile_in(tile_out) - 1) + 2) & ~1; }
 };
 
-// xs4: the LDS image viewed as float4 (two cf32 samples each), written with FirGeomV::lds_index.
+// xs4: the LDS image viewed as 16-byte elements (two cf32 samples each), written with
+// FirGeomV::lds_index.  The window is consumed in chunks of CH reads with the next chunk's reads
+// issued before the current chunk's multiply-adds and a scheduling barrier between chunks: LDS
+// latency hides behind ~100 packed FMAs while only two chunks of samples are ever live in
+// registers (an unconstrained schedule hoists dozens of reads and spills).
+template <int N, typename F>
+RD_HD void fir_static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        fir_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int c, int K, int D, int R, bool FUSED, int CH, typename Q, typename Lds4Ptr, typename TapPtr>
+RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH], float2 (&acc)[R])
+{
+    using G = FirGeomV<K, D, R>;
+    constexpr int NRD = (G::SPAN + 1) / 2; // 16-byte reads in a window
+    constexpr int NCH = (NRD + CH - 1) / CH;
+    if constexpr (c < NCH) {
+        fir_static_for<CH>([&](auto I) { // issue the next chunk's reads first
+            constexpr int i = (c + 1) * CH + I.value;
+            if constexpr (i < NRD) q[(c + 1) & 1][I.value] = xs4[base4 + G::lds_index(2 * i) / 2];
+        });
+        fir_static_for<CH>([&](auto I) {
+            constexpr int m = 2 * (c * CH + I.value);
+            if constexpr (m < G::SPAN) {
+                const Q v = q[c & 1][I.value];
+                const float2 x0 = make_float2(v.x, v.y), x1 = make_float2(v.z, v.w);
+                fir_static_for<R>([&](auto RR) {
+                    constexpr int r = RR.value;
+                    constexpr int j0 = m - r * D, j1 = m + 1 - r * D;
+                    if constexpr (j0 >= 0 && j0 < K) acc[r] = mac<FUSED>(x0, h[j0], acc[r]);
+                    if constexpr (j1 >= 0 && j1 < K && m + 1 < G::SPAN) acc[r] = mac<FUSED>(x1, h[j1], acc[r]);
+                });
+            }
+        });
+        // pin the accumulators here: without a data dependency the compiler sinks every multiply-add
+        // below the last read and the chunking is lost
+#pragma unroll
+        for (int r = 0; r < R; ++r) RD_PIN2(acc[r].x, acc[r].y);
+        RD_SCHED_BARRIER();
+        fir_chunks_v<c + 1, K, D, R, FUSED, CH>(xs4, base4, h, q, acc);
+    }
+}
+
 template <int K, int D, int R, bool FUSED, typename Lds4Ptr, typename TapPtr>
 RD_HD void fir_lane_v(Lds4Ptr xs4, int lane_slot, TapPtr h, float2 (&acc)[R])
 {
     using G = FirGeomV<K, D, R>;
+    using Q = typename std::remove_cv<typename std::remove_reference<decltype(xs4[0])>::type>::type;
+    constexpr int NRD = (G::SPAN + 1) / 2;
+    constexpr int CH = 8; // reads per chunk
     const int base4 = lane_slot * (G::LANE_STRIDE / 2);
-#pragma unroll
-    for (int m = 0; m < G::SPAN; m += 2) {
-        const auto q = xs4[base4 + G::lds_index(m) / 2]; // any 4-float type with .x .y .z .w
-        const float2 x0 = make_float2(q.x, q.y), x1 = make_float2(q.z, q.w);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int j0 = m - r * D, j1 = m + 1 - r * D;
-            if (j0 >= 0 && j0 < K) acc[r] = mac<FUSED>(x0, h[j0], acc[r]);
-            if (j1 >= 0 && j1 < K && m + 1 < G::SPAN) acc[r] = mac<FUSED>(x1, h[j1], acc[r]);
-        }
-    }
+    Q q[2][CH];
+    fir_static_for<CH>([&](auto I) {
+        constexpr int i = I.value;
+        if constexpr (i < NRD) q[0][i] = xs4[base4 + G::lds_index(2 * i) / 2];
+    });
+    fir_chunks_v<0, K, D, R, FUSED, CH>(xs4, base4, h, q, acc);
 }
 
 } // namespace redio

@@ -22,6 +22,14 @@ static inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define RD_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+#else
+#define RD_SCHED_BARRIER() ((void)0)
+#define RD_PIN2(a, b) ((void)0)
+#endif
+
 namespace redio {
 
 // one rounding per operation, never contracted (reference semantics: Rust / plain-cc kissfft)
