@@ -12,6 +12,10 @@
 #include "redio_internal.h"
 #include <type_traits>
 
+#ifndef REDIO_CHAIN_RELOAD_TWIDDLES
+#define REDIO_CHAIN_RELOAD_TWIDDLES 0
+#endif
+
 namespace redio {
 
 template <int K, int D, bool FUSED>
@@ -113,6 +117,8 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
         if (lane + 64 * (NLD - 1) < SUB_V) xs4[G::lds_index(2 * (lane + 64 * (NLD - 1))) / 2] = pre[NLD - 1];
     };
 
+    Fft1kTw twl; // lane-dependent twiddles: loaded once, live in registers across the persistent loop
+    fft1k_load_tw(twl, lane, tw);
     fetch(4 * g); // the first block of a group always exists
     park();
     wave_lds_fence();
@@ -157,11 +163,10 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
             }
         }
         __syncthreads(); // every block is in registers: images and block buffers are free again
-        // the 27 per-lane twiddles are re-read (L1/L2 hits) every group: hoisting them out of the
-        // persistent loop would pin 54 VGPRs across the FIR phase and spill
-        const float2 *twg = tw;
-        asm volatile("" : "+s"(twg));
-        if (blk < nblocks) fft1k_wave_regs<false>(v, out + blk * 1024, reinterpret_cast<float2 *>(xs4), twg, ln);
+#if REDIO_CHAIN_RELOAD_TWIDDLES
+        fft1k_load_tw(twl, ln, tw); // re-read the 27 per-lane twiddles every group (L1/L2 hits)
+#endif
+        if (blk < nblocks) fft1k_wave_regs<false>(v, out + blk * 1024, reinterpret_cast<float2 *>(xs4), tw, twl, ln);
         wave_lds_fence();
         if (4 * (g + gridDim.x) < nblocks) park();
         wave_lds_fence();

@@ -123,34 +123,50 @@ RD_HD int fft1k_A_store(int lane, int k3, int k4) { return (lane & 3) + 4 * k4 +
 
 // Pass B.  lane = d0 + 4 k4 + 16 k3 (the L1 column) holds u[e], e = d1 + 4 d2 (the L1 row).
 RD_HD int fft1k_B_load(int lane, int e) { return lane + FFT1K_ROW * e; }
-template <bool INV, typename TwPtr>
-RD_HD void fft1k_passB(float2 (&u)[16], int lane, TwPtr tw)
+// The 27 lane-dependent twiddles of passes B and C (pass A's are wave-uniform).  A persistent
+// kernel loads them once per lane and keeps them in registers.
+struct Fft1kTw {
+    float2 b[15]; // [0..2] stage m=16; [3 + 3*k2 .. ] stage m=64
+    float2 c[12]; // [3*q ..] stage m=256
+};
+template <typename TwPtr>
+RD_HD void fft1k_load_tw(Fft1kTw &t, int lane, TwPtr tw)
 {
-    const int k = lane >> 2; // k4 + 4 k3
-    {
-        const float2 t1 = tw[16 * k], t2 = tw[32 * k], t3 = tw[48 * k]; // stage m=16, fstride 16
+    const int k = lane >> 2; // pass B lane = d0 + 4 k4 + 16 k3  ->  k = k4 + 4 k3
+    t.b[0] = tw[16 * k]; t.b[1] = tw[32 * k]; t.b[2] = tw[48 * k];
 #pragma unroll
-        for (int d1 = 0; d1 < 4; ++d1) bfly4<INV>(u[d1], u[d1 + 4], u[d1 + 8], u[d1 + 12], t1, t2, t3);
-    }
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) { // stage m=64, fstride 4: k = k4 + 4 k3 + 16 k2
+    for (int k2 = 0; k2 < 4; ++k2) {
         const int kk = k + 16 * k2;
-        bfly4<INV>(u[4 * k2], u[4 * k2 + 1], u[4 * k2 + 2], u[4 * k2 + 3], tw[4 * kk], tw[8 * kk], tw[12 * kk]);
+        t.b[3 + 3 * k2] = tw[4 * kk]; t.b[4 + 3 * k2] = tw[8 * kk]; t.b[5 + 3 * k2] = tw[12 * kk];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { // pass C lane = k4 + 4 k3 + 16 k2  ->  k = lane + 64 q
+        const int kc = lane + 64 * q;
+        t.c[3 * q] = tw[kc]; t.c[3 * q + 1] = tw[2 * kc]; t.c[3 * q + 2] = tw[3 * kc];
+    }
+}
+
+template <bool INV>
+RD_HD void fft1k_passB(float2 (&u)[16], const Fft1kTw &t)
+{
+#pragma unroll
+    for (int d1 = 0; d1 < 4; ++d1) // stage m=16, fstride 16: k = k4 + 4 k3
+        bfly4<INV>(u[d1], u[d1 + 4], u[d1 + 8], u[d1 + 12], t.b[0], t.b[1], t.b[2]);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) // stage m=64, fstride 4: k = k4 + 4 k3 + 16 k2
+        bfly4<INV>(u[4 * k2], u[4 * k2 + 1], u[4 * k2 + 2], u[4 * k2 + 3], t.b[3 + 3 * k2], t.b[4 + 3 * k2], t.b[5 + 3 * k2]);
     // now u[k1 + 4 k2]
 }
 RD_HD int fft1k_B_store(int lane, int k1, int k2) { return (lane >> 2) + 16 * k2 + FFT1K_ROW * (4 * k1 + (lane & 3)); }
 
 // Pass C.  lane = k4 + 4 k3 + 16 k2 (the L2 column) holds w[4 q + j], q = k1, j = d0 (the L2 row).
 RD_HD int fft1k_C_load(int lane, int q, int j) { return lane + FFT1K_ROW * (4 * q + j); }
-template <bool INV, typename TwPtr>
-RD_HD void fft1k_passC(float2 (&w)[16], int lane, TwPtr tw)
+template <bool INV>
+RD_HD void fft1k_passC(float2 (&w)[16], const Fft1kTw &t)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { // stage m=256, fstride 1: k = lane + 64 q
-        const int k = lane + 64 * q;
-        bfly4<INV>(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3], tw[k], tw[2 * k], tw[3 * k]);
-    }
+    for (int q = 0; q < 4; ++q) // stage m=256, fstride 1: k = lane + 64 q
+        bfly4<INV>(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3], t.c[3 * q], t.c[3 * q + 1], t.c[3 * q + 2]);
     // w[4 q + j] is X[lane + 64 q + 256 j]
 }
 

@@ -19,7 +19,7 @@ __device__ __forceinline__ void wave_lds_fence()
 // output in global memory.
 template <bool INV>
 __device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], float2 *dst, float2 *ex,
-                                                const float2 *__restrict__ tw, int lane)
+                                                const float2 *__restrict__ tw, const Fft1kTw &t, int lane)
 {
     fft1k_passA<INV>(v, tw);
     wave_lds_fence(); // every lane has read its inputs before anyone overwrites ex
@@ -31,7 +31,7 @@ __device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], float2 *dst, fl
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = ex[fft1k_B_load(lane, e)];
     wave_lds_fence();
-    fft1k_passB<INV>(v, lane, tw);
+    fft1k_passB<INV>(v, t);
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2)
 #pragma unroll
@@ -41,7 +41,7 @@ __device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], float2 *dst, fl
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * q + j] = ex[fft1k_C_load(lane, q, j)];
-    fft1k_passC<INV>(v, lane, tw);
+    fft1k_passC<INV>(v, t);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -57,7 +57,9 @@ __device__ __forceinline__ void fft1k_wave(SrcPtr src, float2 *dst, float2 *ex,
     float2 v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = src[lane + 64 * t];
-    fft1k_wave_regs<INV>(v, dst, ex, tw, lane);
+    Fft1kTw t;
+    fft1k_load_tw(t, lane, tw);
+    fft1k_wave_regs<INV>(v, dst, ex, tw, t, lane);
 }
 
 } // namespace redio

@@ -84,16 +84,33 @@ RD_HD void fir_static_for(F &&f)
     }
 }
 
+// Taps needed by chunk c: samples m in [2*CH*c, 2*CH*(c+1)) feed output r with tap j = m - r*D, so
+// j spans [2*CH*c - (R-1)*D, 2*CH*(c+1) - 1], clipped to [0, K).
+template <int K, int D, int R, int CH>
+struct FirChunkTaps {
+    static constexpr int NT = 2 * CH + (R - 1) * D; // taps a chunk can touch
+    RD_HD static constexpr int lo(int c) { return 2 * CH * c - (R - 1) * D; }
+};
+
 template <int c, int K, int D, int R, bool FUSED, int CH, typename Q, typename Lds4Ptr, typename TapPtr>
-RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH], float2 (&acc)[R])
+RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH],
+                        float (&hb)[2][FirChunkTaps<K, D, R, CH>::NT], float2 (&acc)[R])
 {
     using G = FirGeomV<K, D, R>;
+    using T = FirChunkTaps<K, D, R, CH>;
     constexpr int NRD = (G::SPAN + 1) / 2; // 16-byte reads in a window
     constexpr int NCH = (NRD + CH - 1) / CH;
     if constexpr (c < NCH) {
-        fir_static_for<CH>([&](auto I) { // issue the next chunk's reads first
+        // everything this chunk consumes was requested one chunk ago; naming one tap and one sample
+        // here makes the single lgkmcnt(0) land BEFORE the next chunk's requests are issued
+        RD_PIN_SV(hb[c & 1][T::NT - 1], q[c & 1][0]);
+        fir_static_for<CH>([&](auto I) { // the next chunk's samples (LDS) ...
             constexpr int i = (c + 1) * CH + I.value;
             if constexpr (i < NRD) q[(c + 1) & 1][I.value] = xs4[base4 + G::lds_index(2 * i) / 2];
+        });
+        fir_static_for<T::NT>([&](auto J) { // ... and taps (scalar cache)
+            constexpr int j = T::lo(c + 1) + J.value;
+            if constexpr (c + 1 < NCH && j >= 0 && j < K) hb[(c + 1) & 1][J.value] = h[j];
         });
         fir_static_for<CH>([&](auto I) {
             constexpr int m = 2 * (c * CH + I.value);
@@ -103,17 +120,17 @@ RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH], float2 
                 fir_static_for<R>([&](auto RR) {
                     constexpr int r = RR.value;
                     constexpr int j0 = m - r * D, j1 = m + 1 - r * D;
-                    if constexpr (j0 >= 0 && j0 < K) acc[r] = mac<FUSED>(x0, h[j0], acc[r]);
-                    if constexpr (j1 >= 0 && j1 < K && m + 1 < G::SPAN) acc[r] = mac<FUSED>(x1, h[j1], acc[r]);
+                    if constexpr (j0 >= 0 && j0 < K) acc[r] = mac<FUSED>(x0, hb[c & 1][j0 - T::lo(c)], acc[r]);
+                    if constexpr (j1 >= 0 && j1 < K && m + 1 < G::SPAN) acc[r] = mac<FUSED>(x1, hb[c & 1][j1 - T::lo(c)], acc[r]);
                 });
             }
         });
-        // pin the accumulators here: without a data dependency the compiler sinks every multiply-add
-        // below the last read and the chunking is lost
+        // pin the accumulators: without a data dependency the compiler sinks every multiply-add below
+        // the last read and the chunking is lost
 #pragma unroll
-        for (int r = 0; r < R; ++r) RD_PIN2(acc[r].x, acc[r].y);
+        for (int r = 0; r < R; ++r) RD_PIN_F2(acc[r]);
         RD_SCHED_BARRIER();
-        fir_chunks_v<c + 1, K, D, R, FUSED, CH>(xs4, base4, h, q, acc);
+        fir_chunks_v<c + 1, K, D, R, FUSED, CH>(xs4, base4, h, q, hb, acc);
     }
 }
 
@@ -124,13 +141,20 @@ RD_HD void fir_lane_v(Lds4Ptr xs4, int lane_slot, TapPtr h, float2 (&acc)[R])
     using Q = typename std::remove_cv<typename std::remove_reference<decltype(xs4[0])>::type>::type;
     constexpr int NRD = (G::SPAN + 1) / 2;
     constexpr int CH = 8; // reads per chunk
+    using T = FirChunkTaps<K, D, R, CH>;
     const int base4 = lane_slot * (G::LANE_STRIDE / 2);
     Q q[2][CH];
+    float hb[2][T::NT];
+    fir_static_for<T::NT>([&](auto J) { // last slot is always written so that it can be pinned
+        constexpr int j = T::lo(0) + J.value;
+        hb[0][J.value] = (j >= 0 && j < K) ? h[j] : 0.0f;
+        hb[1][J.value] = 0.0f;
+    });
     fir_static_for<CH>([&](auto I) {
         constexpr int i = I.value;
         if constexpr (i < NRD) q[0][i] = xs4[base4 + G::lds_index(2 * i) / 2];
     });
-    fir_chunks_v<0, K, D, R, FUSED, CH>(xs4, base4, h, q, acc);
+    fir_chunks_v<0, K, D, R, FUSED, CH>(xs4, base4, h, q, hb, acc);
 }
 
 } // namespace redio

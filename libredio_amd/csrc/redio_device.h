@@ -24,10 +24,21 @@ static inline float4 make_float4(float x, float y, float z, float w) { float4 r 
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#define RD_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+// pins a float2 as ONE 64-bit register pair (two scalar operands would break v_pk_* formation)
+#define RD_PIN_F2(a)                                        \
+    do {                                                    \
+        redio_v2f _t = {(a).x, (a).y};                      \
+        asm volatile("" : "+v"(_t) : : "memory");           \
+        (a).x = _t.x;                                       \
+        (a).y = _t.y;                                       \
+    } while (0)
+typedef float redio_v2f __attribute__((ext_vector_type(2)));
+// names a wave-uniform value and a vector value as inputs of an ordered, memory-clobbering statement
+#define RD_PIN_SV(s, v) asm volatile("" : : "s"(s), "v"(v) : "memory")
 #else
 #define RD_SCHED_BARRIER() ((void)0)
-#define RD_PIN2(a, b) ((void)0)
+#define RD_PIN_F2(a) ((void)0)
+#define RD_PIN_SV(s, v) ((void)0)
 #endif
 
 namespace redio {

@@ -36,14 +36,18 @@ static void emu_fft1k_t(const float2 *in, float2 *out)
     }
     for (int lane = 0; lane < 64; ++lane) { // pass B
         for (int e = 0; e < 16; ++e) v[e] = ex[fft1k_B_load(lane, e)];
-        fft1k_passB<INV>(v, lane, tw.data());
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw.data());
+        fft1k_passB<INV>(v, t);
         for (int k2 = 0; k2 < 4; ++k2)
             for (int k1 = 0; k1 < 4; ++k1) ex2[fft1k_B_store(lane, k1, k2)] = v[k1 + 4 * k2];
     }
     for (int lane = 0; lane < 64; ++lane) { // pass C
         for (int q = 0; q < 4; ++q)
             for (int j = 0; j < 4; ++j) v[4 * q + j] = ex2[fft1k_C_load(lane, q, j)];
-        fft1k_passC<INV>(v, lane, tw.data());
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw.data());
+        fft1k_passC<INV>(v, t);
         for (int q = 0; q < 4; ++q)
             for (int j = 0; j < 4; ++j) out[lane + 64 * q + 256 * j] = v[4 * q + j];
     }
