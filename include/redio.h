@@ -104,7 +104,7 @@ size_t redio_chain_nblocks(const redio_chain *h, size_t n_in);
 int redio_chain_is_fused(const redio_chain *h);
 /* force the two-kernel path (for measurement): 0 = fused when available, 1 = never fused */
 int redio_chain_set_unfused(redio_chain *h, int unfused);
-/* kernel generation of the fused path, for A/B measurement: 0 = current (default), 1 = first */
+/* kernel generation of the fused path, for A/B measurement: 0 = current (default), 1 = first, 2 = second */
 int redio_chain_set_variant(redio_chain *h, int variant);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
 

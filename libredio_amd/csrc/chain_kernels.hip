@@ -173,6 +173,130 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: one wavefront per 1024-sample block, no workgroup at all.
+//   * The wave runs the four FIR sub-tiles of ITS OWN block back to back and keeps the 16 results per
+//     lane in registers: a[4 s + r] = y[256 s + 4 lane + r].  That is exactly the operand layout of
+//     the "native" transform in fft_core.h, whose first and last stages are register-only -- so the
+//     decimated block is never written to or read from LDS, there is no block buffer and no barrier.
+//   * LDS per wave = one 1402-sample input image (12.3 KB), reused as the transform's exchange
+//     scratch; twelve waves fit a CU.
+//   * Input prefetch into registers one sub-tile ahead (across block boundaries too), tap and window
+//     double buffering as in v2.
+// ---------------------------------------------------------------------------------------------
+// ABLATE (timing-only builds, wrong results): 1 = skip the FIR multiply-adds, 2 = skip the transform,
+// 4 = fetch only the very first sub-tile from HBM.  Reached through redio_chain_set_variant(10 + mask).
+template <int K, int D, bool FUSED, int WPS, int CH, int ABLATE = 0>
+__global__ __launch_bounds__(64, WPS) void chain_v3_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
+                                                         const float2 *__restrict__ tw, float2 *__restrict__ out,
+                                                         long nblocks)
+{
+    constexpr int R = 4;
+    using G = FirGeomV<K, D, R>;
+    constexpr int SUB_OUT = 64 * R;
+    constexpr int SUB_IN = G::tile_in(SUB_OUT);
+    static_assert(SUB_IN % 2 == 0 && 4 * SUB_OUT == 1024, "geometry");
+    constexpr int SUB_V = SUB_IN / 2;
+    constexpr int NLD = (SUB_V + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4f *xs4 = reinterpret_cast<v4f *>(smem);
+    float2 *ex = reinterpret_cast<float2 *>(smem);
+
+    const int lane = threadIdx.x;
+    long blk = blockIdx.x;
+    if (blk >= nblocks) return;
+
+    v4f pre[NLD];
+    auto fetch = [&](long b, int s) {
+        const v4f *src = reinterpret_cast<const v4f *>(x + (b * 1024 + s * SUB_OUT) * (long)D) + lane;
+        static_for<NLD - 1>([&](auto I) { pre[I.value] = src[64 * I.value]; });
+        if (lane + 64 * (NLD - 1) < SUB_V) pre[NLD - 1] = src[64 * (NLD - 1)];
+    };
+    auto park = [&]() {
+        static_for<NLD - 1>([&](auto I) { xs4[G::lds_index(2 * (lane + 64 * I.value)) / 2] = pre[I.value]; });
+        if (lane + 64 * (NLD - 1) < SUB_V) xs4[G::lds_index(2 * (lane + 64 * (NLD - 1))) / 2] = pre[NLD - 1];
+    };
+
+    fetch(blk, 0);
+    park();
+    wave_lds_fence();
+    for (; blk < nblocks; blk += gridDim.x) {
+        float2 a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = make_float2(0.f, 0.f);
+        const bool more = blk + gridDim.x < nblocks;
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            if (!(ABLATE & 4)) {
+                if (s < 3) fetch(blk, s + 1);
+                else if (more) fetch(blk + gridDim.x, 0);
+            }
+            float2 acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+            int lf = lane; // opaque per sub-tile: keeps LDS address arithmetic out of the loop's live set
+            asm volatile("" : "+v"(lf));
+            if (ABLATE & 1) {
+                const v4f q0 = xs4[lf * (G::LANE_STRIDE / 2)];
+                acc[0] = make_float2(q0.x, q0.y); acc[1] = make_float2(q0.z, q0.w); acc[2] = acc[0]; acc[3] = acc[1];
+            } else {
+                fir_lane_v<K, D, R, FUSED, CH>(xs4, lf, taps, acc);
+            }
+            // rotate: after four sub-tiles a[4 s + r] holds sub-tile s
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a[i] = a[i + 4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[12 + r] = acc[r];
+            wave_lds_fence(); // window reads done before the image is overwritten
+            if (s < 3) {
+                park();
+                wave_lds_fence();
+            }
+        }
+        // the block is in registers; the input image is free -> exchange scratch
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (ABLATE & 2) {
+            float2 *d0p = out + blk * 1024 + ln;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d0p[64 * i] = a[i];
+            if (more) park();
+            wave_lds_fence();
+            continue;
+        }
+        fft1kn_stage0<false>(a, tw);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+            for (int d0 = 0; d0 < 4; ++d0) ex[fft1kn_x1_store(ln, k4, d0)] = a[4 * k4 + d0];
+        Fft1knTw12 t12;
+        fft1kn_load_tw12(t12, ln, tw);
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = ex[fft1kn_x1_load(ln, e)];
+        wave_lds_fence();
+        fft1kn_pass12<false>(a, t12);
+#pragma unroll
+        for (int k3 = 0; k3 < 4; ++k3)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) ex[fft1kn_x2_store(ln, k2, k3)] = a[k2 + 4 * k3];
+        Fft1knTw34 t34;
+        fft1kn_load_tw34(t34, ln, tw);
+        wave_lds_fence();
+#pragma unroll
+        for (int f = 0; f < 16; ++f) a[f] = ex[fft1kn_x2_load(ln, f)];
+        wave_lds_fence();
+        fft1kn_pass34<false>(a, t34);
+        float2 *dst = out + blk * 1024 + ln;
+#pragma unroll
+        for (int k0 = 0; k0 < 4; ++k0)
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) dst[64 * k1 + 256 * k0] = a[k1 + 4 * k0];
+        if (more) park();
+        wave_lds_fence();
+    }
+}
+
 bool chain_supported(int K, long D, int nfft) { return nfft == 1024 && K == 127 && D == 5; }
 
 static int num_cus()
@@ -208,6 +332,21 @@ static hipError_t launch_chain_v2(const FftPlanDev &p, const float2 *x, const fl
     return hipGetLastError();
 }
 
+template <int K, int D, int WPS, int CH, int ABLATE = 0>
+static hipError_t launch_chain_v3(const FftPlanDev &p, const float2 *x, const float *taps, float2 *out,
+                                  long nblocks, bool fused, hipStream_t s)
+{
+    using G = FirGeomV<K, D, 4>;
+    constexpr int ELEMS = G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS;
+    constexpr size_t LDS = (size_t)ELEMS * sizeof(float2);
+    static_assert(4 * WPS * LDS <= 160 * 1024, "4*WPS waves per CU");
+    long grid = 4L * WPS * num_cus();
+    if (grid > nblocks) grid = nblocks;
+    if (fused) hipLaunchKernelGGL((chain_v3_kernel<K, D, true, WPS, CH, ABLATE>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, p.tw, out, nblocks);
+    else hipLaunchKernelGGL((chain_v3_kernel<K, D, false, WPS, CH, ABLATE>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, p.tw, out, nblocks);
+    return hipGetLastError();
+}
+
 template <int K, int D>
 static hipError_t launch_chain_t(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, float2 *out,
                                  long nblocks, bool fused, hipStream_t s)
@@ -233,9 +372,23 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
 {
     if (nblocks <= 0) return hipSuccess;
     if (p.nfft == 1024 && !p.inverse && K == 127 && D == 5) {
-        // v2 needs 16-byte aligned input (every sub-tile starts on an even sample)
-        if (variant != 1 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-            return launch_chain_v2<127, 5>(p, x, taps, out, nblocks, fused, s);
+        // v2/v3 need 16-byte aligned input (every sub-tile starts on an even sample)
+        const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+        if (variant == 0 && aligned) return launch_chain_v3<127, 5, 3, 6>(p, x, taps, out, nblocks, fused, s);
+        if (variant == 3 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
+        if (variant == 4 && aligned) return launch_chain_v3<127, 5, 3, 8>(p, x, taps, out, nblocks, fused, s);
+        if (variant >= 10 && aligned && fused) { // timing-only ablations of v3 (results are wrong)
+            switch (variant - 10) {
+            case 1: return launch_chain_v3<127, 5, 3, 6, 1>(p, x, taps, out, nblocks, true, s);
+            case 2: return launch_chain_v3<127, 5, 3, 6, 2>(p, x, taps, out, nblocks, true, s);
+            case 3: return launch_chain_v3<127, 5, 3, 6, 3>(p, x, taps, out, nblocks, true, s);
+            case 4: return launch_chain_v3<127, 5, 3, 6, 4>(p, x, taps, out, nblocks, true, s);
+            case 6: return launch_chain_v3<127, 5, 3, 6, 6>(p, x, taps, out, nblocks, true, s);
+            case 7: return launch_chain_v3<127, 5, 3, 6, 7>(p, x, taps, out, nblocks, true, s);
+            default: break;
+            }
+        }
+        if (variant == 2 && aligned) return launch_chain_v2<127, 5>(p, x, taps, out, nblocks, fused, s);
         return launch_chain_t<127, 5>(p, x, n_in, taps, out, nblocks, fused, s);
     }
     return hipErrorNotSupported;

@@ -171,6 +171,85 @@ RD_HD void fft1k_passC(float2 (&w)[16], const Fft1kTw &t)
 }
 
 // ============================================================================================
+// 1024-point transform in the FIR's own register layout ("native" form, used by the fused chain):
+// the wavefront already holds the block as a[4 s + r] = x[256 s + 4 lane + r] (s = FIR sub-tile,
+// r = the lane's four consecutive outputs), i.e. with n = d0 + 4 d1 + 16 d2 + 64 d3 + 256 d4:
+// r = d0, lane = d1 + 4 d2 + 16 d3, s = d4.  Stage m=1 (over d4) and stage m=256 (over d0) are then
+// register-only, and the transform needs no input load at all:
+//     stage 0 | exchange X1 | stages 1,2 | exchange X2 | stages 3,4 -> X[l2 + 64 k1 + 256 k0]
+// X1 image: row = 4 k4 + d0 (stride 68), col = d1 + 4 d2 + 16 d3;  reader lane l1 = d1 + 4 d0 + 16 k4
+// X2 image: row = d0 + 4 d1 (stride 66), col = k4 + 4 k3 + 16 k2;  reader lane l2 = the column
+// Both strides make the b64 writes (16-lane groups) and reads (32-lane groups) conflict-free.
+// ============================================================================================
+constexpr int FFT1KN_ROW1 = 68, FFT1KN_ROW2 = 66;
+constexpr int FFT1KN_LDS = 16 * FFT1KN_ROW1; // float2 per wave
+
+template <bool INV, typename TwPtr>
+RD_HD void fft1kn_stage0(float2 (&a)[16], TwPtr tw)
+{
+    const float2 one = tw[0]; // stage m=1: k = 0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bfly4<INV>(a[r], a[4 + r], a[8 + r], a[12 + r], one, one, one);
+    // now a[4 k4 + d0]
+}
+RD_HD int fft1kn_x1_store(int lane, int k4, int d0) { return (4 * k4 + d0) * FFT1KN_ROW1 + lane; }
+// lane l1 = d1 + 4 d0 + 16 k4 reads element e = d2 + 4 d3
+RD_HD int fft1kn_x1_load(int lane, int e) { return (4 * (lane >> 4) + ((lane >> 2) & 3)) * FFT1KN_ROW1 + (lane & 3) + 4 * e; }
+
+struct Fft1knTw12 { float2 a[3]; float2 b[12]; };
+struct Fft1knTw34 { float2 c[3]; float2 d[12]; };
+template <typename TwPtr>
+RD_HD void fft1kn_load_tw12(Fft1knTw12 &t, int lane, TwPtr tw)
+{
+    const int k4 = lane >> 4;
+    t.a[0] = tw[64 * k4]; t.a[1] = tw[128 * k4]; t.a[2] = tw[192 * k4];
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const int k = k4 + 4 * k3;
+        t.b[3 * k3] = tw[16 * k]; t.b[3 * k3 + 1] = tw[32 * k]; t.b[3 * k3 + 2] = tw[48 * k];
+    }
+}
+template <typename TwPtr>
+RD_HD void fft1kn_load_tw34(Fft1knTw34 &t, int lane, TwPtr tw)
+{
+    t.c[0] = tw[4 * lane]; t.c[1] = tw[8 * lane]; t.c[2] = tw[12 * lane];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        const int k = lane + 64 * k1;
+        t.d[3 * k1] = tw[k]; t.d[3 * k1 + 1] = tw[2 * k]; t.d[3 * k1 + 2] = tw[3 * k];
+    }
+}
+// u[d2 + 4 d3] -> u[k2 + 4 k3]
+template <bool INV>
+RD_HD void fft1kn_pass12(float2 (&u)[16], const Fft1knTw12 &t)
+{
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2) // stage m=4 (over d3), k = k4
+        bfly4<INV>(u[d2], u[d2 + 4], u[d2 + 8], u[d2 + 12], t.a[0], t.a[1], t.a[2]);
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) // stage m=16 (over d2), k = k4 + 4 k3
+        bfly4<INV>(u[4 * k3], u[4 * k3 + 1], u[4 * k3 + 2], u[4 * k3 + 3], t.b[3 * k3], t.b[3 * k3 + 1], t.b[3 * k3 + 2]);
+}
+// lane l1 = d1 + 4 d0 + 16 k4 stores value (k2, k3)
+RD_HD int fft1kn_x2_store(int lane, int k2, int k3)
+{
+    return (((lane >> 2) & 3) + 4 * (lane & 3)) * FFT1KN_ROW2 + (lane >> 4) + 4 * k3 + 16 * k2;
+}
+// lane l2 = k4 + 4 k3 + 16 k2 reads element f = d1 + 4 d0
+RD_HD int fft1kn_x2_load(int lane, int f) { return ((f >> 2) + 4 * (f & 3)) * FFT1KN_ROW2 + lane; }
+// w[d1 + 4 d0] -> w[k1 + 4 k0] = X[lane + 64 k1 + 256 k0]
+template <bool INV>
+RD_HD void fft1kn_pass34(float2 (&w)[16], const Fft1knTw34 &t)
+{
+#pragma unroll
+    for (int d0 = 0; d0 < 4; ++d0) // stage m=64 (over d1), k = lane
+        bfly4<INV>(w[4 * d0], w[4 * d0 + 1], w[4 * d0 + 2], w[4 * d0 + 3], t.c[0], t.c[1], t.c[2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) // stage m=256 (over d0), k = lane + 64 k1
+        bfly4<INV>(w[k1], w[k1 + 4], w[k1 + 8], w[k1 + 12], t.d[3 * k1], t.d[3 * k1 + 1], t.d[3 * k1 + 2]);
+}
+
+// ============================================================================================
 // Generic mixed-radix stage (any nfft): butterfly b of the stage with radix p, sub-length m and
 // twiddle stride fstride, operating in place on F (LDS or global).  Positions g*p*m + k + j*m.
 // Radix > 5 is done out of place (src -> dst) because kf_bfly_generic needs all p inputs.

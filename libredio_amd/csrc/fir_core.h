@@ -134,13 +134,12 @@ RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH],
     }
 }
 
-template <int K, int D, int R, bool FUSED, typename Lds4Ptr, typename TapPtr>
+template <int K, int D, int R, bool FUSED, int CH = 8 /* 16-byte reads per chunk */, typename Lds4Ptr, typename TapPtr>
 RD_HD void fir_lane_v(Lds4Ptr xs4, int lane_slot, TapPtr h, float2 (&acc)[R])
 {
     using G = FirGeomV<K, D, R>;
     using Q = typename std::remove_cv<typename std::remove_reference<decltype(xs4[0])>::type>::type;
     constexpr int NRD = (G::SPAN + 1) / 2;
-    constexpr int CH = 8; // reads per chunk
     using T = FirChunkTaps<K, D, R, CH>;
     const int base4 = lane_slot * (G::LANE_STRIDE / 2);
     Q q[2][CH];

@@ -270,7 +270,7 @@ struct redio_chain {
     int nfft;
     int fused_ok;
     int force_unfused;
-    int variant; // 0 = best fused kernel, 1 = first-generation fused kernel (kept for A/B runs)
+    int variant; // fused kernel generation: 0 = v3 (wave per block), 1 = v1, 2 = v2 (kept for A/B runs)
     float2 *d_mid; // intermediate for the two-kernel path
     size_t mid_elems;
 };
@@ -313,7 +313,7 @@ extern "C" int redio_chain_set_unfused(redio_chain *h, int unfused)
 }
 extern "C" int redio_chain_set_variant(redio_chain *h, int variant)
 {
-    if (!h || variant < 0 || variant > 1) return REDIO_ERR_ARG;
+    if (!h || variant < 0 || variant > 17) return REDIO_ERR_ARG;
     h->variant = variant;
     return REDIO_OK;
 }

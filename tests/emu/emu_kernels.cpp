@@ -59,6 +59,60 @@ extern "C" void emu_fft1k(const float2 *in, float2 *out, int inverse)
     else emu_fft1k_t<false>(in, out);
 }
 
+// the "native" transform of the fused chain: input already in the FIR register layout
+template <bool INV>
+static void emu_fft1kn_t(const float2 *in, float2 *out)
+{
+    std::vector<float2> tw = make_tw(1024, INV);
+    std::vector<float2> x1(FFT1KN_LDS), x2(FFT1KN_LDS);
+    float2 v[16];
+    for (int lane = 0; lane < 64; ++lane) {
+        for (int s = 0; s < 4; ++s)
+            for (int r = 0; r < 4; ++r) v[4 * s + r] = in[256 * s + 4 * lane + r];
+        fft1kn_stage0<INV>(v, tw.data());
+        for (int k4 = 0; k4 < 4; ++k4)
+            for (int d0 = 0; d0 < 4; ++d0) x1[fft1kn_x1_store(lane, k4, d0)] = v[4 * k4 + d0];
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        for (int e = 0; e < 16; ++e) v[e] = x1[fft1kn_x1_load(lane, e)];
+        Fft1knTw12 t;
+        fft1kn_load_tw12(t, lane, tw.data());
+        fft1kn_pass12<INV>(v, t);
+        for (int k3 = 0; k3 < 4; ++k3)
+            for (int k2 = 0; k2 < 4; ++k2) x2[fft1kn_x2_store(lane, k2, k3)] = v[k2 + 4 * k3];
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        for (int f = 0; f < 16; ++f) v[f] = x2[fft1kn_x2_load(lane, f)];
+        Fft1knTw34 t;
+        fft1kn_load_tw34(t, lane, tw.data());
+        fft1kn_pass34<INV>(v, t);
+        for (int k0 = 0; k0 < 4; ++k0)
+            for (int k1 = 0; k1 < 4; ++k1) out[lane + 64 * k1 + 256 * k0] = v[k1 + 4 * k0];
+    }
+}
+extern "C" void emu_fft1kn(const float2 *in, float2 *out, int inverse)
+{
+    if (inverse) emu_fft1kn_t<true>(in, out);
+    else emu_fft1kn_t<false>(in, out);
+}
+extern "C" int emu_fft1kn_bank_conflicts(void)
+{
+    int worst = 1;
+    auto check = [&](int (*addr)(int, int), int nacc, int group) {
+        for (int a = 0; a < nacc; ++a)
+            for (int g0 = 0; g0 < 64; g0 += group) {
+                int cnt[32] = {0};
+                for (int l = g0; l < g0 + group; ++l) cnt[addr(l, a) % 32]++;
+                for (int b = 0; b < 32; ++b) if (cnt[b] > worst) worst = cnt[b];
+            }
+    };
+    check([](int l, int a) { return fft1kn_x1_store(l, a >> 2, a & 3); }, 16, 16);
+    check([](int l, int a) { return fft1kn_x1_load(l, a); }, 16, 32);
+    check([](int l, int a) { return fft1kn_x2_store(l, a & 3, a >> 2); }, 16, 16);
+    check([](int l, int a) { return fft1kn_x2_load(l, a); }, 16, 32);
+    return worst;
+}
+
 // LDS bank check of the 1024-point exchanges: returns the worst number of distinct addresses that
 // share a bank inside one lane group (1 = conflict free).  group = 16 lanes for ds_write_b64,
 // 32 lanes for ds_read_b64; bank of an 8-byte access = (dword address / 2) % 32 pairs.
