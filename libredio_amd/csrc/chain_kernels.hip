@@ -374,8 +374,8 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
     if (p.nfft == 1024 && !p.inverse && K == 127 && D == 5) {
         // v2/v3 need 16-byte aligned input (every sub-tile starts on an even sample)
         const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-        if (variant == 0 && aligned) return launch_chain_v3<127, 5, 3, 6>(p, x, taps, out, nblocks, fused, s);
-        if (variant == 3 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
+        if (variant == 0 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
+        if (variant == 3 && aligned) return launch_chain_v3<127, 5, 3, 6>(p, x, taps, out, nblocks, fused, s);
         if (variant == 4 && aligned) return launch_chain_v3<127, 5, 3, 8>(p, x, taps, out, nblocks, fused, s);
         if (variant >= 10 && aligned && fused) { // timing-only ablations of v3 (results are wrong)
             switch (variant - 10) {

@@ -4,7 +4,7 @@
 #include <stdio.h>
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int MODE>
+template <int MODE, int NACC = 8>
 __global__ void k(float *out, float h0, float h1, int iters)
 {
     v2f a[8];
@@ -14,7 +14,8 @@ __global__ void k(float *out, float h0, float h1, int iters)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int ii = 0; ii < 8; ++ii) {
+                const int i = ii % NACC;
                 if (MODE == 0) { // packed: one v_pk_fma_f32 per complex MAC
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(x), "s"(v2f{h0, h1}));
                 } else {         // scalar: two v_fmac_f32
@@ -50,6 +51,17 @@ int main()
             double cmacs = (double)iters * 64 * 256.0 * 256 * wps; // complex MACs (2 FMA each)
             printf("waves/SIMD=%d mode=%s  %.3f ms  %.2f T complex-MAC/s  = %.1f TFLOP/s\n", wps, mode == 0 ? "v_pk_fma_f32" : "2x v_fmac_f32", ms, cmacs / ms / 1e9, cmacs * 4 / ms / 1e9);
         }
+    }
+    // dependent-chain sensitivity: NACC independent accumulators per wave
+    for (int wps = 1; wps <= 4; ++wps) {
+        dim3 grid(256), block(256 * wps);
+        auto run = [&](auto kern, int nacc) {
+            for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL(kern, grid, block, 0, 0, d, 1.0001f, 0.9999f, iters); hipEventRecord(e1); hipEventSynchronize(e1); }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double cmacs = (double)iters * 64 * 256.0 * 256 * wps;
+            printf("waves/SIMD=%d v_pk_fma_f32 nacc=%d  %.2f T complex-MAC/s\n", wps, nacc, cmacs / ms / 1e9);
+        };
+        run(k<0, 1>, 1); run(k<0, 2>, 2); run(k<0, 4>, 4); run(k<0, 8>, 8);
     }
     return 0;
 }
