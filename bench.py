@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="fused kernel generation (0 = current, 1 = first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2-samples", type=int, default=25)
-    ap.add_argument("--traffic-json", default=None, help="file with {'traffic': bytes_per_launch} from the PMC passes")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
     return ap.parse_args()
 
 
@@ -141,7 +141,7 @@ def main():
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
         ach = alg_bytes / kavg / 1e9
         traffic = None
-        if a.traffic_json and os.path.exists(a.traffic_json):
+        if a.traffic_json and os.path.exists(a.traffic_json) and a.variant == 0 and not a.unfused and a.log2_samples == 28:
             traffic = json.load(open(a.traffic_json)).get("traffic")
         rec = {
             "metric": "MSamples/s through FIR+FFT chain (127-tap FIR decimate-by-5 -> 1024-pt FFT, cf32 IQ)",
