@@ -108,6 +108,41 @@ int redio_chain_set_unfused(redio_chain *h, int unfused);
 int redio_chain_set_variant(redio_chain *h, int variant);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
 
+/* ---- A6: samplerate::resample's native side, src/samplerate/src/samplerate.rs:59-87 ----
+ * nchan independent mono streams that share ratio and block lengths (the reference creates one
+ * src_new(SRC_SINC_MEDIUM_QUALITY, 1) state per block, :61).  Control flow, output count law and
+ * arithmetic order are those of the published libsamplerate 0.1.8 sinc converter; the coefficient
+ * table is a stated design.  Bit-identical to oracle/oracle_src.c.
+ * Return values: REDIO_OK, a negative redio error, or one of the library's positive error codes. */
+enum {
+    REDIO_SRC_ERR_MALLOC_FAILED = 1, REDIO_SRC_ERR_BAD_STATE = 2, REDIO_SRC_ERR_BAD_DATA = 3,
+    REDIO_SRC_ERR_BAD_DATA_PTR = 4, REDIO_SRC_ERR_NO_PRIVATE = 5, REDIO_SRC_ERR_BAD_SRC_RATIO = 6,
+    REDIO_SRC_ERR_BAD_PROC_PTR = 7, REDIO_SRC_ERR_SHIFT_BITS = 8, REDIO_SRC_ERR_FILTER_LEN = 9,
+    REDIO_SRC_ERR_BAD_CONVERTER = 10, REDIO_SRC_ERR_BAD_CHANNEL_COUNT = 11,
+    REDIO_SRC_ERR_SINC_BAD_BUFFER_LEN = 12, REDIO_SRC_ERR_SIZE_INCOMPATIBILITY = 13,
+    REDIO_SRC_ERR_BAD_PRIV_PTR = 14, REDIO_SRC_ERR_BAD_SINC_STATE = 15, REDIO_SRC_ERR_DATA_OVERLAP = 16,
+    REDIO_SRC_ERR_BAD_CALLBACK = 17, REDIO_SRC_ERR_BAD_MODE = 18, REDIO_SRC_ERR_NULL_CALLBACK = 19,
+    REDIO_SRC_ERR_NO_VARIABLE_RATIO = 20, REDIO_SRC_ERR_SINC_PREPARE_DATA_BAD_LEN = 21,
+    REDIO_SRC_ERR_BAD_INTERNAL_STATE = 22
+};
+typedef struct redio_src redio_src;
+/* converter: 0 best / 1 medium / 2 fastest sinc (3 zero-order-hold and 4 linear are not built:
+ * REDIO_SRC_ERR_BAD_CONVERTER; the reference only ever asks for 1) */
+int redio_src_create(redio_src **h, int converter, int nchan);
+int redio_src_destroy(redio_src *h);
+int redio_src_reset(redio_src *h);
+int redio_src_set_ratio(redio_src *h, double ratio);
+/* device-resident: d_in[nchan][in_stride], d_out[nchan][out_stride] f32; synchronises the stream
+ * before returning (per-output parameters are produced by the host state machine) */
+int redio_src_process(redio_src *h, const void *d_in, long input_frames, long in_stride, void *d_out, long output_frames,
+                      long out_stride, double src_ratio, int end_of_input, long *input_frames_used,
+                      long *output_frames_gen, void *stream);
+/* host buffers, mono, synchronous: the body of the src_process drop-in (include/samplerate.h) */
+int redio_src_process_host(redio_src *h, const float *data_in, long input_frames, float *data_out, long output_frames,
+                           double src_ratio, int end_of_input, long *input_frames_used, long *output_frames_gen);
+/* the coefficient table of a converter (coeffs_out may be NULL; it holds half_len + 2 floats) */
+int redio_src_table(int converter, float *coeffs_out, int *half_len, int *increment);
+
 /* ---- synthetic input: hash-generated cf32 / f32 in [-1, 1), device side ---- */
 int redio_synth_iq(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);
 int redio_synth_f32(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);

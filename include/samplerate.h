@@ -1,0 +1,58 @@
+/*
+ * samplerate.h -- drop-in for the nine C symbols LibRedio's Rust binds from libsamplerate
+ * (src/samplerate/src/samplerate.rs:32-42, linked by name "samplerate"):
+ *     src_new, src_delete, src_process, src_get_name, src_get_description, src_get_version,
+ *     src_set_ratio, src_is_valid_ratio, src_strerror
+ * plus src_reset / src_error / src_simple for C callers.  Exported by libsamplerate.so in this repo;
+ * the arithmetic runs on the MI355X through redio_src_* (include/redio.h).
+ *
+ * SRC_DATA is the C layout behind the Rust struct at samplerate.rs:15-24 (64 bytes on LP64).
+ * src_process writes input_frames_used / output_frames_gen back through the pointer, as the
+ * reference relies on (samplerate.rs:76,84).  Converter 1 (SRC_SINC_MEDIUM_QUALITY), channels 1 is
+ * what the reference uses (:61); sinc converters 0-2 are built, 3-4 and channels > 1 return NULL
+ * with the library's error code.  Deviation stated in DESIGN.md: the coefficient tables are not the
+ * library's (they cannot be reproduced here), so sample values differ from the real library within
+ * its quality class; control flow and frame counts follow the published 0.1.8 algorithm.
+ */
+#ifndef SAMPLERATE_H
+#define SAMPLERATE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SRC_STATE_tag SRC_STATE;
+
+typedef struct {
+    const float *data_in;
+    float *data_out;
+    long input_frames, output_frames;
+    long input_frames_used, output_frames_gen;
+    int end_of_input;
+    double src_ratio;
+} SRC_DATA;
+
+enum {
+    SRC_SINC_BEST_QUALITY = 0,   /* samplerate.rs:26 */
+    SRC_SINC_MEDIUM_QUALITY = 1, /* :27 */
+    SRC_SINC_FASTEST = 2,        /* :28 */
+    SRC_ZERO_ORDER_HOLD = 3,     /* :29 */
+    SRC_LINEAR = 4               /* :30 */
+};
+
+SRC_STATE *src_new(int converter_type, int channels, int *error);
+SRC_STATE *src_delete(SRC_STATE *state);
+int src_process(SRC_STATE *state, SRC_DATA *data);
+const char *src_get_name(int converter_type);
+const char *src_get_description(int converter_type);
+const char *src_get_version(void);
+int src_set_ratio(SRC_STATE *state, double new_ratio);
+int src_is_valid_ratio(double ratio);
+const char *src_strerror(int error);
+int src_reset(SRC_STATE *state);
+int src_error(SRC_STATE *state);
+int src_simple(SRC_DATA *data, int converter_type, int channels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

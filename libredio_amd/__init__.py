@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 LIBREDIO = os.path.join(_BUILD, "libredio.so")
 LIBKISSFFT = os.path.join(_BUILD, "libkissfft.so")
+LIBSAMPLERATE = os.path.join(_BUILD, "libsamplerate.so")
 
 REDIO_FIR_COMPLEX = 1
 REDIO_FIR_FUSED = 2
@@ -38,6 +39,7 @@ def build(verbose=False):
 
 _lib = None
 _kiss = None
+_src = None
 
 
 def _sig(f, res, *args):
@@ -90,6 +92,14 @@ def lib():
     _sig(L.redio_chain_set_unfused, i, vp, i)
     _sig(L.redio_chain_set_variant, i, vp, i)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
+    pl = C.POINTER(C.c_long)
+    _sig(L.redio_src_create, i, C.POINTER(vp), i, i)
+    _sig(L.redio_src_destroy, i, vp)
+    _sig(L.redio_src_reset, i, vp)
+    _sig(L.redio_src_set_ratio, i, vp, C.c_double)
+    _sig(L.redio_src_process, i, vp, vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_double, i, pl, pl, vp)
+    _sig(L.redio_src_process_host, i, vp, pf, C.c_long, pf, C.c_long, C.c_double, i, pl, pl)
+    _sig(L.redio_src_table, i, i, pf, C.POINTER(i), C.POINTER(i))
     _sig(L.redio_synth_iq, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _sig(L.redio_synth_f32, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _lib = L
@@ -115,10 +125,35 @@ def kisslib():
     return K
 
 
+def samplerate_lib():
+    """The loaded libsamplerate.so drop-in (the nine src_* symbols of samplerate.rs:32-42)."""
+    global _src
+    if _src is not None:
+        return _src
+    lib()
+    if not os.path.exists(LIBSAMPLERATE):
+        raise ImportError(f"{LIBSAMPLERATE} is missing: run libredio_amd.build()")
+    S = C.CDLL(LIBSAMPLERATE)
+    _sig(S.src_new, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int))
+    _sig(S.src_delete, C.c_void_p, C.c_void_p)
+    _sig(S.src_process, C.c_int, C.c_void_p, C.c_void_p)
+    _sig(S.src_get_name, C.c_char_p, C.c_int)
+    _sig(S.src_get_description, C.c_char_p, C.c_int)
+    _sig(S.src_get_version, C.c_char_p)
+    _sig(S.src_set_ratio, C.c_int, C.c_void_p, C.c_double)
+    _sig(S.src_is_valid_ratio, C.c_int, C.c_double)
+    _sig(S.src_strerror, C.c_char_p, C.c_int)
+    _sig(S.src_reset, C.c_int, C.c_void_p)
+    _sig(S.src_error, C.c_int, C.c_void_p)
+    _sig(S.src_simple, C.c_int, C.c_void_p, C.c_int, C.c_int)
+    _src = S
+    return S
+
+
 def check(code, what="redio"):
     if code != 0:
         raise RedioError(code, what)
 
 
-from . import dsputils, kissfft, plans  # noqa: E402,F401
-from .plans import Chain, Fft, Fir, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from . import dsputils, kissfft, plans, samplerate  # noqa: E402,F401
+from .plans import Chain, Fft, Fir, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401

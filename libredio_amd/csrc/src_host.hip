@@ -1,0 +1,389 @@
+// src_host.hip -- the converter state machine of samplerate::resample's native side
+// (src/samplerate/src/samplerate.rs:61,76: src_new / src_process) for nchan independent mono streams
+// that share ratio and block lengths.  It follows the published libsamplerate 0.1.8 control flow
+// (src_process checks, sinc_mono_vari_process, prepare_data) with the ring buffer mirrored in device
+// memory; every output sample is computed by src_sinc_exact_kernel.  Between two buffer refills the
+// outputs depend on one buffer image, so each refill epoch costs one compute launch.
+#include "../../include/redio.h"
+#include "redio_internal.h"
+#include "src_internal.h"
+#include <math.h>
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace redio {
+
+// ---- coefficient tables: same sizes / increments as the library's three sinc converters; the
+// contents are a stated design (Kaiser-windowed sinc) because the library's tables are not available
+// (DESIGN.md section 2).  Evaluated in double, rounded once to float.
+struct SrcTableSpec { int n; int increment; double fc; double beta; };
+static const SrcTableSpec kSpecs[3] = {
+    {340239, 2381, 0.9650, 16.0}, // SRC_SINC_BEST_QUALITY
+    {22438, 491, 0.9425, 12.4},   // SRC_SINC_MEDIUM_QUALITY
+    {2464, 128, 0.80, 9.0},       // SRC_SINC_FASTEST
+};
+
+static double bessel_i0(double x)
+{
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 500; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+bool src_make_table(int converter, std::vector<float> &c, int &half_len, int &increment)
+{
+    if (converter < 0 || converter > 2) return false;
+    const SrcTableSpec &t = kSpecs[converter];
+    const double pi = 3.14159265358979323846;
+    c.assign((size_t)t.n, 0.0f);
+    const int half = t.n - 2;
+    const double i0b = bessel_i0(t.beta);
+    for (int i = 0; i <= half; ++i) {
+        const double x = (double)i / (double)t.increment;
+        const double a = pi * t.fc * x;
+        const double s = (i == 0) ? 1.0 : sin(a) / a;
+        const double r = (double)i / (double)half;
+        const double w = bessel_i0(t.beta * sqrt(1.0 - r * r)) / i0b;
+        c[(size_t)i] = (float)(t.fc * s * w);
+    }
+    half_len = half;
+    increment = t.increment;
+    return true;
+}
+
+} // namespace redio
+
+using namespace redio;
+
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : REDIO_ERR_HIP_BASE - (int)e; }
+#define SRC_TRY(expr)                               \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) return hip_rc(_e);    \
+    } while (0)
+
+enum { SRC_MAX_RATIO = 256, SRC_SHIFT = 12 };
+
+struct redio_src {
+    int device, converter, nchan;
+    int coeff_half_len, index_inc;
+    float *d_coeffs;
+    // converter state (shared by every channel)
+    double last_ratio, last_position;
+    int b_current, b_end, b_real_end, b_len;
+    // device mirror of the library's buffer: two images of [nchan][b_len + 1]
+    float *d_buf[2];
+    int cur; // which image is live
+    long buf_stride;
+    // per-call scratch
+    std::vector<int> h_pos, h_start, h_inc;
+    std::vector<double> h_scale;
+    int *d_pos, *d_start, *d_inc;
+    double *d_scale;
+    size_t d_cap;
+    float *d_stage_in, *d_stage_out; // only used by the host-buffer entry point
+    size_t stage_in_cap, stage_out_cap;
+};
+
+static double fmod_one(double x)
+{
+    double res = x - (double)lrint(x);
+    if (res < 0.0) return res + 1.0;
+    return res;
+}
+static bool is_bad_src_ratio(double r) { return r < (1.0 / SRC_MAX_RATIO) || r > (1.0 * SRC_MAX_RATIO); }
+
+extern "C" int redio_src_reset(redio_src *s)
+{
+    if (!s) return REDIO_SRC_ERR_BAD_STATE;
+    SRC_TRY(hipSetDevice(s->device));
+    s->last_ratio = 0.0;
+    s->last_position = 0.0;
+    s->b_current = s->b_end = 0;
+    s->b_real_end = -1;
+    s->cur = 0;
+    SRC_TRY(hipMemset(s->d_buf[0], 0, (size_t)s->nchan * s->buf_stride * sizeof(float)));
+    SRC_TRY(hipMemset(s->d_buf[1], 0, (size_t)s->nchan * s->buf_stride * sizeof(float)));
+    return REDIO_OK;
+}
+
+extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    if (nchan < 1) return REDIO_SRC_ERR_BAD_CHANNEL_COUNT;
+    std::vector<float> coeffs;
+    int half = 0, inc = 0;
+    if (!src_make_table(converter, coeffs, half, inc)) return REDIO_SRC_ERR_BAD_CONVERTER; // ZOH / linear: not built
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return REDIO_ERR_NO_DEVICE;
+    redio_src *s = new (std::nothrow) redio_src();
+    if (!s) return REDIO_ERR_NOMEM;
+    s->device = dev; s->converter = converter; s->nchan = nchan;
+    s->coeff_half_len = half; s->index_inc = inc;
+    s->d_coeffs = nullptr; s->d_buf[0] = s->d_buf[1] = nullptr;
+    s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
+    s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0;
+    long bl = lrint(2.5 * half / (inc * 1.0) * SRC_MAX_RATIO);
+    if (bl < 4096) bl = 4096;
+    s->b_len = (int)bl;
+    s->buf_stride = (long)s->b_len + 1;
+    hipError_t e = hipMalloc((void **)&s->d_coeffs, coeffs.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(s->d_coeffs, coeffs.data(), coeffs.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_buf[0], (size_t)nchan * s->buf_stride * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_buf[1], (size_t)nchan * s->buf_stride * sizeof(float));
+    if (e != hipSuccess) { redio_src_destroy(s); return hip_rc(e); }
+    int rc = redio_src_reset(s);
+    if (rc) { redio_src_destroy(s); return rc; }
+    *h = s;
+    return REDIO_OK;
+}
+
+extern "C" int redio_src_destroy(redio_src *s)
+{
+    if (!s) return REDIO_OK;
+    hipFree(s->d_coeffs); hipFree(s->d_buf[0]); hipFree(s->d_buf[1]);
+    hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
+    hipFree(s->d_stage_in); hipFree(s->d_stage_out);
+    delete s;
+    return REDIO_OK;
+}
+
+extern "C" int redio_src_set_ratio(redio_src *s, double ratio)
+{
+    if (!s) return REDIO_SRC_ERR_BAD_STATE;
+    if (is_bad_src_ratio(ratio)) return REDIO_SRC_ERR_BAD_SRC_RATIO;
+    s->last_ratio = ratio;
+    return REDIO_OK;
+}
+
+extern "C" int redio_src_table(int converter, float *coeffs_out, int *half_len, int *increment)
+{
+    std::vector<float> c;
+    int h = 0, inc = 0;
+    if (!src_make_table(converter, c, h, inc)) return REDIO_SRC_ERR_BAD_CONVERTER;
+    if (half_len) *half_len = h;
+    if (increment) *increment = inc;
+    if (coeffs_out) memcpy(coeffs_out, c.data(), c.size() * sizeof(float));
+    return REDIO_OK;
+}
+
+static int ensure_scratch(redio_src *s, size_t nout)
+{
+    if (nout <= s->d_cap) return REDIO_OK;
+    hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
+    s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
+    size_t cap = nout + nout / 4 + 1024;
+    SRC_TRY(hipMalloc((void **)&s->d_pos, cap * sizeof(int)));
+    SRC_TRY(hipMalloc((void **)&s->d_start, cap * sizeof(int)));
+    SRC_TRY(hipMalloc((void **)&s->d_inc, cap * sizeof(int)));
+    SRC_TRY(hipMalloc((void **)&s->d_scale, cap * sizeof(double)));
+    s->d_cap = cap;
+    s->h_pos.resize(cap); s->h_start.resize(cap); s->h_inc.resize(cap); s->h_scale.resize(cap);
+    return REDIO_OK;
+}
+
+// where the new input of this call lives
+struct SrcInput {
+    const float *host; // host pointer (mono, nchan == 1) or NULL
+    const float *dev;  // device [nchan][in_stride] or NULL
+    long in_stride;
+};
+
+// prepare_data: refill the (device) buffer image, keeping `half` samples of history before b_current
+static int prepare_data(redio_src *f, const SrcInput &in, long in_count, long &in_used, int end_of_input, int half, hipStream_t st)
+{
+    int len;
+    if (f->b_real_end >= 0) return REDIO_OK;
+    if (f->b_current == 0) {
+        len = f->b_len - 2 * half;
+        f->b_current = f->b_end = half;
+    } else if (f->b_end + half + 1 < f->b_len) {
+        len = f->b_len - f->b_current - half;
+        if (len < 0) len = 0;
+    } else {
+        len = f->b_end - f->b_current;
+        // memmove(buffer, buffer + b_current - half, half + len): through the other image
+        const int other = f->cur ^ 1;
+        SRC_TRY(launch_src_copy_rows(f->d_buf[f->cur], f->buf_stride, f->b_current - half, f->d_buf[other], f->buf_stride, 0,
+                                     (long)half + len, f->nchan, st));
+        f->cur = other;
+        f->b_current = half;
+        f->b_end = f->b_current + len;
+        len = f->b_len - f->b_current - half;
+        if (len < 0) len = 0;
+    }
+    const long avail = in_count - in_used;
+    if (avail < len) len = (int)avail;
+    if (len < 0 || f->b_end + len > f->b_len) return REDIO_SRC_ERR_SINC_PREPARE_DATA_BAD_LEN;
+    if (len > 0) {
+        if (in.host) {
+            SRC_TRY(hipMemcpyAsync(f->d_buf[f->cur] + f->b_end, in.host + in_used, (size_t)len * sizeof(float), hipMemcpyHostToDevice, st));
+        } else {
+            SRC_TRY(launch_src_copy_rows(in.dev, in.in_stride, in_used, f->d_buf[f->cur], f->buf_stride, f->b_end, len, f->nchan, st));
+        }
+    }
+    f->b_end += len;
+    in_used += len;
+    if (in_used == in_count && f->b_end - f->b_current < 2 * half && end_of_input) {
+        if (f->b_len - f->b_end < half + 5) {
+            len = f->b_end - f->b_current;
+            const int other = f->cur ^ 1;
+            SRC_TRY(launch_src_copy_rows(f->d_buf[f->cur], f->buf_stride, f->b_current - half, f->d_buf[other], f->buf_stride, 0,
+                                         (long)half + len, f->nchan, st));
+            f->cur = other;
+            f->b_current = half;
+            f->b_end = f->b_current + len;
+        }
+        f->b_real_end = f->b_end;
+        len = half + 5;
+        if (len < 0 || f->b_end + len > f->b_len) len = f->b_len - f->b_end;
+        SRC_TRY(launch_src_fill_rows(f->d_buf[f->cur], f->buf_stride, f->b_end, len, f->nchan, 0.0f, st));
+        f->b_end += len;
+    }
+    return REDIO_OK;
+}
+
+// flush the outputs decided since the last refill: they all read the current buffer image
+static int flush_epoch(redio_src *f, long first, long count, float *d_out, long out_stride, hipStream_t st)
+{
+    if (count <= 0) return REDIO_OK;
+    SRC_TRY(hipMemcpyAsync(f->d_pos + first, f->h_pos.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_start + first, f->h_start.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_inc + first, f->h_inc.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_scale + first, f->h_scale.data() + first, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+    SRC_TRY(launch_src_exact(f->d_buf[f->cur], f->buf_stride, f->d_coeffs, f->coeff_half_len, f->d_pos + first, f->d_start + first,
+                             f->d_inc + first, f->d_scale + first, d_out + first, out_stride, count, f->nchan, st));
+    return REDIO_OK;
+}
+
+// src_process + sinc_mono_vari_process; outputs land in d_out[nchan][out_stride]
+static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames, float *d_out, long out_stride, long output_frames,
+                            double src_ratio_arg, int end_of_input, long *in_used_out, long *out_gen_out, hipStream_t st)
+{
+    if (is_bad_src_ratio(src_ratio_arg)) return REDIO_SRC_ERR_BAD_SRC_RATIO;
+    if (input_frames < 0) input_frames = 0;
+    if (output_frames < 0) output_frames = 0;
+    if (f->last_ratio < (1.0 / SRC_MAX_RATIO)) f->last_ratio = src_ratio_arg;
+
+    const long in_count = input_frames, out_count = output_frames;
+    long in_used = 0, out_gen = 0;
+    double src_ratio = f->last_ratio;
+    if (is_bad_src_ratio(src_ratio)) return REDIO_SRC_ERR_BAD_INTERNAL_STATE;
+    int rc = ensure_scratch(f, (size_t)out_count);
+    if (rc) return rc;
+    // the scratch upload of an earlier call on another stream must not be overwritten while in
+    // flight: calls on one handle are serialised by the caller (one block thread per handle)
+
+    double count = (f->coeff_half_len + 2.0) / f->index_inc;
+    const double minr = f->last_ratio < src_ratio_arg ? f->last_ratio : src_ratio_arg;
+    if (minr < 1.0) count /= minr;
+    const int half = (int)lrint(count) + 1;
+
+    double input_index = f->last_position;
+    double rem = fmod_one(input_index);
+    f->b_current = (f->b_current + (int)lrint(input_index - rem)) % f->b_len;
+    input_index = rem;
+    const double terminate = 1.0 / src_ratio + 1e-20;
+    const double fp_one = (double)(1 << SRC_SHIFT);
+
+    long epoch_first = 0;
+    while (out_gen < out_count) {
+        int samples_in_hand = (f->b_end - f->b_current + f->b_len) % f->b_len;
+        if (samples_in_hand <= half) {
+            rc = flush_epoch(f, epoch_first, out_gen - epoch_first, d_out, out_stride, st); // before the image changes
+            if (rc) return rc;
+            epoch_first = out_gen;
+            rc = prepare_data(f, in, in_count, in_used, end_of_input, half, st);
+            if (rc) return rc;
+            samples_in_hand = (f->b_end - f->b_current + f->b_len) % f->b_len;
+            if (samples_in_hand <= half) break;
+        }
+        if (f->b_real_end >= 0) {
+            if (f->b_current + input_index + terminate > f->b_real_end) break;
+        }
+        if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-10)
+            src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
+        const double float_increment = f->index_inc * (src_ratio < 1.0 ? src_ratio : 1.0);
+        f->h_inc[(size_t)out_gen] = (int)lrint(float_increment * fp_one);
+        f->h_start[(size_t)out_gen] = (int)lrint(input_index * float_increment * fp_one);
+        f->h_scale[(size_t)out_gen] = float_increment / f->index_inc;
+        f->h_pos[(size_t)out_gen] = f->b_current;
+        ++out_gen;
+        input_index += 1.0 / src_ratio;
+        rem = fmod_one(input_index);
+        f->b_current = (f->b_current + (int)lrint(input_index - rem)) % f->b_len;
+        input_index = rem;
+    }
+    rc = flush_epoch(f, epoch_first, out_gen - epoch_first, d_out, out_stride, st);
+    if (rc) return rc;
+    f->last_position = input_index;
+    f->last_ratio = src_ratio;
+    if (in_used_out) *in_used_out = in_used;
+    if (out_gen_out) *out_gen_out = out_gen;
+    return REDIO_OK;
+}
+
+extern "C" int redio_src_process(redio_src *s, const void *d_in, long input_frames, long in_stride, void *d_out, long output_frames,
+                                 long out_stride, double src_ratio, int end_of_input, long *input_frames_used,
+                                 long *output_frames_gen, void *stream)
+{
+    if (input_frames_used) *input_frames_used = 0;
+    if (output_frames_gen) *output_frames_gen = 0;
+    if (!s) return REDIO_SRC_ERR_BAD_STATE;
+    if (!d_in || !d_out) return REDIO_SRC_ERR_BAD_DATA_PTR;
+    SRC_TRY(hipSetDevice(s->device));
+    SrcInput in = {nullptr, (const float *)d_in, in_stride};
+    // pinned-free staging of the per-output parameters means the host arrays must stay untouched until
+    // the uploads have run: synchronise at the end of the call (the uploads are tiny)
+    int rc = src_process_impl(s, in, input_frames, (float *)d_out, out_stride, output_frames, src_ratio, end_of_input,
+                              input_frames_used, output_frames_gen, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (rc) return rc;
+    return hip_rc(e);
+}
+
+// host-buffer, mono: the body of the src_process drop-in (samplerate_shim.cpp)
+extern "C" int redio_src_process_host(redio_src *s, const float *data_in, long input_frames, float *data_out, long output_frames,
+                                      double src_ratio, int end_of_input, long *input_frames_used, long *output_frames_gen)
+{
+    if (input_frames_used) *input_frames_used = 0;
+    if (output_frames_gen) *output_frames_gen = 0;
+    if (!s) return REDIO_SRC_ERR_BAD_STATE;
+    if (s->nchan != 1) return REDIO_SRC_ERR_BAD_CHANNEL_COUNT;
+    if (!data_in || !data_out) return REDIO_SRC_ERR_BAD_DATA_PTR;
+    if (is_bad_src_ratio(src_ratio)) return REDIO_SRC_ERR_BAD_SRC_RATIO;
+    if (input_frames < 0) input_frames = 0;
+    if (output_frames < 0) output_frames = 0;
+    if (data_in < data_out) {
+        if (data_in + input_frames > data_out) return REDIO_SRC_ERR_DATA_OVERLAP;
+    } else if (data_out + output_frames > data_in) {
+        return REDIO_SRC_ERR_DATA_OVERLAP;
+    }
+    SRC_TRY(hipSetDevice(s->device));
+    if ((size_t)output_frames > s->stage_out_cap) {
+        hipFree(s->d_stage_out);
+        s->d_stage_out = nullptr; s->stage_out_cap = 0;
+        SRC_TRY(hipMalloc((void **)&s->d_stage_out, ((size_t)output_frames + 1024) * sizeof(float)));
+        s->stage_out_cap = (size_t)output_frames + 1024;
+    }
+    SrcInput in = {data_in, nullptr, 0};
+    long used = 0, gen = 0;
+    int rc = src_process_impl(s, in, input_frames, s->d_stage_out, (long)s->stage_out_cap, output_frames, src_ratio, end_of_input,
+                              &used, &gen, nullptr);
+    hipError_t e = hipSuccess;
+    if (rc == REDIO_OK && gen > 0) e = hipMemcpy(data_out, s->d_stage_out, (size_t)gen * sizeof(float), hipMemcpyDeviceToHost);
+    else e = hipStreamSynchronize(nullptr);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_rc(e);
+    if (input_frames_used) *input_frames_used = used;
+    if (output_frames_gen) *output_frames_gen = gen;
+    return REDIO_OK;
+}

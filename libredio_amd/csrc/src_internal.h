@@ -1,0 +1,12 @@
+// src_internal.h -- launch entry points of src_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace redio {
+hipError_t launch_src_exact(const float *win, long win_stride, const float *coeffs, int coeff_half_len,
+                            const int *pos, const int *start, const int *inc, const double *scale,
+                            float *out, long out_stride, long nout, int nchan, hipStream_t s);
+hipError_t launch_src_copy_rows(const float *src, long src_stride, long src_off, float *dst, long dst_stride, long dst_off,
+                                long n, int nchan, hipStream_t s);
+hipError_t launch_src_fill_rows(float *dst, long dst_stride, long dst_off, long n, int nchan, float v, hipStream_t s);
+} // namespace redio

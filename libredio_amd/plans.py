@@ -118,6 +118,37 @@ class Chain:
             self._h = None
 
 
+class Src:
+    """redio_src_*: nchan independent mono streams through the libsamplerate-style sinc converter
+    (samplerate.rs:59-87 semantics per stream), device-resident rows [nchan][frames]."""
+
+    def __init__(self, nchan, converter=1):
+        self.nchan = int(nchan)
+        self._h = C.c_void_p()
+        check(lib().redio_src_create(C.byref(self._h), int(converter), self.nchan), "src_create")
+
+    def process(self, x, ratio, output_frames=None, end_of_input=False):
+        """x: float32 CUDA tensor [nchan, frames]. Returns (out[nchan, gen], input_frames_used)."""
+        import torch
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == self.nchan and x.is_contiguous()
+        frames = x.shape[1]
+        cap = int(ratio * frames + 1.0) if output_frames is None else int(output_frames)
+        out = torch.empty((self.nchan, max(cap, 1)), dtype=torch.float32, device=x.device)
+        used, gen = C.c_long(0), C.c_long(0)
+        rc = lib().redio_src_process(self._h, _dev_ptr(x), frames, x.stride(0), _dev_ptr(out), cap, out.stride(0),
+                                     float(ratio), int(bool(end_of_input)), C.byref(used), C.byref(gen), current_stream())
+        check(rc, "src_process")
+        return out[:, : gen.value], used.value
+
+    def reset(self):
+        check(lib().redio_src_reset(self._h), "src_reset")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().redio_src_destroy(self._h)
+            self._h = None
+
+
 def synth_iq(seed, first, n, device="cuda"):
     """Hash-generated cf32 IQ in [-1,1), generated on the device."""
     import torch

@@ -31,6 +31,23 @@ def test_kiss_fft_h_symbols(redio):
         assert hasattr(K, n), f"libkissfft.so does not export {n}"
 
 
+def test_samplerate_h_symbols(redio):
+    S = redio.samplerate_lib()
+    names = [n for n in declared("samplerate.h") if n.startswith("src_")]
+    bound = {"src_new", "src_delete", "src_process", "src_get_name", "src_get_description", "src_get_version",
+             "src_set_ratio", "src_is_valid_ratio", "src_strerror"}  # samplerate.rs:34-42
+    assert bound <= set(names)
+    for n in names:
+        assert hasattr(S, n), f"libsamplerate.so does not export {n}"
+    assert S.src_is_valid_ratio(0.02) == 1 and S.src_strerror(6)
+
+
+def test_src_data_layout_is_64_bytes():
+    import ctypes as C
+    from libredio_amd.samplerate import SRC_DATA
+    assert C.sizeof(SRC_DATA) == 64  # samplerate.rs:15-24 on LP64
+
+
 def test_no_cpu_fallback_without_device(redio):
     import torch
     if torch.cuda.is_available():
@@ -40,6 +57,8 @@ def test_no_cpu_fallback_without_device(redio):
     with pytest.raises(redio.RedioError):
         redio.dsputils.convolve([1.0, 2.0, 3.0], [1.0])
     assert redio.kisslib().kiss_fft_alloc(64, 0, None, None) is None
+    err = C.c_int(0)
+    assert redio.samplerate_lib().src_new(1, 1, C.byref(err)) is None and err.value != 0
 
 
 def test_errors_have_text(redio):
