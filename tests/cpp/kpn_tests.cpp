@@ -1,0 +1,286 @@
+// kpn_tests.cpp -- exercises the C++ kpn twin (include/kpn.hpp, include/wavio.hpp).
+//   kpn_tests plumbing            CPU only: channel semantics and every kpn.rs block
+//   kpn_tests c1 in.wav out.wav   BASELINE.json configs[0]: WAV -> shaper(1024) -> convolve(63 taps) -> WAV
+//   kpn_tests fft in.bin out.bin N inv      kissfft::fft block over raw cf32 messages of N samples
+//   kpn_tests resample in.bin out.bin ratio msg_len   samplerate::resample block over raw f32 messages
+#include "../../include/kpn.hpp"
+#include "../../include/wavio.hpp"
+#include <cassert>
+#include <cmath>
+#include <fstream>
+
+using namespace kpn;
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+template <typename T>
+static std::vector<T> drain(Receiver<T> &r)
+{
+    std::vector<T> out;
+    while (auto v = r.try_recv_blocking()) out.push_back(*v);
+    return out;
+}
+template <typename T>
+static void feed(Sender<T> s, std::vector<T> v) { for (auto &x : v) s.send(x); }
+
+static int plumbing()
+{
+    { // channel: FIFO, blocking recv, hang-up when the last sender drops
+        auto [tx, rx] = channel<int>();
+        auto tx2 = tx;
+        tx.send(1); tx2.send(2);
+        CHECK(rx.recv() == 1 && rx.recv() == 2);
+        { Sender<int> a = std::move(tx); Sender<int> b = std::move(tx2); }
+        bool threw = false;
+        try { rx.recv(); } catch (const hangup &) { threw = true; }
+        CHECK(threw);
+    }
+    { // send to a dropped receiver fails (Err), does not throw
+        auto [tx, rx] = channel<int>();
+        rx.close();
+        CHECK(!tx.send(1));
+    }
+    { // rle (kpn.rs:17): last run never flushed
+        auto [a, ar] = channel<int>(); auto [b, br] = channel<std::pair<int, size_t>>();
+        auto t = spawn([&, r = std::move(ar), s = std::move(b)]() mutable { rle<int>(std::move(r), std::move(s)); });
+        feed<int>(std::move(a), {1, 1, 1, 0, 0, 1, 1});
+        t.join();
+        auto o = drain(br);
+        CHECK(o.size() == 2 && o[0] == std::make_pair(1, (size_t)3) && o[1] == std::make_pair(0, (size_t)2));
+    }
+    { // rld(rle) round trip on complete runs + dle/dld
+        auto [a, ar] = channel<std::pair<int, size_t>>(); auto [b, br] = channel<int>();
+        auto t = spawn([&, r = std::move(ar), s = std::move(b)]() mutable { rld<int>(std::move(r), std::move(s)); });
+        feed<std::pair<int, size_t>>(std::move(a), {{7, 2}, {9, 3}});
+        t.join();
+        auto o = drain(br);
+        CHECK((o == std::vector<int>{7, 7, 9, 9, 9}));
+        auto [c, cr] = channel<std::pair<int, size_t>>(); auto [d, dr] = channel<std::pair<int, float>>();
+        auto t2 = spawn([&, r = std::move(cr), s = std::move(d)]() mutable { dle<int>(std::move(r), std::move(s), 1000); });
+        feed<std::pair<int, size_t>>(std::move(c), {{1, 500}});
+        t2.join();
+        auto o2 = drain(dr);
+        CHECK(o2.size() == 1 && o2[0].second == 0.5f);
+        auto [e, er] = channel<std::pair<int, float>>(); auto [g, gr] = channel<int>();
+        auto t3 = spawn([&, r = std::move(er), s = std::move(g)]() mutable { dld<int>(std::move(r), std::move(s), 8.0f); });
+        feed<std::pair<int, float>>(std::move(e), {{3, 0.5f}});
+        t3.join();
+        CHECK(drain(gr).size() == 4);
+    }
+    { // differentiator (first value never emitted), dxdt (keeps the difference)
+        auto [a, ar] = channel<int>(); auto [b, br] = channel<int>();
+        auto t = spawn([&, r = std::move(ar), s = std::move(b)]() mutable { differentiator<int>(std::move(r), std::move(s)); });
+        feed<int>(std::move(a), {5, 5, 6, 6, 5});
+        t.join();
+        CHECK((drain(br) == std::vector<int>{6, 5}));
+        auto [c, cr] = channel<float>(); auto [d, dr] = channel<float>();
+        auto t2 = spawn([&, r = std::move(cr), s = std::move(d)]() mutable { dxdt<float>(std::move(r), std::move(s)); });
+        feed<float>(std::move(c), {1.f, 4.f, 10.f});
+        t2.join();
+        CHECK((drain(dr) == std::vector<float>{3.f, 7.f})); // 4-1, then 10-3 (as written)
+    }
+    { // shaper drops a trailing partial block; shaper_vecs / unpacketizer flatten
+        auto [a, ar] = channel<int>(); auto [b, br] = channel<std::vector<int>>();
+        auto t = spawn([&, r = std::move(ar), s = std::move(b)]() mutable { shaper<int>(std::move(r), std::move(s), 3); });
+        feed<int>(std::move(a), {1, 2, 3, 4, 5, 6, 7});
+        t.join();
+        auto blocks = drain(br);
+        CHECK(blocks.size() == 2 && blocks[1] == (std::vector<int>{4, 5, 6}));
+        auto [c, cr] = channel<std::vector<int>>(); auto [d, dr] = channel<int>();
+        auto t2 = spawn([&, r = std::move(cr), s = std::move(d)]() mutable { shaper_vecs<int>(std::move(r), std::move(s)); });
+        feed<std::vector<int>>(std::move(c), blocks);
+        t2.join();
+        CHECK((drain(dr) == std::vector<int>{1, 2, 3, 4, 5, 6}));
+        auto [e, er] = channel<std::vector<int>>(); auto [g, gr] = channel<int>();
+        auto t3 = spawn([&, r = std::move(er), s = std::move(g)]() mutable { unpacketizer<int>(std::move(r), std::move(s)); });
+        feed<std::vector<int>>(std::move(e), blocks);
+        t3.join();
+        CHECK(drain(gr).size() == 6);
+    }
+    { // shaper_optional: emit only exact-length groups
+        auto [a, ar] = channel<std::optional<int>>(); auto [b, br] = channel<std::vector<int>>();
+        auto t = spawn([&, r = std::move(ar), s = std::move(b)]() mutable { shaper_optional<int>(std::move(r), std::move(s), 2); });
+        feed<std::optional<int>>(std::move(a), {1, 2, std::nullopt, 3, std::nullopt, 4, 5, std::nullopt});
+        t.join();
+        auto o = drain(br);
+        CHECK(o.size() == 2 && o[1] == (std::vector<int>{4, 5}));
+    }
+    { // fork, mul, sum, mul_vecs (zip truncation), sum_vecs, delay, applicator, cross_applicator(_vecs), looper_optional
+        auto [a, ar] = channel<float>(); auto [b, br] = channel<float>(); auto [c, cr] = channel<float>();
+        std::vector<Sender<float>> outs; outs.push_back(std::move(b)); outs.push_back(std::move(c));
+        auto t = spawn([&, r = std::move(ar), o = std::move(outs)]() mutable { fork<float>(std::move(r), std::move(o)); });
+        feed<float>(std::move(a), {1.f, 2.f});
+        t.join();
+        CHECK(drain(br).size() == 2 && drain(cr).size() == 2);
+        auto [d, dr] = channel<float>(); auto [e, er] = channel<float>();
+        auto t2 = spawn([&, r = std::move(dr), s = std::move(e)]() mutable { mul<float>(std::move(r), std::move(s), 3.f); });
+        feed<float>(std::move(d), {2.f});
+        t2.join();
+        CHECK(drain(er)[0] == 6.f);
+        auto [g, gr] = channel<std::vector<float>>(); auto [h, hr] = channel<std::vector<float>>();
+        auto t3 = spawn([&, r = std::move(gr), s = std::move(h)]() mutable { mul_vecs<float>(std::move(r), std::move(s), {2.f, 3.f}); });
+        feed<std::vector<float>>(std::move(g), {{1.f, 1.f, 1.f}});
+        t3.join();
+        auto mv = drain(hr);
+        CHECK(mv[0] == (std::vector<float>{2.f, 3.f}));
+        auto [i, ir] = channel<int>(); auto [j, jr] = channel<int>();
+        auto t4 = spawn([&, r = std::move(ir), s = std::move(j)]() mutable { delay<int>(std::move(r), std::move(s), -1); });
+        feed<int>(std::move(i), {1, 2});
+        t4.join();
+        CHECK((drain(jr) == std::vector<int>{-1, 1, 2}));
+        auto [k, kr] = channel<int>(); auto [l, lr] = channel<double>();
+        auto t5 = spawn([&, r = std::move(kr), s = std::move(l)]() mutable {
+            cross_applicator<int, double>(std::move(r), std::move(s), [](int x) { return x * 0.5; }); });
+        feed<int>(std::move(k), {3});
+        t5.join();
+        CHECK(drain(lr)[0] == 1.5);
+        auto [m, mr] = channel<std::optional<int>>(); auto [n, nr] = channel<int>();
+        auto t6 = spawn([&, r = std::move(mr), s = std::move(n)]() mutable { looper_optional<int>(std::move(r), std::move(s)); });
+        feed<std::optional<int>>(std::move(m), {1, std::nullopt, 2});
+        t6.join();
+        CHECK((drain(nr) == std::vector<int>{1, 2}));
+    }
+    { // sum_across / mul_across / sum_across_vecs
+        auto [a, ar] = channel<float>(); auto [b, br] = channel<float>(); auto [o, orx] = channel<float>();
+        std::vector<Receiver<float>> ins; ins.push_back(std::move(ar)); ins.push_back(std::move(br));
+        auto t = spawn([&, r = std::move(ins), s = std::move(o)]() mutable { sum_across<float>(std::move(r), std::move(s), 10.f); });
+        feed<float>(std::move(a), {1.f, 2.f}); feed<float>(std::move(b), {3.f, 4.f});
+        t.join();
+        CHECK((drain(orx) == std::vector<float>{14.f, 16.f}));
+    }
+    { // grapes panics on an empty input (kpn.rs:245)
+        auto [a, ar] = channel<int>(); auto [o, orx] = channel<int>();
+        std::vector<Receiver<int>> ins; ins.push_back(std::move(ar));
+        bool threw = false;
+        try { grapes<int>(std::move(ins), std::move(o)); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+        (void)a; (void)orx;
+    }
+    // b2d / eat / binconv (kpn.rs:111-124,295-299) with the width lists of ratpak.rs:115,119
+    CHECK(b2d({1, 0, 1}) == 5);
+    {
+        std::vector<size_t> bits(36, 0);
+        bits[3] = 1; bits[11] = 1; bits[35] = 1; // 0001 00000001 0000 000000000000 00000001
+        auto f = eat(bits, {4, 8, 4, 12, 8});
+        CHECK((f == std::vector<size_t>{1, 1, 0, 0, 1}));
+        auto g = eat(bits, {4, 8, 2, 10, 12});
+        CHECK(g.size() == 5 && g[4] == 1);
+        bool threw = false;
+        try { eat(bits, {30, 10}); } catch (const std::out_of_range &) { threw = true; }
+        CHECK(threw);
+    }
+    { // WAV round trip (float32 mono + stereo-as-IQ, PCM16 read)
+        std::vector<float> x(4096);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = std::sin(0.01f * (float)i);
+        wavio::write_wav_f32("/tmp/kpn_rt.wav", x, 48000, 1);
+        auto [a, ar] = channel<float>();
+        auto t = spawn([&, s = std::move(a)]() mutable { wavio::wav_source_f32(std::move(s), "/tmp/kpn_rt.wav", 48000); });
+        t.join();
+        CHECK(drain(ar) == x);
+        auto [b, br] = channel<float>();
+        auto t2 = spawn([&, s = std::move(b)]() mutable { wavio::wav_source_f32(std::move(s), "/tmp/kpn_rt.wav", 48000, true); });
+        t2.join();
+        CHECK(drain(br).size() == 2048); // the reference's (frames/2)/1024 chunk count
+        bool threw = false;
+        try { auto [c, cr] = channel<float>(); wavio::wav_source_f32(std::move(c), "/tmp/kpn_rt.wav", 44100); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw); // assert_eq!(samplerate)
+        wavio::write_wav_f32("/tmp/kpn_iq.wav", x, 48000, 2);
+        auto [d, dr] = channel<std::complex<float>>();
+        auto t3 = spawn([&, s = std::move(d)]() mutable { wavio::wav_source_complex_f32(std::move(s), "/tmp/kpn_iq.wav", 48000); });
+        t3.join();
+        auto iq = drain(dr);
+        CHECK(iq.size() == 2048 && iq[1] == std::complex<float>(x[2], x[3]));
+    }
+    std::puts("plumbing ok");
+    return 0;
+}
+
+// BASELINE.json configs[0]: wav in -> shaper(1024) -> cross_applicator(convolve 63 taps) -> shaper_vecs -> wav out
+static int c1(const char *in, const char *out)
+{
+    const std::vector<float> taps = dsputils::lpf_corrected(63, 0.1f);
+    auto [s0, r0] = channel<float>();
+    auto [s1, r1] = channel<std::vector<float>>();
+    auto [s2, r2] = channel<std::vector<float>>();
+    auto [s3, r3] = channel<float>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), in]() mutable { wavio::wav_source_f32(std::move(s), in, 48000); }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { shaper<float>(std::move(r), std::move(s), 1024); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), &taps]() mutable {
+        cross_applicator<std::vector<float>, std::vector<float>>(std::move(r), std::move(s),
+                                                                 [&taps](std::vector<float> x) { return dsputils::convolve(x, taps); });
+    }));
+    th.push_back(spawn([r = std::move(r2), s = std::move(s3)]() mutable { shaper_vecs<float>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r3), out]() mutable { wavio::wav_sink_f32(std::move(r), out, 48000); }));
+    for (auto &t : th) t.join();
+    return 0;
+}
+
+template <typename T>
+static std::vector<T> read_bin(const char *fn)
+{
+    std::ifstream f(fn, std::ios::binary | std::ios::ate);
+    size_t n = (size_t)f.tellg() / sizeof(T);
+    std::vector<T> v(n);
+    f.seekg(0);
+    f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * sizeof(T)));
+    return v;
+}
+template <typename T>
+static void write_bin(const char *fn, const std::vector<T> &v)
+{
+    std::ofstream f(fn, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+}
+
+static int fft_graph(const char *in, const char *out, uint32_t n, uint32_t inv)
+{
+    auto x = read_bin<std::complex<float>>(in);
+    auto [s0, r0] = channel<std::complex<float>>();
+    auto [s1, r1] = channel<std::vector<std::complex<float>>>();
+    auto [s2, r2] = channel<std::vector<std::complex<float>>>();
+    auto [s3, r3] = channel<std::complex<float>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x]() mutable { for (auto &v : x) s.send(v); }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1), n]() mutable { shaper<std::complex<float>>(std::move(r), std::move(s), n); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), n, inv]() mutable { kissfft::fft(std::move(r), std::move(s), n, inv); }));
+    th.push_back(spawn([r = std::move(r2), s = std::move(s3)]() mutable { shaper_vecs<std::complex<float>>(std::move(r), std::move(s)); }));
+    std::vector<std::complex<float>> y;
+    while (auto v = r3.try_recv_blocking()) y.push_back(*v);
+    for (auto &t : th) t.join();
+    write_bin(out, y);
+    return 0;
+}
+
+static int resample_graph(const char *in, const char *out, double ratio, size_t msg)
+{
+    auto x = read_bin<float>(in);
+    auto [s0, r0] = channel<float>();
+    auto [s1, r1] = channel<std::vector<float>>();
+    auto [s2, r2] = channel<std::vector<float>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x]() mutable { for (auto &v : x) s.send(v); }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1), msg]() mutable { shaper<float>(std::move(r), std::move(s), msg); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), ratio]() mutable { samplerate::resample(std::move(r), std::move(s), ratio); }));
+    std::vector<float> y;
+    while (auto v = r2.try_recv_blocking()) y.insert(y.end(), v->begin(), v->end());
+    for (auto &t : th) t.join();
+    write_bin(out, y);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        std::string mode = argc > 1 ? argv[1] : "plumbing";
+        if (mode == "plumbing") return plumbing();
+        if (mode == "c1" && argc == 4) return c1(argv[2], argv[3]);
+        if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
+        if (mode == "resample" && argc == 6) return resample_graph(argv[2], argv[3], std::atof(argv[4]), (size_t)std::atol(argv[5]));
+        std::fprintf(stderr, "usage: see the header of kpn_tests.cpp\n");
+        return 2;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "kpn_tests: %s\n", e.what());
+        return 3;
+    }
+}

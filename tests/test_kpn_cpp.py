@@ -1,0 +1,92 @@
+"""The C++ kpn twin (include/kpn.hpp, include/wavio.hpp): plumbing on the CPU, and the reference-style
+graphs around the three hot blocks on the MI355X, checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "_build", "kpn_tests")
+
+
+@pytest.fixture(scope="module")
+def exe(redio):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
+    return EXE
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def write_wav_f32(path, x, rate):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    data = x.tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, rate, rate * 4, 4, 32))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+
+
+def read_wav_f32(path):
+    b = open(path, "rb").read()
+    i = b.index(b"data")
+    n = struct.unpack("<I", b[i + 4:i + 8])[0]
+    return np.frombuffer(b[i + 8:i + 8 + n], dtype=np.float32)
+
+
+def test_plumbing_blocks_cpu(exe):
+    out = subprocess.run([exe, "plumbing"], capture_output=True, text=True)
+    assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stderr
+
+
+def test_hot_blocks_fail_loudly_without_gpu(exe, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    write_wav_f32(tmp_path / "in.wav", np.zeros(2048, np.float32), 48000)
+    out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True)
+    # convolve has no CPU path: the block dies with the library's error, nothing is computed on the host
+    assert not os.path.exists(tmp_path / "out.wav") or len(read_wav_f32(tmp_path / "out.wav")) == 0
+
+
+@pytest.mark.gpu
+def test_config1_wav_fir_wav(exe, gpu, oracle, tmp_path):
+    """BASELINE.json configs[0]: wavio WAV in -> dsputils 63-tap FIR lowpass -> WAV out on a kpn graph.
+    Per-block valid mode: every 1024-sample block yields 1024-62 outputs."""
+    n = 1 << 16
+    x = oracle.synth_f32(0x5EED0001, 0, n + 300)  # 300 trailing samples do not fill a block: dropped by shaper
+    write_wav_f32(tmp_path / "in.wav", x, 48000)
+    out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    y = read_wav_f32(tmp_path / "out.wav")
+    taps = oracle.lpf_corrected(63, 0.1)
+    nblk = (n + 300) // 1024
+    want = np.concatenate([oracle.convolve(x[b * 1024:(b + 1) * 1024], taps) for b in range(nblk)])
+    assert len(y) == nblk * (1024 - 62)
+    assert np.array_equal(bits(y), bits(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,inv", [(1024, 0), (64, 1)])
+def test_kissfft_block_in_cpp_graph(exe, gpu, oracle, tmp_path, n, inv):
+    x = oracle.synth_iq(3, 0, n * 6 + 5)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "fft", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(n), str(inv)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    y = np.fromfile(tmp_path / "out.bin", dtype=np.complex64)
+    assert np.array_equal(bits(y), bits(oracle.fft(x[: n * 6], n, bool(inv))))
+
+
+@pytest.mark.gpu
+def test_resample_block_in_cpp_graph(exe, gpu, oracle, tmp_path):
+    x = oracle.synth_f32(5, 0, 30000)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "resample", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0.5", "7000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    ref = oracle.Resampler(1)
+    want = np.concatenate([ref.block(x[i:i + 7000], 0.5) for i in range(0, 28000, 7000)])
+    assert np.array_equal(bits(y), bits(want))
