@@ -96,8 +96,10 @@ def main():
     chain.set_variant(a.variant)
     nblk = chain.nblocks(n)
     used = nblk * NFFT * DECIM  # input samples that contribute to a spectrum
-    # rank r owns the slice that starts at decimated block r*nblk of the global stream
-    first = rank * nblk * NFFT * DECIM
+    # rank r owns the slice that starts at decimated block r*nblk of the global stream (sharding.weak_slice)
+    from libredio_amd import sharding
+    first, need = sharding.weak_slice(rank, nblk, NTAPS, DECIM, NFFT)
+    assert need <= n
     x = R.synth_iq(SEED, first, n)
     out = torch.empty((nblk, NFFT), dtype=torch.complex64, device="cuda")
     stream = R.current_stream()
