@@ -108,6 +108,20 @@ int redio_chain_set_unfused(redio_chain *h, int unfused);
 int redio_chain_set_variant(redio_chain *h, int variant);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
 
+/* ---- C4: M-channel polyphase channelizer (BASELINE.json configs[3]; a new composition) ----
+ * Prototype of nchan*taps_per_branch taps; branch m filters rows x_t[m] = x[nchan*t + m] with
+ * g_m[p] = proto[nchan*p + m] using the fold of dsputils::convolve (dsputils.rs:31), then every row
+ * goes through kissfft's nchan-point forward transform (kissfft.rs:26).  Output rows: T-P+1 with
+ * T = floor(n_in / nchan).  Built for nchan = 64, taps_per_branch in {4, 8, 16}; anything else is
+ * REDIO_ERR_UNSUPPORTED.  flags: REDIO_FIR_FUSED as for redio_fir_create.
+ * Output layout: ngroups = 1 -> [row][nchan]; ngroups = G -> [group][row][nchan/G], the send layout
+ * of the multi-GPU regrouping (one contiguous chunk per destination rank). */
+typedef struct redio_pfb redio_pfb;
+int redio_pfb_create(redio_pfb **h, const float *proto_taps_host, int nchan, int taps_per_branch, unsigned flags);
+int redio_pfb_destroy(redio_pfb *h);
+size_t redio_pfb_nrows(const redio_pfb *h, size_t n_in);
+int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, int ngroups, void *stream);
+
 /* ---- A6: samplerate::resample's native side, src/samplerate/src/samplerate.rs:59-87 ----
  * nchan independent mono streams that share ratio and block lengths (the reference creates one
  * src_new(SRC_SINC_MEDIUM_QUALITY, 1) state per block, :61).  Control flow, output count law and

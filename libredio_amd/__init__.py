@@ -100,6 +100,10 @@ def lib():
     _sig(L.redio_src_process, i, vp, vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_double, i, pl, pl, vp)
     _sig(L.redio_src_process_host, i, vp, pf, C.c_long, pf, C.c_long, C.c_double, i, pl, pl)
     _sig(L.redio_src_table, i, i, pf, C.POINTER(i), C.POINTER(i))
+    _sig(L.redio_pfb_create, i, C.POINTER(vp), pf, i, i, u)
+    _sig(L.redio_pfb_destroy, i, vp)
+    _sig(L.redio_pfb_nrows, sz, vp, sz)
+    _sig(L.redio_pfb_enqueue, i, vp, vp, sz, vp, i, vp)
     _sig(L.redio_synth_iq, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _sig(L.redio_synth_f32, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _lib = L
@@ -156,4 +160,4 @@ def check(code, what="redio"):
 
 
 from . import dsputils, kissfft, plans, samplerate  # noqa: E402,F401
-from .plans import Chain, Fft, Fir, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from .plans import Chain, Channelizer, Fft, Fir, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401

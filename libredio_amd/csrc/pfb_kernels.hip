@@ -1,0 +1,127 @@
+// pfb_kernels.hip -- 64-channel polyphase channelizer (BASELINE.json configs[3]) on gfx950.
+// Lane programs, layouts and the arithmetic contract: pfb_core.h.
+//
+// Algorithmic bytes: 8 B read + 8 B written per input sample (16 B/sample); 4 P + 30 flop per sample.
+// Bound: HBM.  Each wavefront owns a contiguous range of rows (time instants), carries the P-1 rows
+// of filter history in registers from tile to tile so every input row is loaded exactly once
+// (512 contiguous bytes per wave instruction), and prefetches the next tile's rows while it computes.
+#include "fft_wave.h"
+#include "pfb_core.h"
+#include "redio_internal.h"
+
+namespace redio {
+
+template <int P, bool FUSED>
+__global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x, const float *__restrict__ h,
+                                                    const float2 *__restrict__ tw, float2 *__restrict__ out, long rows,
+                                                    long rows_per_wave, int ngroups)
+{
+    static_assert(PFB_TILE % P == 0, "the register window rotates in place only if the tile is a multiple of P");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2 *lds = reinterpret_cast<float2 *>(smem) + wave * PFB_LDS;
+    const long t0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave;
+    if (t0 >= rows) return; // wave-uniform; no workgroup barrier in this kernel
+    const long t1 = (t0 + rows_per_wave < rows) ? t0 + rows_per_wave : rows;
+    const long last_in_row = rows + P - 2; // T - 1
+
+    float g[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) g[p] = h[PFB_M * p + lane];
+    float2 win[P];
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p) win[p] = x[PFB_M * (t0 + p) + lane];
+    float2 cur[PFB_TILE], nx[PFB_TILE];
+#pragma unroll
+    for (int ti = 0; ti < PFB_TILE; ++ti) {
+        long r = t0 + ti + P - 1;
+        r = r < last_in_row ? r : last_in_row;
+        cur[ti] = x[PFB_M * r + lane];
+    }
+    for (long tb = t0; tb < t1; tb += PFB_TILE) {
+        if (tb + PFB_TILE < t1) {
+#pragma unroll
+            for (int ti = 0; ti < PFB_TILE; ++ti) {
+                long r = tb + PFB_TILE + ti + P - 1;
+                r = r < last_in_row ? r : last_in_row;
+                nx[ti] = x[PFB_M * r + lane];
+            }
+        }
+        // branch FIRs: lane = branch, strict fold over p (dsputils.rs:31)
+#pragma unroll
+        for (int ti = 0; ti < PFB_TILE; ++ti) {
+            win[(ti + P - 1) % P] = cur[ti];
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc = mac<FUSED>(win[(ti + p) % P], g[p], acc);
+            lds[pfb_x1_store(ti, lane)] = acc;
+        }
+        wave_lds_fence();
+        float2 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = lds[pfb_x1_load(lane, e)];
+        wave_lds_fence();
+        pfb_fft64_passAB<false>(v, tw);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) lds[pfb_x2_store(lane, k1, k2)] = v[k1 + 4 * k2];
+        wave_lds_fence();
+#pragma unroll
+        for (int f = 0; f < 16; ++f) v[f] = lds[pfb_x2_load(lane, f)];
+        wave_lds_fence();
+        pfb_fft64_passC<false>(v, lane, tw);
+        const long row = tb + (lane >> 2);
+        if (row < t1) {
+#pragma unroll
+            for (int k0 = 0; k0 < 4; ++k0) {
+                if (ngroups <= 16) { // the four k2 of one k0 are consecutive channels of one group: a 32-byte run
+                    float2 *dst = out + pfb_out_index(row, pfb_out_channel(lane, k0, 0), rows, ngroups);
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) dst[k2] = v[k0 + 4 * k2];
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) out[pfb_out_index(row, pfb_out_channel(lane, k0, k2), rows, ngroups)] = v[k0 + 4 * k2];
+                }
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < PFB_TILE; ++ti) cur[ti] = nx[ti];
+    }
+}
+
+bool pfb_supported(int nchan, int taps_per_branch)
+{
+    return nchan == PFB_M && (taps_per_branch == 4 || taps_per_branch == 8 || taps_per_branch == 16);
+}
+
+template <int P>
+static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw, float2 *out, long rows, int ngroups,
+                               bool fused, hipStream_t s)
+{
+    // contiguous row ranges per wave, a multiple of the 16-row tile; aim for >= 8 waves per CU
+    long waves = 8L * 256;
+    long rpw = (rows + waves - 1) / waves;
+    rpw = ((rpw + PFB_TILE - 1) / PFB_TILE) * PFB_TILE;
+    if (rpw < 4 * PFB_TILE) rpw = 4 * PFB_TILE; // amortise the P-1 row prologue
+    const long nwaves = (rows + rpw - 1) / rpw;
+    const unsigned grid = (unsigned)((nwaves + 3) / 4);
+    const size_t lds = 4 * PFB_LDS * sizeof(float2);
+    if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+    else hipLaunchKernelGGL((pfb64_kernel<P, false>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_pfb(const float2 *x, const float *h, const float2 *tw64, float2 *out, long rows, int taps_per_branch,
+                      int ngroups, bool fused, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    switch (taps_per_branch) {
+    case 16: return launch_pfb_t<16>(x, h, tw64, out, rows, ngroups, fused, s);
+    case 8: return launch_pfb_t<8>(x, h, tw64, out, rows, ngroups, fused, s);
+    case 4: return launch_pfb_t<4>(x, h, tw64, out, rows, ngroups, fused, s);
+    default: return hipErrorNotSupported;
+    }
+}
+
+} // namespace redio

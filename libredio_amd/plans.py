@@ -162,3 +162,54 @@ def synth_f32(seed, first, n, device="cuda"):
     out = torch.empty(n, dtype=torch.float32, device=device)
     check(lib().redio_synth_f32(_dev_ptr(out), seed, first, n, current_stream()), "synth_f32")
     return out
+
+
+class Channelizer:
+    """redio_pfb_*: 64-channel polyphase channelizer (BASELINE.json configs[3]): branch FIRs with the
+    dsputils fold + kissfft across branches.  out[row][channel], or [group][row][64/ngroups] for the
+    multi-GPU regrouping (see channelizer_all_to_all)."""
+
+    def __init__(self, proto, nchan=64, taps_per_branch=16, fused=True):
+        t, p = _taps(proto)
+        assert len(t) == nchan * taps_per_branch
+        self.nchan, self.taps_per_branch = int(nchan), int(taps_per_branch)
+        self._h = C.c_void_p()
+        check(lib().redio_pfb_create(C.byref(self._h), p, self.nchan, self.taps_per_branch,
+                                     REDIO_FIR_FUSED if fused else 0), "pfb_create")
+
+    def nrows(self, n_in):
+        return lib().redio_pfb_nrows(self._h, n_in)
+
+    def __call__(self, x, ngroups=1, out=None):
+        import torch
+        assert x.dtype == torch.complex64
+        rows = self.nrows(x.numel())
+        if out is None:
+            shape = (rows, self.nchan) if ngroups == 1 else (ngroups, rows, self.nchan // ngroups)
+            out = torch.empty(shape, dtype=torch.complex64, device=x.device)
+        check(lib().redio_pfb_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), int(ngroups), current_stream()), "pfb_enqueue")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().redio_pfb_destroy(self._h)
+            self._h = None
+
+
+def channelizer_all_to_all(grouped, group=None):
+    """The one exchange step of the time-sharded channelizer: every rank holds
+    grouped[g] = [its rows][channels of rank g]; after the all-to-all rank g holds
+    [all rows, in rank (= time) order][its channels].  Rows per rank may differ (ragged split sizes).
+    Works with any torch.distributed backend (nccl = RCCL over xGMI on the GPU box, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    assert grouped.shape[0] == world
+    my_rows, cpg = grouped.shape[1], grouped.shape[2]
+    rows = [torch.zeros(1, dtype=torch.int64, device=grouped.device) for _ in range(world)]
+    dist.all_gather(rows, torch.tensor([my_rows], dtype=torch.int64, device=grouped.device), group=group)
+    rows = [int(r) for r in rows]
+    send = torch.view_as_real(grouped.contiguous()).reshape(world * my_rows, cpg * 2)
+    recv = torch.empty((sum(rows), cpg * 2), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rows, input_split_sizes=[my_rows] * world, group=group)
+    return torch.view_as_complex(recv.reshape(sum(rows), cpg, 2))

@@ -64,6 +64,8 @@ def lib():
     L.orc_synth_f32.argtypes = [C.c_uint32, C.c_uint64, sz, _f32p]; L.orc_synth_f32.restype = None
     L.orc_chain_fir_fft.argtypes = [_c64p, sz, _f32p, sz, sz, C.c_int, C.c_int, _c64p]
     L.orc_chain_fir_fft.restype = sz
+    L.orc_pfb_channelizer.argtypes = [_c64p, sz, _f32p, C.c_int, C.c_int, C.c_int, _c64p]
+    L.orc_pfb_channelizer.restype = sz
     L.orc_src_new.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]; L.orc_src_new.restype = C.c_void_p
     L.orc_src_delete.argtypes = [C.c_void_p]; L.orc_src_delete.restype = None
     L.orc_src_process.argtypes = [C.c_void_p, C.POINTER(SrcData)]; L.orc_src_process.restype = C.c_int
@@ -181,6 +183,19 @@ def chain_fir_fft(x, taps, decim, nfft, fused=False):
     out = np.empty((ny // nfft) * nfft, np.complex64)
     nb = lib().orc_chain_fir_fft(x, len(x), taps, k, decim, nfft, int(fused), out)
     return out[: nb * nfft].reshape(nb, nfft)
+
+
+def pfb_channelizer(x, h, M, P, fused=False):
+    """M-channel polyphase channelizer: branch FIRs (dsputils fold) + kissfft across branches."""
+    x = _c64(x); h = _f32(h)
+    assert len(h) == M * P
+    T = len(x) // M
+    rows = max(T - P + 1, 0)
+    out = np.empty((rows, M), np.complex64)
+    if rows:
+        n = lib().orc_pfb_channelizer(x, len(x), h, M, P, int(fused), out)
+        assert n == rows
+    return out
 
 
 # ---- A6 -------------------------------------------------------------------------------------

@@ -280,3 +280,44 @@ size_t orc_chain_fir_fft(const orc_cpx *x, size_t n, const float *taps, size_t k
     free(y);
     return nblk;
 }
+
+/* ---------------------------------------------------------------- C4 polyphase channelizer */
+
+/* M-channel critically-sampled analysis filterbank composed from the two reference primitives
+ * (a new composition): with rows x_t[m] = x[M t + m] and branch filters
+ * g_m[p] = h[M p + m] (prototype h of M*P taps),
+ *     v_t[m] = fold_{p=0..P-1} x_{t+p}[m] * g_m[p]      -- dsputils::convolve per branch (dsputils.rs:31)
+ *     out_t  = kiss_fft_M(v_t)  forward                  -- kissfft::fft per row (kissfft.rs:26)
+ * for t = 0 .. T-P where T = floor(n / M).  Returns the number of output rows. */
+size_t orc_pfb_channelizer(const orc_cpx *x, size_t n, const float *h, int M, int P, int fused, orc_cpx *out)
+{
+    if (M <= 0 || P <= 0) return 0;
+    size_t T = n / (size_t)M;
+    if (T < (size_t)P) return 0;
+    size_t rows = T - (size_t)P + 1;
+    orc_kiss_state *st = orc_kiss_fft_alloc(M, 0);
+    orc_cpx *v = (orc_cpx *)malloc((size_t)M * sizeof(orc_cpx));
+    for (size_t t = 0; t < rows; ++t) {
+        for (int m = 0; m < M; ++m) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int p = 0; p < P; ++p) {
+                const orc_cpx s = x[(size_t)M * (t + (size_t)p) + (size_t)m];
+                const float g = h[(size_t)M * (size_t)p + (size_t)m];
+                if (fused) {
+                    ar = fmaf(s.r, g, ar);
+                    ai = fmaf(s.i, g, ai);
+                } else {
+                    float pr = s.r * g, pi = s.i * g;
+                    ar = ar + pr;
+                    ai = ai + pi;
+                }
+            }
+            v[m].r = ar;
+            v[m].i = ai;
+        }
+        orc_kiss_fft(st, v, out + t * (size_t)M);
+    }
+    free(v);
+    orc_kiss_fft_free(st);
+    return rows;
+}

@@ -71,6 +71,9 @@ void orc_synth_f32(uint32_t seed, uint64_t first_sample, size_t n, float *out);
 size_t orc_chain_fir_fft(const orc_cpx *x, size_t n, const float *taps, size_t k, size_t decim,
                          int nfft, int fused, orc_cpx *out);
 
+/* ---- C4: M-channel polyphase channelizer = per-branch convolve + per-row kiss_fft (new composition) ---- */
+size_t orc_pfb_channelizer(const orc_cpx *x, size_t n, const float *h, int M, int P, int fused, orc_cpx *out);
+
 /* ---- A6/A6x: samplerate::resample, src/samplerate/src/samplerate.rs:59-87 + src_sinc.c ---- */
 typedef struct {
     const float *data_in; float *data_out;

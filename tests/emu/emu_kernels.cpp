@@ -4,6 +4,7 @@
 // the very same headers, one lane at a time, against the oracle.  g++ -ffp-contract=off.
 #include "../../libredio_amd/csrc/fft_core.h"
 #include "../../libredio_amd/csrc/fir_core.h"
+#include "../../libredio_amd/csrc/pfb_core.h"
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -233,4 +234,49 @@ extern "C" int emu_fir_bank_conflicts(void)
     if ((t = fir_banks<127, 5, 4>(1)) > w) w = t;
     if ((t = fir_banks<63, 1, 8>(1)) > w) w = t;
     return w;
+}
+
+// 64-channel polyphase channelizer: one wave tile (16 rows) at a time, lane programs of pfb_core.h
+template <int P, bool FUSED>
+static long emu_pfb_t(const float2 *x, long n, const float *h, float2 *out, int ngroups)
+{
+    const long T = n / PFB_M;
+    if (T < P) return 0;
+    const long rows = T - P + 1;
+    std::vector<float2> tw = make_tw(64, 0);
+    std::vector<float2> l1(PFB_LDS), l2(PFB_LDS);
+    for (long tb = 0; tb < rows; tb += PFB_TILE) {
+        for (int lane = 0; lane < 64; ++lane)      // branch FIRs, lane = branch
+            for (int ti = 0; ti < PFB_TILE; ++ti) {
+                long t = tb + ti;
+                if (t >= rows) t = rows - 1;       // clamped (masked at the store)
+                float2 acc = make_float2(0.f, 0.f);
+                for (int p = 0; p < P; ++p) acc = mac<FUSED>(x[PFB_M * (t + p) + lane], h[PFB_M * p + lane], acc);
+                l1[pfb_x1_store(ti, lane)] = acc;
+            }
+        for (int lane = 0; lane < 64; ++lane) {
+            float2 v[16];
+            for (int e = 0; e < 16; ++e) v[e] = l1[pfb_x1_load(lane, e)];
+            pfb_fft64_passAB<false>(v, tw.data());
+            for (int k2 = 0; k2 < 4; ++k2)
+                for (int k1 = 0; k1 < 4; ++k1) l2[pfb_x2_store(lane, k1, k2)] = v[k1 + 4 * k2];
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            float2 w[16];
+            for (int f = 0; f < 16; ++f) w[f] = l2[pfb_x2_load(lane, f)];
+            pfb_fft64_passC<false>(w, lane, tw.data());
+            const long row = tb + (lane >> 2);
+            if (row < rows)
+                for (int k2 = 0; k2 < 4; ++k2)
+                    for (int k0 = 0; k0 < 4; ++k0) out[pfb_out_index(row, pfb_out_channel(lane, k0, k2), rows, ngroups)] = w[k0 + 4 * k2];
+        }
+    }
+    return rows;
+}
+extern "C" long emu_pfb(const float2 *x, long n, const float *h, int P, int fused, float2 *out, int ngroups)
+{
+    if (P == 16) return fused ? emu_pfb_t<16, true>(x, n, h, out, ngroups) : emu_pfb_t<16, false>(x, n, h, out, ngroups);
+    if (P == 8) return fused ? emu_pfb_t<8, true>(x, n, h, out, ngroups) : emu_pfb_t<8, false>(x, n, h, out, ngroups);
+    if (P == 4) return fused ? emu_pfb_t<4, true>(x, n, h, out, ngroups) : emu_pfb_t<4, false>(x, n, h, out, ngroups);
+    return -1;
 }

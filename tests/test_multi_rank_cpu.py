@@ -83,3 +83,41 @@ def test_slice_arithmetic():
     rows = [S.channelizer_time_shard(r, 8, 1000, 16) for r in range(8)]
     assert sum(r[1] for r in rows) == 985 and all(r[2] == r[1] + 15 for r in rows)
     assert S.channelizer_exchange_layout(8, 64) == 8
+
+
+def _a2a_worker(rank, world, port, q):
+    import oracle as O
+    from libredio_amd import sharding
+    from libredio_amd.plans import channelizer_all_to_all
+    _init(rank, world, port)
+    P, M = 16, 64
+    h = O.lpf_corrected(M * P, 0.45 / M)
+    total_rows = 333                                   # input rows; ragged over two ranks
+    first, nout, nin = sharding.channelizer_time_shard(rank, world, total_rows, P)
+    x = O.synth_iq(0x5EED0004, M * first, M * nin)     # this rank's rows plus P-1 rows of look-ahead
+    y = O.pfb_channelizer(x, h, M, P, True)            # [nout][64] (stand-in for the GPU kernel)
+    assert y.shape[0] == nout
+    cpg = sharding.channelizer_exchange_layout(world, M)
+    grouped = torch.from_numpy(np.ascontiguousarray(y.reshape(nout, world, cpg).transpose(1, 0, 2)))  # [g][row][cpg]
+    mine = channelizer_all_to_all(grouped).numpy()     # [all rows][my channels]
+    whole = O.pfb_channelizer(O.synth_iq(0x5EED0004, 0, M * total_rows), h, M, P, True)
+    ok = mine.shape == (total_rows - P + 1, cpg) and np.array_equal(
+        mine.view(np.uint32), np.ascontiguousarray(whole[:, rank * cpg:(rank + 1) * cpg]).view(np.uint32))
+    oks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(oks, torch.tensor([int(ok)]))
+    if rank == 0:
+        q.put(all(int(o) == 1 for o in oks))
+    dist.destroy_process_group()
+
+
+def test_channelizer_all_to_all_regroups_time_shards_into_channel_shards():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_a2a_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -1,0 +1,55 @@
+"""Throughput of the non-headline configs of BASELINE.json on one MI355X (own measurements; bench.py
+stays on configs[1]).  usage: python tools/bench_configs.py [c3|c4|fir|fft]..."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, libredio_amd as R
+
+
+def timeit(f, n=50, warm=10):
+    for _ in range(warm): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+which = sys.argv[1:] or ["c4", "fir", "fft"]
+n = 1 << 28
+if "c4" in which:
+    h = R.dsputils.lpf_corrected(1024, 0.45 / 64)
+    x = R.synth_iq(0x5EED0004, 0, n)
+    plan = R.Channelizer(h)
+    out = torch.empty((plan.nrows(n), 64), dtype=torch.complex64, device="cuda")
+    ms = timeit(lambda: plan(x, out=out))
+    print(f"C4 channelizer 64ch P=16: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {16*n/ms/1e6:.0f} GB/s algorithmic ({16*n/ms/1e6/8000:.1%} of 8 TB/s)")
+    g = torch.empty((8, plan.nrows(n), 8), dtype=torch.complex64, device="cuda")
+    ms = timeit(lambda: plan(x, ngroups=8, out=g))
+    print(f"C4 channelizer grouped x8 layout: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s")
+if "fir" in which:
+    taps = R.dsputils.lpf_corrected(127, 0.08)
+    x = R.synth_iq(1, 0, n)
+    for d in (5, 1):
+        plan = R.Fir(taps, d, fused=True)
+        out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan(x, out=out), n=20)
+        b = 8 + 8 / d
+        print(f"FIR 127 taps /{d}: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {b*n/ms/1e6:.0f} GB/s algorithmic ({b*n/ms/1e6/8000:.1%})")
+if "fft" in which:
+    for nfft in (1024, 64, 4096, 65536):
+        x = R.synth_iq(2, 0, n if nfft != 65536 else 1 << 24)
+        plan = R.Fft(nfft)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: plan(x, out=out), n=20 if nfft != 65536 else 5, warm=3)
+        print(f"FFT {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  {16*x.numel()/ms/1e6:.0f} GB/s algorithmic ({16*x.numel()/ms/1e6/8000:.1%})")
+if "c3" in which:
+    nch, frames = 256, 1 << 20
+    x = torch.stack([R.synth_f32(100 + c, 0, frames) for c in range(nch)])
+    plan = R.Src(nch, 1)
+    import time
+    plan.process(x, 0.02)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out, used = plan.process(x, 0.02)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"C3 resample 1/50 x{nch} ch, {frames} frames each (exact mode): {dt*1e3:.1f} ms  {nch*frames/dt/1e9:.2f} GS/s")
