@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors in tests/golden/ (small .npz files).
+
+The reference ships no vectors and cannot be run here, so these are produced by the
+CPU oracle (oracle/) and, where an independent definition exists, cross-checked against float64
+numpy at generation time.  Inputs are the hash-generated streams of SURVEY.md 8d, stored alongside
+the expected outputs so a fixture is self-contained data.  Re-running this script must reproduce the
+files bit for bit (tests/test_golden.py::test_generator_is_reproducible).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle as O  # noqa: E402
+
+
+def fir_cases():
+    out = {}
+    for name, k, d, cplx in (("k3", 3, 1, False), ("k63", 63, 1, False), ("k127", 127, 1, True), ("k127d5", 127, 5, True)):
+        taps = O.lpf_corrected(k, 0.08) if k > 3 else np.array([0.25, 0.5, 0.25], np.float32)
+        x = O.synth_iq(0x5EED0000 + k, 0, 4096) if cplx else O.synth_f32(0x5EED0000 + k, 0, 4096)
+        y = O.fir(x, taps, d, fused=False)
+        yf = O.fir(x, taps, d, fused=True)
+        ref = np.correlate(x.astype(np.complex128 if cplx else np.float64), taps.astype(np.float64), "valid")[::d]
+        assert np.abs(y - ref).max() <= k * 2.0 ** -24 * np.abs(taps).sum()
+        out.update({f"{name}_x": x, f"{name}_taps": taps, f"{name}_y": y, f"{name}_y_fused": yf, f"{name}_decim": np.int64(d)})
+    # quirk generators: NaN position recorded
+    for m in (4, 63, 127):
+        out[f"quirk_lpf_{m}"] = O.lpf(m, 0.1)
+        out[f"quirk_window_{m}"] = O.window(m)
+    out["corrected_lpf_63_0p1"] = O.lpf_corrected(63, 0.1)
+    out["corrected_lpf_127_0p08"] = O.lpf_corrected(127, 0.08)
+    return out
+
+
+def fft_cases():
+    out = {}
+    for n in (4, 16, 64, 1024, 30, 7):
+        for kind in ("impulse", "tone", "random"):
+            if kind == "impulse":
+                x = np.zeros(n, np.complex64); x[1 % n] = 1
+            elif kind == "tone":
+                x = np.exp(2j * np.pi * 3 * np.arange(n) / n).astype(np.complex64)
+            else:
+                x = O.synth_iq(0x5EED0100 + n, 0, n)
+            for inv in (0, 1):
+                X = O.fft(x, inverse=bool(inv))
+                ref = np.fft.fft(x.astype(np.complex128)) if not inv else np.fft.ifft(x.astype(np.complex128)) * n
+                assert np.linalg.norm(X - ref) <= 2e-6 * max(np.linalg.norm(ref), 1e-30)
+                out[f"n{n}_{kind}_inv{inv}_x"] = x
+                out[f"n{n}_{kind}_inv{inv}_X"] = X
+    # 65536: hash only -- stored as the uint32 bit pattern checksum
+    x = O.synth_iq(0x5EED0165, 0, 65536)
+    X = O.fft(x)
+    out["n65536_random_checksum"] = np.array([int(X.view(np.uint32).astype(np.uint64).sum())], np.uint64)
+    return out
+
+
+def chain_cases():
+    taps = O.lpf_corrected(127, 0.08)
+    x = O.synth_iq(0x5EED0002, 0, 2 * 5120 + 126)
+    return {"x": x, "taps": taps, "spectra": O.chain_fir_fft(x, taps, 5, 1024, fused=False),
+            "spectra_fused": O.chain_fir_fft(x, taps, 5, 1024, fused=True)}
+
+
+def resample_cases():
+    out = {}
+    x = O.synth_f32(0x5EED0003, 0, 12000)
+    out["x"] = x
+    for name, ratio in (("r0p02", 0.02), ("r0p5", 0.5), ("r2", 2.0), ("r48_44p1", 48000 / 44100)):
+        for sname, seg in (("one", [12000]), ("three", [5000, 1, 6999]), ("many", [1000] * 12)):
+            r = O.Resampler(1)
+            ys, off = [], 0
+            for m in seg:
+                ys.append(r.block(x[off:off + m], ratio)); off += m
+            out[f"{name}_{sname}_y"] = np.concatenate(ys)
+            out[f"{name}_{sname}_counts"] = np.array([len(y) for y in ys], np.int64)
+        out[f"{name}_ratio"] = np.float64(ratio)
+    return out
+
+
+def bit_cases():
+    out = {}
+    bytes_all = np.arange(256, dtype=np.uint8)
+    out["d2s_bytes"] = np.repeat(bytes_all, 2)
+    out["d2s_samples"] = O.data_to_samples(out["d2s_bytes"])
+    x = O.synth_f32(0x5EED0009, 0, 512) ** 2
+    out["disc_x"] = x
+    out["disc_bits"] = O.discretize(x).astype(np.uint8)
+    rng = np.random.default_rng(0x5EED)
+    bits36 = rng.integers(0, 2, 36).astype(np.uint64)
+    out["eat_bits36"] = bits36
+    out["eat_w_4_8_4_12_8"] = np.array(O.eat(bits36, [4, 8, 4, 12, 8]), np.uint64)   # ratpak.rs:115
+    out["eat_w_4_8_2_10_12"] = np.array(O.eat(bits36, [4, 8, 2, 10, 12]), np.uint64)  # ratpak.rs:119
+    out["b2d_101"] = np.array([O.b2d([1, 0, 1])], np.uint64)
+    return out
+
+
+def pfb_cases():
+    h = O.lpf_corrected(1024, 0.45 / 64)
+    x = O.synth_iq(0x5EED0004, 0, 64 * 20)
+    return {"x": x, "proto": h, "y": O.pfb_channelizer(x, h, 64, 16, False), "y_fused": O.pfb_channelizer(x, h, 64, 16, True)}
+
+
+CASES = {"fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
+
+
+def generate(outdir=HERE):
+    for name, fn in CASES.items():
+        np.savez(os.path.join(outdir, f"{name}.npz"), **fn())
+
+
+if __name__ == "__main__":
+    generate()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
