@@ -92,6 +92,8 @@ typedef struct redio_fft redio_fft;
 int redio_fft_create(redio_fft **h, int nfft, int inverse);
 int redio_fft_destroy(redio_fft *h);
 int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, void *stream);
+/* messages that start every in_stride samples (overlapping blocks when in_stride < nfft); no aliasing */
+int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, long in_stride, void *stream);
 
 /* ---- C2 chain: FIR (ntaps, decimate decim) -> nfft-point forward FFT of consecutive blocks ----
  * Fused single kernel for (ntaps, decim, nfft) = (127, 5, 1024); other shapes run the FIR and FFT
@@ -107,6 +109,18 @@ int redio_chain_set_unfused(redio_chain *h, int unfused);
 /* kernel generation of the fused path, for A/B measurement: 0 = current (default), 1 = first, 2 = second */
 int redio_chain_set_variant(redio_chain *h, int variant);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
+
+/* ---- C5: overlap-save FFT convolution (BASELINE.json configs[4]; a new composition) ----
+ * The valid-mode correlation of dsputils::convolve (dsputils.rs:30-32) on cf32 with real taps, computed
+ * per block of nfft samples: out[b*hop + i] = IFFT(FFT(x[b*hop ..]) .* conj(FFT(taps)))[i] / nfft, i < hop,
+ * hop = nfft - ntaps + 1, kissfft-order transforms.  Only whole blocks are produced:
+ * nout = ((n_in - nfft)/hop + 1) * hop, 0 when n_in < nfft.  Bit-identical to oracle orc_overlap_save;
+ * within K*eps*sum|x*h| of the direct fold. */
+typedef struct redio_ovsave redio_ovsave;
+int redio_ovsave_create(redio_ovsave **h, const float *taps_host, size_t ntaps, int nfft);
+int redio_ovsave_destroy(redio_ovsave *h);
+size_t redio_ovsave_nout(const redio_ovsave *h, size_t n_in);
+int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_in, void *d_out, void *stream);
 
 /* ---- C4: M-channel polyphase channelizer (BASELINE.json configs[3]; a new composition) ----
  * Prototype of nchan*taps_per_branch taps; branch m filters rows x_t[m] = x[nchan*t + m] with

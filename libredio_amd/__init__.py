@@ -100,6 +100,11 @@ def lib():
     _sig(L.redio_src_process, i, vp, vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_double, i, pl, pl, vp)
     _sig(L.redio_src_process_host, i, vp, pf, C.c_long, pf, C.c_long, C.c_double, i, pl, pl)
     _sig(L.redio_src_table, i, i, pf, C.POINTER(i), C.POINTER(i))
+    _sig(L.redio_fft_enqueue_strided, i, vp, vp, vp, sz, C.c_long, vp)
+    _sig(L.redio_ovsave_create, i, C.POINTER(vp), pf, sz, i)
+    _sig(L.redio_ovsave_destroy, i, vp)
+    _sig(L.redio_ovsave_nout, sz, vp, sz)
+    _sig(L.redio_ovsave_enqueue, i, vp, vp, sz, vp, vp)
     _sig(L.redio_pfb_create, i, C.POINTER(vp), pf, i, i, u)
     _sig(L.redio_pfb_destroy, i, vp)
     _sig(L.redio_pfb_nrows, sz, vp, sz)
@@ -160,4 +165,4 @@ def check(code, what="redio"):
 
 
 from . import dsputils, kissfft, plans, samplerate  # noqa: E402,F401
-from .plans import Chain, Channelizer, Fft, Fir, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from .plans import Chain, Channelizer, Fft, Fir, OverlapSave, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401

@@ -14,26 +14,26 @@ namespace redio {
 
 template <bool INV>
 __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float2 *out,
-                                                         const float2 *__restrict__ tw, long nbatch)
+                                                         const float2 *__restrict__ tw, long nbatch, long in_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
     const long b = (long)blockIdx.x * 4 + wave;
     if (b >= nbatch) return; // wave-uniform
-    fft1k_wave<INV>(in + b * 1024, out + b * 1024, ex, tw, lane);
+    fft1k_wave<INV>(in + b * in_stride, out + b * 1024, ex, tw, lane);
 }
 
 // ---- any N that fits LDS: one workgroup per transform ----------------------------------------
 template <bool INV>
 __global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2 *in,
-                                                      float2 *out, int two_buffers)
+                                                      float2 *out, long in_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *A = reinterpret_cast<float2 *>(smem);
     float2 *B = A + p.nfft;
     const int n = p.nfft, tid = threadIdx.x, nt = blockDim.x;
-    const float2 *src = in + (long)blockIdx.x * n;
+    const float2 *src = in + (long)blockIdx.x * in_stride;
     float2 *dst = out + (long)blockIdx.x * n;
     for (int P = tid; P < n; P += nt) A[P] = src[p.leaf_src[P]];
     __syncthreads();
@@ -54,19 +54,18 @@ __global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2
             float2 *t = A; A = B; B = t;
         }
     }
-    (void)two_buffers;
     for (int P = tid; P < n; P += nt) dst[P] = A[P];
 }
 
 // ---- large N: global-memory stages -----------------------------------------------------------
 __global__ __launch_bounds__(256) void fft_global_leaf_kernel(FftPlanDev p, const float2 *__restrict__ in,
-                                                              float2 *__restrict__ out, long total)
+                                                              float2 *__restrict__ out, long total, long in_stride)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const long b = i / p.nfft;
     const int P = (int)(i - b * p.nfft);
-    out[i] = in[b * p.nfft + p.leaf_src[P]];
+    out[i] = in[b * in_stride + p.leaf_src[P]];
 }
 
 template <bool INV>
@@ -81,15 +80,16 @@ __global__ __launch_bounds__(256) void fft_global_stage_kernel(FftPlanDev p, int
     fft_stage_butterfly<INV>(data + b * p.nfft, p.tw, st, bf);
 }
 
-hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s)
+hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride)
 {
+    if (in_stride <= 0) in_stride = p.nfft; // consecutive messages; smaller strides give overlapping blocks (overlap-save)
     if (nbatch <= 0) return hipSuccess;
     const bool inv = p.inverse != 0;
     if (p.nfft == 1024) {
         const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
         const unsigned grid = (unsigned)((nbatch + 3) / 4);
-        if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch);
-        else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch);
+        if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
     }
     bool generic = false;
@@ -104,13 +104,13 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
             if (e != hipSuccess) return e;
         }
         const int nt = p.nfft >= 1024 ? 256 : (p.nfft >= 256 ? 128 : 64);
-        if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, (int)generic);
-        else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, (int)generic);
+        if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
+        else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         return hipGetLastError();
     }
     if (generic || in == out) return hipErrorNotSupported; // the C-ABI layer routes in-place calls through a temporary
     const long total = nbatch * p.nfft;
-    hipLaunchKernelGGL(fft_global_leaf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, in, out, total);
+    hipLaunchKernelGGL(fft_global_leaf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, in, out, total, in_stride);
     for (int st = p.nstages - 1; st >= 0; --st) {
         const long nb = nbatch * (p.nfft / p.st[st].p);
         const unsigned grid = (unsigned)((nb + 255) / 256);

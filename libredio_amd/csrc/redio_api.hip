@@ -263,6 +263,19 @@ extern "C" int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, si
     return hip_rc(e);
 }
 
+// messages that start every in_stride samples (in_stride < nfft: overlapping blocks, as overlap-save
+// needs); d_in and d_out must not alias
+extern "C" int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, long in_stride, void *stream)
+{
+    if (!h) return REDIO_ERR_ARG;
+    if (nbatch == 0) return REDIO_OK;
+    if (!d_in || !d_out || d_in == d_out || in_stride <= 0) return REDIO_ERR_ARG;
+    RD_TRY(hipSetDevice(h->device));
+    hipError_t e = launch_fft(h->dev, (const float2 *)d_in, (float2 *)d_out, (long)nbatch, (hipStream_t)stream, in_stride);
+    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
+    return hip_rc(e);
+}
+
 // ---------------------------------------------------------------- chain plan
 struct redio_chain {
     redio_fir *fir;

@@ -23,7 +23,7 @@ struct FftPlanDev {
 };
 // in != out required unless work is given; work (nfft*nbatch float2) is used for in-place calls and
 // by the global-memory path
-hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s);
+hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0);
 
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);

@@ -213,3 +213,31 @@ def channelizer_all_to_all(grouped, group=None):
     recv = torch.empty((sum(rows), cpg * 2), dtype=send.dtype, device=send.device)
     dist.all_to_all_single(recv, send, output_split_sizes=rows, input_split_sizes=[my_rows] * world, group=group)
     return torch.view_as_complex(recv.reshape(sum(rows), cpg, 2))
+
+
+class OverlapSave:
+    """redio_ovsave_*: overlap-save FFT convolution (BASELINE.json configs[4]) with the semantics of
+    dsputils::convolve (valid-mode correlation, dsputils.rs:30-32) on complex64 streams."""
+
+    def __init__(self, taps, nfft=65536):
+        t, p = _taps(taps)
+        self.ntaps, self.nfft = len(t), int(nfft)
+        self._h = C.c_void_p()
+        check(lib().redio_ovsave_create(C.byref(self._h), p, len(t), self.nfft), "ovsave_create")
+
+    def nout(self, n_in):
+        return lib().redio_ovsave_nout(self._h, n_in)
+
+    def __call__(self, x, out=None):
+        import torch
+        assert x.dtype == torch.complex64
+        n = self.nout(x.numel())
+        if out is None:
+            out = torch.empty(n, dtype=torch.complex64, device=x.device)
+        check(lib().redio_ovsave_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "ovsave_enqueue")
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().redio_ovsave_destroy(self._h)
+            self._h = None

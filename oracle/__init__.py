@@ -66,6 +66,7 @@ def lib():
     L.orc_chain_fir_fft.restype = sz
     L.orc_pfb_channelizer.argtypes = [_c64p, sz, _f32p, C.c_int, C.c_int, C.c_int, _c64p]
     L.orc_pfb_channelizer.restype = sz
+    L.orc_overlap_save.argtypes = [_c64p, sz, _f32p, sz, C.c_int, _c64p]; L.orc_overlap_save.restype = sz
     L.orc_src_new.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]; L.orc_src_new.restype = C.c_void_p
     L.orc_src_delete.argtypes = [C.c_void_p]; L.orc_src_delete.restype = None
     L.orc_src_process.argtypes = [C.c_void_p, C.POINTER(SrcData)]; L.orc_src_process.restype = C.c_int
@@ -183,6 +184,19 @@ def chain_fir_fft(x, taps, decim, nfft, fused=False):
     out = np.empty((ny // nfft) * nfft, np.complex64)
     nb = lib().orc_chain_fir_fft(x, len(x), taps, k, decim, nfft, int(fused), out)
     return out[: nb * nfft].reshape(nb, nfft)
+
+
+def overlap_save(x, h, nfft):
+    """convolve semantics (valid-mode correlation) through kissfft blocks of nfft samples."""
+    x = _c64(x); h = _f32(h)
+    k = len(h)
+    hop = nfft - k + 1
+    nblk = 0 if len(x) < nfft else (len(x) - nfft) // hop + 1
+    out = np.empty(nblk * hop, np.complex64)
+    if nblk:
+        n = lib().orc_overlap_save(x, len(x), h, k, nfft, out)
+        assert n == nblk * hop
+    return out
 
 
 def pfb_channelizer(x, h, M, P, fused=False):

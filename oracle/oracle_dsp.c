@@ -321,3 +321,40 @@ size_t orc_pfb_channelizer(const orc_cpx *x, size_t n, const float *h, int M, in
     orc_kiss_fft_free(st);
     return rows;
 }
+
+/* ---------------------------------------------------------------- C5 overlap-save FFT convolution */
+
+/* Valid-mode correlation y[i] = sum_j x[i+j] h[j] (the semantics of dsputils::convolve,
+ * dsputils.rs:30-32, on cf32 with real taps) computed block-wise in the frequency domain with
+ * kissfft: H = kiss_fft(h zero-padded to nfft); for every block b of nfft input samples starting at
+ * b*hop (hop = nfft-k+1): X = kiss_fft(block), Y[q] = X[q] * conj(H[q]) (C_MUL order),
+ * y = kiss_fft_inverse(Y), out[b*hop + i] = y[i] * (1.0f/nfft) for i < hop.  Only whole blocks are
+ * produced (a trailing partial block is dropped, as kpn::shaper would).  Returns outputs written. */
+size_t orc_overlap_save(const orc_cpx *x, size_t n, const float *h, size_t k, int nfft, orc_cpx *out)
+{
+    if (nfft <= 0 || k == 0 || k > (size_t)nfft || n < (size_t)nfft) return 0;
+    const size_t N = (size_t)nfft, hop = N - k + 1;
+    const size_t nblk = (n - N) / hop + 1;
+    orc_kiss_state *fw = orc_kiss_fft_alloc(nfft, 0), *bw = orc_kiss_fft_alloc(nfft, 1);
+    orc_cpx *hp = (orc_cpx *)calloc(N, sizeof(orc_cpx)), *H = (orc_cpx *)malloc(N * sizeof(orc_cpx));
+    orc_cpx *X = (orc_cpx *)malloc(N * sizeof(orc_cpx)), *Y = (orc_cpx *)malloc(N * sizeof(orc_cpx));
+    for (size_t j = 0; j < k; ++j) hp[j].r = h[j];
+    orc_kiss_fft(fw, hp, H);
+    for (size_t q = 0; q < N; ++q) H[q].i = -H[q].i; /* conj */
+    const float scale = 1.0f / (float)nfft;
+    for (size_t b = 0; b < nblk; ++b) {
+        orc_kiss_fft(fw, x + b * hop, X);
+        for (size_t q = 0; q < N; ++q) {
+            Y[q].r = X[q].r * H[q].r - X[q].i * H[q].i;
+            Y[q].i = X[q].r * H[q].i + X[q].i * H[q].r;
+        }
+        orc_kiss_fft(bw, Y, X);
+        for (size_t i = 0; i < hop; ++i) {
+            out[b * hop + i].r = X[i].r * scale;
+            out[b * hop + i].i = X[i].i * scale;
+        }
+    }
+    free(hp); free(H); free(X); free(Y);
+    orc_kiss_fft_free(fw); orc_kiss_fft_free(bw);
+    return nblk * hop;
+}

@@ -74,6 +74,9 @@ size_t orc_chain_fir_fft(const orc_cpx *x, size_t n, const float *taps, size_t k
 /* ---- C4: M-channel polyphase channelizer = per-branch convolve + per-row kiss_fft (new composition) ---- */
 size_t orc_pfb_channelizer(const orc_cpx *x, size_t n, const float *h, int M, int P, int fused, orc_cpx *out);
 
+/* ---- C5: overlap-save FFT convolution = convolve semantics through kiss_fft blocks (new composition) ---- */
+size_t orc_overlap_save(const orc_cpx *x, size_t n, const float *h, size_t k, int nfft, orc_cpx *out);
+
 /* ---- A6/A6x: samplerate::resample, src/samplerate/src/samplerate.rs:59-87 + src_sinc.c ---- */
 typedef struct {
     const float *data_in; float *data_out;

@@ -1,0 +1,46 @@
+"""Overlap-save FFT convolution (BASELINE.json configs[4]) on the MI355X: bit-exact against the
+oracle composition (kissfft-order transforms), and within the stated tolerance of the direct
+dsputils::convolve fold it replaces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("nfft,k", [(1024, 127), (4096, 63), (65536, 8193), (65536, 127), (256, 256), (64, 1)])
+def test_overlap_save_bit_exact_and_close_to_direct(gpu, redio, oracle, nfft, k):
+    taps = oracle.lpf_corrected(k, 0.02) if k > 1 else np.array([0.75], np.float32)
+    hop = nfft - k + 1
+    for n in (nfft, nfft + hop - 1, nfft + 2 * hop + 17):
+        x = oracle.synth_iq(0x5EED0005, 0, n)
+        plan = redio.OverlapSave(taps, nfft)
+        want = oracle.overlap_save(x, taps, nfft)
+        got = plan(gpu.from_numpy(x).cuda()).cpu().numpy()
+        assert len(got) == len(want) == ((n - nfft) // hop + 1) * hop
+        assert np.array_equal(bits(got), bits(want)), (nfft, k, n)
+        # vs the direct fold (A1 semantics): f32 FFT round trip error, stated tolerance 2e-6 * sum|h| * sqrt(log2 N)
+        direct = oracle.fir(x, taps, 1, False)[: len(got)]
+        assert np.abs(got - direct).max() <= 2e-6 * np.abs(taps).sum() * np.sqrt(np.log2(nfft)) + 1e-7
+
+
+def test_overlap_save_short_input_and_bad_args(gpu, redio, oracle):
+    plan = redio.OverlapSave(oracle.lpf_corrected(127, 0.1), 1024)
+    assert plan.nout(1023) == 0 and plan.nout(1024) == 898
+    assert plan(gpu.zeros(100, dtype=gpu.complex64, device="cuda")).numel() == 0
+    with pytest.raises(redio.RedioError):
+        redio.OverlapSave(oracle.lpf_corrected(127, 0.1), 64)   # more taps than the block
+
+
+def test_overlap_save_many_blocks_chunking(gpu, redio, oracle):
+    # more blocks than one work-buffer chunk (64 MiB / (1024*8 B) = 8192 blocks)
+    taps = oracle.lpf_corrected(127, 0.08)
+    n = 1024 + 898 * 9000
+    x = redio.synth_iq(3, 0, n)
+    y = redio.OverlapSave(taps, 1024)(x)
+    for b in (0, 8191, 8192, 9000):
+        xw = oracle.synth_iq(3, 898 * b, 1024)
+        assert np.array_equal(bits(y[898 * b: 898 * (b + 1)].cpu().numpy()), bits(oracle.overlap_save(xw, taps, 1024)))
