@@ -110,6 +110,30 @@ int redio_chain_set_unfused(redio_chain *h, int unfused);
 int redio_chain_set_variant(redio_chain *h, int variant);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
 
+/* ---- A9: the bit-exact ingest / slicing path of the shipped graph (src/ratpak.rs:60-76) ----
+ * All device-resident; results are bit-identical to the reference arithmetic (oracle_bits.c). */
+/* rtlsdr::data_to_samples, src/rtlsdr/src/rtlsdr.rs:159-162: byte pairs -> cf32 (i as f32/127.0 - 1.0);
+ * an odd byte count is the reference's index panic -> REDIO_ERR_ASSERT */
+int redio_data_to_samples(const void *d_bytes, size_t nbytes, void *d_out_c32, void *stream);
+/* the |x| map of src/ratpak.rs:64-68: Complex::norm = hypotf(re, im) */
+int redio_norm_c32(const void *d_in_c32, size_t n, void *d_out_f32, void *stream);
+/* both of the above fused: u8 IQ -> magnitude (2 B read + 4 B written per sample); d_bytes 8-byte and
+ * d_mag 16-byte aligned */
+int redio_ingest_u8_mag(const void *d_bytes, size_t nbytes, void *d_mag_f32, void *stream);
+/* per-block sums in sample order, the `s` of bitfount::trigger (src/bitfount/src/bitfount.rs:48) */
+int redio_block_sums(const void *d_in_f32, size_t nblocks, size_t block, void *d_sums_f32, void *stream);
+/* bitfount::discretize, src/bitfount/src/bitfount.rs:87-96: max = fold(0.0, f32::max); out = (x > max/2)
+ * as one byte per sample (the reference sends usize); d_scratch_u32 holds the max's bit pattern */
+int redio_discretize(const void *d_in_f32, size_t n, void *d_out_u8, void *d_scratch_u32, void *stream);
+/* bitfount::trigger, src/bitfount/src/bitfount.rs:36-85: state persists across calls; feeds nblocks
+ * blocks of `block` f32 magnitudes; emitted buffers are appended to d_out with their lengths in
+ * lens[] (host).  Synchronous (the adaptive threshold is a scalar recurrence run on the host). */
+typedef struct redio_trigger redio_trigger;
+int redio_trigger_create(redio_trigger **h);
+int redio_trigger_destroy(redio_trigger *h);
+int redio_trigger_feed(redio_trigger *h, const void *d_blocks_f32, size_t nblocks, size_t block, void *d_out_f32, size_t out_cap,
+                       size_t *lens, size_t lens_cap, size_t *nemit, size_t *total, void *stream);
+
 /* ---- C5: overlap-save FFT convolution (BASELINE.json configs[4]; a new composition) ----
  * The valid-mode correlation of dsputils::convolve (dsputils.rs:30-32) on cf32 with real taps, computed
  * per block of nfft samples: out[b*hop + i] = IFFT(FFT(x[b*hop ..]) .* conj(FFT(taps)))[i] / nfft, i < hop,

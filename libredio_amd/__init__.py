@@ -105,6 +105,15 @@ def lib():
     _sig(L.redio_ovsave_destroy, i, vp)
     _sig(L.redio_ovsave_nout, sz, vp, sz)
     _sig(L.redio_ovsave_enqueue, i, vp, vp, sz, vp, vp)
+    psz = C.POINTER(sz)
+    _sig(L.redio_data_to_samples, i, vp, sz, vp, vp)
+    _sig(L.redio_norm_c32, i, vp, sz, vp, vp)
+    _sig(L.redio_ingest_u8_mag, i, vp, sz, vp, vp)
+    _sig(L.redio_block_sums, i, vp, sz, sz, vp, vp)
+    _sig(L.redio_discretize, i, vp, sz, vp, vp, vp)
+    _sig(L.redio_trigger_create, i, C.POINTER(vp))
+    _sig(L.redio_trigger_destroy, i, vp)
+    _sig(L.redio_trigger_feed, i, vp, vp, sz, sz, vp, sz, psz, sz, psz, psz, vp)
     _sig(L.redio_pfb_create, i, C.POINTER(vp), pf, i, i, u)
     _sig(L.redio_pfb_destroy, i, vp)
     _sig(L.redio_pfb_nrows, sz, vp, sz)
@@ -164,5 +173,5 @@ def check(code, what="redio"):
         raise RedioError(code, what)
 
 
-from . import dsputils, kissfft, plans, samplerate  # noqa: E402,F401
+from . import bitfount, dsputils, kissfft, plans, samplerate  # noqa: E402,F401
 from .plans import Chain, Channelizer, Fft, Fir, OverlapSave, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401

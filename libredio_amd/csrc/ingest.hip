@@ -1,0 +1,313 @@
+// ingest.hip -- the steps immediately upstream of the hot path in the one graph LibRedio ships
+// (src/ratpak.rs:60-76) -- SURVEY.md 8f rank 1, the "bit-exact slicing/indexing" clause:
+//   rtlsdr::data_to_samples  src/rtlsdr/src/rtlsdr.rs:159-162   u8 IQ pairs -> cf32, i as f32/127.0 - 1.0
+//   |x| map                  src/ratpak.rs:64-68                 Complex::norm = hypotf(re, im)
+//   bitfount::trigger        src/bitfount/src/bitfount.rs:36-85  per-block sum (sequential f32), adaptive
+//                                                                threshold, collect blocks while triggered
+//   bitfount::discretize     src/bitfount/src/bitfount.rs:87-96  max = fold(0.0, f32::max); (x > max/2)
+// Every result is bit-identical to the oracle (oracle_bits.c): IEEE divide/subtract, hypotf evaluated
+// as (float)sqrt((double)re*re + (double)im*im) (= glibc's hypotf on the whole u8 domain and on random
+// data), the block sum accumulated in sample order by one lane per block, max by an order-free
+// wave-shuffle + atomic reduction.  All kernels are HBM-bound elementwise / reduction work.
+#include "../../include/redio.h"
+#include "redio_internal.h"
+#include <new>
+#include <string.h>
+#include <vector>
+
+namespace redio {
+
+__device__ __forceinline__ float i2f(unsigned b) { return (float)b / 127.0f - 1.0f; } // rtlsdr.rs:159
+__device__ __forceinline__ float norm_f32(float re, float im)
+{
+    return (float)sqrt((double)re * (double)re + (double)im * (double)im);
+}
+
+// 4 samples (8 bytes) per thread iteration
+__global__ __launch_bounds__(256) void data_to_samples_kernel(const uint8_t *__restrict__ d, float2 *__restrict__ out, long nsamp)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nsamp; i += stride)
+        out[i] = make_float2(i2f(d[2 * i]), i2f(d[2 * i + 1]));
+}
+
+__global__ __launch_bounds__(256) void norm_kernel(const float2 *__restrict__ x, float *__restrict__ out, long n)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = norm_f32(x[i].x, x[i].y);
+}
+
+// fused: u8 IQ -> magnitude, 8 bytes (4 samples) in and 16 bytes out per lane per step
+__global__ __launch_bounds__(256) void ingest_mag_kernel(const uint8_t *__restrict__ d, float *__restrict__ mag, long nsamp)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = nsamp / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const uint2 w = reinterpret_cast<const uint2 *>(d)[q];
+        float4 m;
+        m.x = norm_f32(i2f(w.x & 255u), i2f((w.x >> 8) & 255u));
+        m.y = norm_f32(i2f((w.x >> 16) & 255u), i2f(w.x >> 24));
+        m.z = norm_f32(i2f(w.y & 255u), i2f((w.y >> 8) & 255u));
+        m.w = norm_f32(i2f((w.y >> 16) & 255u), i2f(w.y >> 24));
+        reinterpret_cast<float4 *>(mag)[q] = m;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (nsamp & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        mag[i] = norm_f32(i2f(d[2 * i]), i2f(d[2 * i + 1]));
+    }
+}
+
+// per-block sums in sample order (bitfount.rs:48): one lane per block; a wave stages 64 blocks'
+// chunks through LDS so that global reads stay coalesced (row padded by one float: lane stride 65)
+__global__ __launch_bounds__(64) void block_sum_kernel(const float *__restrict__ x, float *__restrict__ sums, long nblocks, int block)
+{
+    __shared__ float tile[64 * 65];
+    const int lane = threadIdx.x;
+    const long b0 = (long)blockIdx.x * 64;
+    float s = 0.0f;
+    for (int c0 = 0; c0 < block; c0 += 64) {
+        // rows = blocks b0..b0+63, columns = samples c0..c0+63 of each block
+        for (int r = 0; r < 64; ++r) {
+            const long b = b0 + r;
+            const int c = c0 + lane;
+            tile[r * 65 + lane] = (b < nblocks && c < block) ? x[b * block + c] : 0.0f;
+        }
+        __syncthreads();
+        const int lim = (block - c0 < 64) ? block - c0 : 64;
+        for (int c = 0; c < lim; ++c) s = add_rn(s, tile[lane * 65 + c]);
+        __syncthreads();
+    }
+    if (b0 + lane < nblocks) sums[b0 + lane] = s;
+}
+
+// discretize pass 1: max = fold(0.0, f32::max): NaN operands are ignored, negatives never win, so the
+// result is a non-negative float whose bit pattern orders like an unsigned integer
+__global__ __launch_bounds__(256) void max_kernel(const float *__restrict__ x, long n, unsigned *max_bits)
+{
+    float m = 0.0f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = x[i];
+        if (v > m) m = v; // false for NaN
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        if (o > m) m = o;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void slice_kernel(const float *__restrict__ x, long n, const unsigned *max_bits, uint8_t *__restrict__ out)
+{
+    const float thr = __uint_as_float(*max_bits) / 2.0f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = x[i] > thr ? 1 : 0;
+}
+
+// gather whole blocks (trigger's push_all of triggered blocks): seg = (src_block, dst_offset)
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const float *__restrict__ x, const long *__restrict__ src_block,
+                                                            const long *__restrict__ dst_off, int block, float *__restrict__ out)
+{
+    const long b = blockIdx.x;
+    const float *s = x + src_block[b] * block;
+    float *d = out + dst_off[b];
+    for (int i = threadIdx.x; i < block; i += blockDim.x) d[i] = s[i];
+}
+
+static unsigned grid_for(long n, int per = 256)
+{
+    long g = (n + per - 1) / per;
+    return (unsigned)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+} // namespace redio
+using namespace redio;
+
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : REDIO_ERR_HIP_BASE - (int)e; }
+#define IN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_rc(_e); } while (0)
+
+extern "C" int redio_data_to_samples(const void *d_bytes, size_t nbytes, void *d_out, void *stream)
+{
+    if (nbytes & 1) return REDIO_ERR_ASSERT; // chunks(2) then i[1]: index panic (rtlsdr.rs:161)
+    if (nbytes == 0) return REDIO_OK;
+    if (!d_bytes || !d_out) return REDIO_ERR_ARG;
+    const long ns = (long)(nbytes / 2);
+    hipLaunchKernelGGL(data_to_samples_kernel, dim3(grid_for(ns)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float2 *)d_out, ns);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int redio_norm_c32(const void *d_in, size_t n, void *d_out, void *stream)
+{
+    if (n == 0) return REDIO_OK;
+    if (!d_in || !d_out) return REDIO_ERR_ARG;
+    hipLaunchKernelGGL(norm_kernel, dim3(grid_for((long)n)), dim3(256), 0, (hipStream_t)stream, (const float2 *)d_in, (float *)d_out, (long)n);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int redio_ingest_u8_mag(const void *d_bytes, size_t nbytes, void *d_mag, void *stream)
+{
+    if (nbytes & 1) return REDIO_ERR_ASSERT;
+    if (nbytes == 0) return REDIO_OK;
+    if (!d_bytes || !d_mag) return REDIO_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_bytes) & 7) || (reinterpret_cast<uintptr_t>(d_mag) & 15)) return REDIO_ERR_ARG;
+    const long ns = (long)(nbytes / 2);
+    hipLaunchKernelGGL(ingest_mag_kernel, dim3(grid_for(ns / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float *)d_mag, ns);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int redio_block_sums(const void *d_in, size_t nblocks, size_t block, void *d_sums, void *stream)
+{
+    if (nblocks == 0) return REDIO_OK;
+    if (!d_in || !d_sums || block == 0 || block > (1u << 30)) return REDIO_ERR_ARG;
+    hipLaunchKernelGGL(block_sum_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float *)d_in,
+                       (float *)d_sums, (long)nblocks, (int)block);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int redio_discretize(const void *d_in, size_t n, void *d_out_u8, void *d_scratch_u32, void *stream)
+{
+    if (n == 0) return REDIO_OK;
+    if (!d_in || !d_out_u8 || !d_scratch_u32) return REDIO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    IN_TRY(hipMemsetAsync(d_scratch_u32, 0, sizeof(unsigned), st)); // fold starts at 0.0
+    hipLaunchKernelGGL(max_kernel, dim3(grid_for((long)n, 1024)), dim3(256), 0, st, (const float *)d_in, (long)n, (unsigned *)d_scratch_u32);
+    hipLaunchKernelGGL(slice_kernel, dim3(grid_for((long)n)), dim3(256), 0, st, (const float *)d_in, (long)n, (const unsigned *)d_scratch_u32,
+                       (uint8_t *)d_out_u8);
+    return hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- trigger (bitfount.rs:36-85)
+struct redio_trigger {
+    int device;
+    long trigger;       // :42
+    float threshold;    // :44
+    // sample_buffer (:43) lives on the device; it starts as [0.0]
+    float *d_buf;
+    size_t len, cap;
+    float *d_sums; size_t sums_cap;
+    long *d_src, *d_dst; size_t seg_cap;
+};
+
+extern "C" int redio_trigger_create(redio_trigger **h)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return REDIO_ERR_NO_DEVICE;
+    redio_trigger *t = new (std::nothrow) redio_trigger();
+    if (!t) return REDIO_ERR_NOMEM;
+    memset(t, 0, sizeof(*t));
+    t->device = dev;
+    t->cap = 1 + 64 * 512;
+    hipError_t e = hipMalloc((void **)&t->d_buf, t->cap * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(t->d_buf, 0, sizeof(float)); // vec!(0.0)
+    if (e != hipSuccess) { delete t; return hip_rc(e); }
+    t->len = 1;
+    *h = t;
+    return REDIO_OK;
+}
+
+extern "C" int redio_trigger_destroy(redio_trigger *t)
+{
+    if (!t) return REDIO_OK;
+    hipFree(t->d_buf); hipFree(t->d_sums); hipFree(t->d_src); hipFree(t->d_dst);
+    delete t;
+    return REDIO_OK;
+}
+
+static int trig_reserve(redio_trigger *t, size_t need, hipStream_t st)
+{
+    if (need <= t->cap) return REDIO_OK;
+    size_t nc = t->cap;
+    while (nc < need) nc *= 2;
+    float *nb = nullptr;
+    IN_TRY(hipMalloc((void **)&nb, nc * sizeof(float)));
+    IN_TRY(hipMemcpyAsync(nb, t->d_buf, t->len * sizeof(float), hipMemcpyDeviceToDevice, st));
+    IN_TRY(hipStreamSynchronize(st));
+    hipFree(t->d_buf);
+    t->d_buf = nb;
+    t->cap = nc;
+    return REDIO_OK;
+}
+
+// Feeds nblocks blocks of `block` magnitudes (device).  Emitted buffers are appended to d_out (device,
+// capacity out_cap floats) and their lengths to lens (host).  Synchronous: the adaptive threshold is a
+// scalar recurrence over the block sums and runs on the host between two launches.
+extern "C" int redio_trigger_feed(redio_trigger *t, const void *d_blocks, size_t nblocks, size_t block, void *d_out, size_t out_cap,
+                                  size_t *lens, size_t lens_cap, size_t *nemit_out, size_t *total_out, void *stream)
+{
+    if (nemit_out) *nemit_out = 0;
+    if (total_out) *total_out = 0;
+    if (!t) return REDIO_ERR_ARG;
+    if (nblocks == 0) return REDIO_OK;
+    if (!d_blocks || block == 0) return REDIO_ERR_ARG;
+    IN_TRY(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (nblocks > t->sums_cap) {
+        hipFree(t->d_sums); t->d_sums = nullptr; t->sums_cap = 0;
+        IN_TRY(hipMalloc((void **)&t->d_sums, nblocks * sizeof(float)));
+        t->sums_cap = nblocks;
+    }
+    int rc = redio_block_sums(d_blocks, nblocks, block, t->d_sums, st);
+    if (rc) return rc;
+    std::vector<float> s(nblocks);
+    IN_TRY(hipMemcpyAsync(s.data(), t->d_sums, nblocks * sizeof(float), hipMemcpyDeviceToHost, st));
+    IN_TRY(hipStreamSynchronize(st));
+
+    const long trigger_duration = 50;  // :41
+    const size_t block_size = 512;     // :38 (only in the OOM bound)
+    size_t nemit = 0, total = 0;
+    std::vector<long> src, dst; // pending pushes into the device sample_buffer since the last flush
+    auto flush = [&]() -> int {
+        if (src.empty()) return REDIO_OK;
+        if (src.size() > t->seg_cap) {
+            hipFree(t->d_src); hipFree(t->d_dst); t->d_src = t->d_dst = nullptr; t->seg_cap = 0;
+            IN_TRY(hipMalloc((void **)&t->d_src, src.size() * 2 * sizeof(long)));
+            IN_TRY(hipMalloc((void **)&t->d_dst, src.size() * 2 * sizeof(long)));
+            t->seg_cap = src.size() * 2;
+        }
+        IN_TRY(hipMemcpyAsync(t->d_src, src.data(), src.size() * sizeof(long), hipMemcpyHostToDevice, st));
+        IN_TRY(hipMemcpyAsync(t->d_dst, dst.data(), dst.size() * sizeof(long), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_blocks_kernel, dim3((unsigned)src.size()), dim3(256), 0, st, (const float *)d_blocks, t->d_src, t->d_dst,
+                           (int)block, t->d_buf);
+        IN_TRY(hipStreamSynchronize(st)); // src/dst are reused
+        src.clear(); dst.clear();
+        return REDIO_OK;
+    };
+    for (size_t b = 0; b < nblocks; ++b) {
+        t->trigger -= 1;                                              // :46
+        if (t->len > 1000 * (size_t)trigger_duration * block_size) {  // :52-54
+            rc = flush(); if (rc) return rc;
+            IN_TRY(hipMemsetAsync(t->d_buf, 0, sizeof(float), st));
+            t->len = 1;
+        }
+        if (t->threshold == 0.0f) t->threshold = s[b];                // :57-59
+        if (t->trigger < 0) {                                         // :62-65
+            t->threshold += s[b] / 1000.0f;
+            t->threshold -= t->threshold * 0.002f;
+        }
+        if (s[b] > t->threshold * 4.0f) t->trigger = trigger_duration; // :68-70
+        if (t->trigger > 1) {                                          // :73-75
+            if (t->len + block > t->cap) { rc = flush(); if (rc) return rc; rc = trig_reserve(t, t->len + block, st); if (rc) return rc; }
+            src.push_back((long)b); dst.push_back((long)t->len);
+            t->len += block;
+        }
+        if (t->trigger == 0) {                                         // :78-81
+            rc = flush(); if (rc) return rc;
+            if (nemit < lens_cap && total + t->len <= out_cap && d_out) {
+                IN_TRY(hipMemcpyAsync((float *)d_out + total, t->d_buf, t->len * sizeof(float), hipMemcpyDeviceToDevice, st));
+                lens[nemit] = t->len;
+            }
+            total += t->len;
+            ++nemit;
+            t->len = 0;
+        }
+    }
+    rc = flush();
+    if (rc) return rc;
+    IN_TRY(hipStreamSynchronize(st));
+    if (nemit_out) *nemit_out = nemit;
+    if (total_out) *total_out = total;
+    return REDIO_OK;
+}

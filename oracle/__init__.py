@@ -84,6 +84,7 @@ def lib():
     L.orc_trigger_feed.argtypes = [C.c_void_p, _f32p, sz, sz, _f32p, sz, _szp, sz, C.POINTER(sz)]
     L.orc_trigger_feed.restype = sz
     L.orc_block_sum.argtypes = [_f32p, sz]; L.orc_block_sum.restype = C.c_float
+    L.orc_norm_c32.argtypes = [_c64p, sz, _f32p]; L.orc_norm_c32.restype = None
     _lib = L
     return L
 
@@ -274,6 +275,11 @@ def data_to_samples(d):
     if lib().orc_data_to_samples(d, len(d), out):
         raise IndexError("data_to_samples: odd byte count (index panic in the reference)")
     return out
+
+
+def norm(x):
+    """|x| = Complex::norm() = hypotf(re, im) (the map of src/ratpak.rs:64-68)."""
+    x = _c64(x); out = np.empty(len(x), np.float32); lib().orc_norm_c32(x, len(x), out); return out
 
 
 def block_sum(x):

@@ -131,3 +131,10 @@ size_t orc_trigger_feed(orc_trigger_state *t, const float *blocks, size_t nblock
     if (out_total) *out_total = total;
     return nemit;
 }
+
+/* |x| of the shipped graph's first map, src/ratpak.rs:64-68: cross_applicator_vecs(.., |x|{x.norm()})
+ * with num 0.1.22 Complex::norm = re.hypot(im) (libm hypotf). */
+void orc_norm_c32(const orc_cpx *x, size_t n, float *out)
+{
+    for (size_t i = 0; i < n; ++i) out[i] = hypotf(x[i].r, x[i].i);
+}

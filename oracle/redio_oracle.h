@@ -106,6 +106,7 @@ void   orc_trigger_free(orc_trigger_state *t);
 size_t orc_trigger_feed(orc_trigger_state *t, const float *blocks, size_t nblocks, size_t block,
                         float *out, size_t out_cap, size_t *out_lens, size_t lens_cap, size_t *out_total);
 float  orc_block_sum(const float *x, size_t n); /* sequential f32 sum, bitfount.rs:48 */
+void   orc_norm_c32(const orc_cpx *x, size_t n, float *out); /* Complex::norm = hypotf, src/ratpak.rs:64-68 */
 
 #ifdef __cplusplus
 }

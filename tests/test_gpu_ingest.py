@@ -1,0 +1,86 @@
+"""The bit-exact ingest / slicing path on the MI355X against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_data_to_samples_all_256_byte_values(gpu, redio, oracle):
+    d = np.repeat(np.arange(256, dtype=np.uint8), 2)
+    d = np.concatenate([d, np.arange(256, dtype=np.uint8)[::-1], np.arange(256, dtype=np.uint8)])  # mixed pairs too
+    got = redio.bitfount.data_to_samples(gpu.from_numpy(d).cuda()).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.data_to_samples(d)))
+    with pytest.raises(redio.RedioError) as e:
+        redio.bitfount.data_to_samples(gpu.zeros(7, dtype=gpu.uint8, device="cuda"))   # i[1] index panic
+    assert e.value.code == -5
+
+
+def test_norm_is_hypotf_on_the_whole_u8_domain(gpu, redio, oracle):
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    d = np.stack([a.reshape(-1), b.reshape(-1)], axis=1).reshape(-1)                 # all 65536 IQ byte pairs
+    x = oracle.data_to_samples(d)
+    want = oracle.norm(x)
+    assert np.array_equal(bits(redio.bitfount.norm(gpu.from_numpy(x).cuda()).cpu().numpy()), bits(want))
+    assert np.array_equal(bits(redio.bitfount.ingest_mag(gpu.from_numpy(d).cuda()).cpu().numpy()), bits(want))
+    y = oracle.synth_iq(5, 0, 100003) * np.float32(1000.0)                              # and on random data
+    assert np.array_equal(bits(redio.bitfount.norm(gpu.from_numpy(y).cuda()).cpu().numpy()), bits(oracle.norm(y)))
+
+
+@pytest.mark.parametrize("block", [512, 64, 100, 1])
+def test_block_sums_are_sequential_f32(gpu, redio, oracle, block):
+    nb = 333
+    x = (oracle.synth_f32(8, 0, nb * block) * np.float32(100.0)).astype(np.float32)
+    got = redio.bitfount.block_sums(gpu.from_numpy(x).cuda(), block).cpu().numpy()
+    want = np.array([oracle.block_sum(x[b * block:(b + 1) * block]) for b in range(nb)], np.float32)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_discretize_bit_exact(gpu, redio, oracle):
+    for n in (1, 513, 100000):
+        x = np.abs(oracle.synth_f32(n, 0, n)) ** 2
+        x[n // 2] = 3.0
+        got = redio.bitfount.discretize(gpu.from_numpy(x).cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.discretize(x).astype(np.uint8))
+    # NaN is ignored by f32::max; all-negative input keeps max = 0.0 (the fold's seed)
+    x = np.array([np.nan, -1.0, 0.5, 2.0, np.nan, 1.1], np.float32)
+    assert redio.bitfount.discretize(gpu.from_numpy(x).cuda()).cpu().numpy().tolist() == oracle.discretize(x).tolist() == [0, 0, 0, 1, 0, 1]
+    x = np.array([-3.0, -1.0], np.float32)
+    assert redio.bitfount.discretize(gpu.from_numpy(x).cuda()).cpu().numpy().tolist() == oracle.discretize(x).tolist()
+
+
+def test_trigger_state_machine_matches_the_reference_walk(gpu, redio, oracle):
+    # quiet noise with three bursts; blocks of 512 like rtl_source_cmplx (bitfount.rs:17)
+    rng = np.random.default_rng(7)
+    nb = 600
+    blocks = (0.05 * rng.random((nb, 512))).astype(np.float32)
+    for start, ln in ((100, 7), (250, 60), (480, 3)):
+        blocks[start:start + ln] += 1.0
+    dev, ref = redio.bitfount.Trigger(), oracle.Trigger()
+    got, want = [], []
+    for lo, hi in ((0, 130), (130, 131), (131, 600)):          # state persists across calls
+        got += [g.cpu().numpy() for g in dev.feed(gpu.from_numpy(blocks[lo:hi]).cuda())]
+        want += ref.feed(blocks[lo:hi])
+    assert len(got) == len(want) >= 3
+    for g, w in zip(got, want):
+        assert len(g) == len(w) and np.array_equal(bits(g), bits(w))
+    assert want[0][0] == 0.0 and len(want[0]) % 512 == 1       # the first buffer starts as vec!(0.0) (bitfount.rs:43)
+
+
+def test_shipped_graph_front_end_end_to_end(gpu, redio, oracle):
+    """rtl bytes -> data_to_samples -> |x| -> trigger -> discretize, as src/ratpak.rs:60-76 wires them."""
+    rng = np.random.default_rng(11)
+    nb = 400
+    raw = rng.integers(120, 136, size=(nb, 1024), dtype=np.uint8)       # 512 IQ samples per block near mid-scale
+    raw[150:190] = rng.integers(0, 256, size=(40, 1024), dtype=np.uint8)  # an OOK burst
+    mag_ref = oracle.norm(oracle.data_to_samples(raw.reshape(-1))).reshape(nb, 512)
+    bufs_ref = oracle.Trigger().feed(mag_ref)
+    mag = redio.bitfount.ingest_mag(gpu.from_numpy(raw.reshape(-1)).cuda()).reshape(nb, 512)
+    bufs = redio.bitfount.Trigger().feed(mag)
+    assert len(bufs) == len(bufs_ref) >= 1
+    for b, r in zip(bufs, bufs_ref):
+        assert np.array_equal(bits(b.cpu().numpy()), bits(r))
+        assert np.array_equal(redio.bitfount.discretize(b).cpu().numpy(), oracle.discretize(r).astype(np.uint8))
