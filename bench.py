@@ -155,7 +155,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single f32 IQ stream, 1024-pt FFT + 127-tap FIR decimate-by-5",
                        "samples_per_gpu": n, "ntaps": NTAPS, "decim": DECIM, "nfft": NFFT,
-                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else {0: "chain_v3_kernel (fused, wave per block)", 1: "chain_fir_fft1k_kernel (fused, v1)", 2: "chain_v2_kernel (fused, v2)"}.get(a.variant, f"chain_v3_kernel tuning {a.variant}"),
+                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else {0: "chain_v4_kernel (fused, wave per block run, halo carried in LDS)", 1: "chain_fir_fft1k_kernel (fused, v1)", 2: "chain_v2_kernel (fused, v2)", 6: "chain_v3_kernel (fused, v3)", 7: "chain_v5_kernel (fused, dynamic queue)"}.get(a.variant, f"fused kernel tuning {a.variant}"),
                        "fir_rounding": "mul+add (reference)" if a.exact else "fmaf, reference order",
                        "parallelism": f"time-sliced replicas x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

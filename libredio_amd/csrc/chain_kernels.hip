@@ -257,9 +257,15 @@ __global__ __launch_bounds__(64, WPS) void chain_v3_kernel(const float2 *__restr
         int ln = lane;
         asm volatile("" : "+v"(ln));
         if (ABLATE & 2) {
-            float2 *d0p = out + blk * 1024 + ln;
+            if (ABLATE & 8) { // 16-byte stores (timing probe for the store width)
+                v4f *d4 = reinterpret_cast<v4f *>(out + blk * 1024) + ln;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d0p[64 * i] = a[i];
+                for (int i = 0; i < 8; ++i) d4[64 * i] = v4f{a[2 * i].x, a[2 * i].y, a[2 * i + 1].x, a[2 * i + 1].y};
+            } else {
+                float2 *d0p = out + blk * 1024 + ln;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d0p[64 * i] = a[i];
+            }
             if (more) park();
             wave_lds_fence();
             continue;
@@ -296,6 +302,13 @@ __global__ __launch_bounds__(64, WPS) void chain_v3_kernel(const float2 *__restr
         wave_lds_fence();
     }
 }
+
+hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, int wps,
+                           hipStream_t s, unsigned long long *dbg); // chain_v4.hip
+hipError_t launch_chain_v5(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, int tuning,
+                           unsigned *queue, hipStream_t s); // chain_v5.hip
+static unsigned long long *g_chain_dbg = nullptr; // diagnostic stamps (tools/clock_probe.py), never set in production
+void chain_set_debug_buffer(unsigned long long *p) { g_chain_dbg = p; }
 
 bool chain_supported(int K, long D, int nfft) { return nfft == 1024 && K == 127 && D == 5; }
 
@@ -368,13 +381,17 @@ static hipError_t launch_chain_t(const FftPlanDev &p, const float2 *x, long n_in
 }
 
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
-                        float2 *out, long nblocks, bool fused, int variant, hipStream_t s)
+                        float2 *out, long nblocks, bool fused, int variant, hipStream_t s, unsigned *queue)
 {
     if (nblocks <= 0) return hipSuccess;
     if (p.nfft == 1024 && !p.inverse && K == 127 && D == 5) {
         // v2/v3 need 16-byte aligned input (every sub-tile starts on an even sample)
         const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-        if (variant == 0 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
+        // default: v4 (static contiguous block ranges).  v5 (dynamic chunk queue) measures the same, 7-10 select it.
+        if (variant == 0 && aligned) return launch_chain_v4(x, taps, p.tw, out, nblocks, fused, 2, s, g_chain_dbg);
+        if (variant >= 7 && variant <= 10 && aligned && queue) return launch_chain_v5(x, taps, p.tw, out, nblocks, fused, variant - 7, queue, s);
+        if (variant == 5 && aligned) return launch_chain_v4(x, taps, p.tw, out, nblocks, fused, 3, s, g_chain_dbg);
+        if (variant == 6 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
         if (variant == 3 && aligned) return launch_chain_v3<127, 5, 3, 6>(p, x, taps, out, nblocks, fused, s);
         if (variant == 4 && aligned) return launch_chain_v3<127, 5, 3, 8>(p, x, taps, out, nblocks, fused, s);
         if (variant >= 10 && aligned && fused) { // timing-only ablations of v3 (results are wrong)
@@ -385,6 +402,8 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
             case 4: return launch_chain_v3<127, 5, 3, 6, 4>(p, x, taps, out, nblocks, true, s);
             case 6: return launch_chain_v3<127, 5, 3, 6, 6>(p, x, taps, out, nblocks, true, s);
             case 7: return launch_chain_v3<127, 5, 3, 6, 7>(p, x, taps, out, nblocks, true, s);
+            case 11: return launch_chain_v3<127, 5, 2, 8, 11>(p, x, taps, out, nblocks, true, s);
+            case 13: return launch_chain_v3<127, 5, 2, 8, 3>(p, x, taps, out, nblocks, true, s);
             default: break;
             }
         }

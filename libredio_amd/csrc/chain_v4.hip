@@ -1,0 +1,159 @@
+// chain_v4.hip -- the north-star chain kernel, generation 4: chain_v3's wave-per-block structure
+// (chain_kernels.hip) with two changes to the data movement:
+//   * a wave owns a CONTIGUOUS range of blocks, so consecutive sub-tiles are consecutive in the stream;
+//   * the 122-sample FIR halo that two consecutive sub-tiles share is carried over inside the CU
+//     (one 16-byte LDS read + write per lane) instead of being fetched again: per sub-tile exactly
+//     640 x 16 B = 10 loads per lane of NEW samples.  v3 re-read 8.7 % of its input through L2.
+// Arithmetic, layouts and results are identical to v3 (bit-exact with the oracle).
+#include "fir_core.h"
+#include "fft_wave.h"
+#include "redio_internal.h"
+#include <type_traits>
+
+namespace redio {
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for4(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for4<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int K, int D, bool FUSED, int WPS, int CH>
+__global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
+                                                           const float2 *__restrict__ tw, float2 *__restrict__ out,
+                                                           long nblocks, long blocks_per_wave, unsigned long long *dbg)
+{
+    // diagnostic only (dbg != nullptr): shader-clock and 100 MHz real-time stamps around the wave's life,
+    // written to a buffer of their own; run times of such launches are never quoted
+    unsigned long long t0c = 0, t0r = 0;
+    if (dbg) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    constexpr int R = 4;
+    using G = FirGeomV<K, D, R>;
+    constexpr int SUB_OUT = 64 * R;                   // 256 outputs per sub-tile
+    constexpr int SUB_NEW = SUB_OUT * D;              // 1280 new input samples per sub-tile
+    constexpr int HALO = G::tile_in(SUB_OUT) - SUB_NEW; // 122 samples shared with the previous sub-tile
+    static_assert(HALO % 2 == 0 && SUB_NEW % 128 == 0 && 4 * SUB_OUT == 1024, "geometry");
+    constexpr int HALO_V = HALO / 2;                  // 61 float4
+    constexpr int NLD = SUB_NEW / 2 / 64;             // 10 float4 per lane
+    static_assert(HALO_V <= 64, "the halo moves with one instruction per lane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4f_t *xs4 = reinterpret_cast<v4f_t *>(smem);
+    float2 *ex = reinterpret_cast<float2 *>(smem);
+
+    const int lane = threadIdx.x;
+    const long b0 = (long)blockIdx.x * blocks_per_wave;
+    if (b0 >= nblocks) return;
+    const long b1 = (b0 + blocks_per_wave < nblocks) ? b0 + blocks_per_wave : nblocks;
+    const long nsub = 4 * (b1 - b0);                  // sub-tiles of this wave, consecutive in the stream
+    // float4 index of the first NEW sample of sub-tile j (the halo precedes it)
+    const v4f_t *src0 = reinterpret_cast<const v4f_t *>(x + b0 * 1024 * (long)D) + lane;
+
+    v4f_t pre[NLD];
+    auto fetch = [&](long j) { // new samples of sub-tile j: [HALO + j*SUB_NEW, HALO + (j+1)*SUB_NEW)
+        const v4f_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
+        static_for4<NLD>([&](auto I) { pre[I.value] = src[64 * I.value]; });
+    };
+    auto park = [&]() {
+        static_for4<NLD>([&](auto I) { xs4[G::lds_index(HALO + 2 * (lane + 64 * I.value)) / 2] = pre[I.value]; });
+    };
+
+    // prologue: the head (the only halo this wave ever fetches) and the first sub-tile
+    if (lane < HALO_V) xs4[G::lds_index(2 * lane) / 2] = src0[0];
+    fetch(0);
+    park();
+    wave_lds_fence();
+
+    float2 a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (long j = 0; j < nsub; ++j) {
+        const bool more = j + 1 < nsub;
+        if (more) fetch(j + 1);
+        float2 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+        int lf = lane; // opaque per sub-tile: keeps LDS address arithmetic out of the loop's live set
+        asm volatile("" : "+v"(lf));
+        fir_lane_v<K, D, R, FUSED, CH>(xs4, lf, taps, acc);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a[i] = a[i + 4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[12 + r] = acc[r];
+        wave_lds_fence(); // window reads done
+        // the last HALO samples of this image are the first HALO samples of the next one
+        v4f_t halo = v4f_t{0.f, 0.f, 0.f, 0.f};
+        if (more && lf < HALO_V) halo = xs4[G::lds_index(SUB_NEW + 2 * lf) / 2];
+        if ((j & 3) == 3) { // a block is complete in registers: transform it, the image is scratch meanwhile
+            wave_lds_fence();
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            fft1kn_wave<false>(a, ex, tw, out + (b0 + (j >> 2)) * 1024, ln);
+            wave_lds_fence();
+        }
+        if (more) {
+            if (lf < HALO_V) xs4[G::lds_index(2 * lf) / 2] = halo;
+            park();
+        }
+        wave_lds_fence();
+    }
+    if (dbg && lane == 0) {
+        dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        dbg[4 * blockIdx.x + 2] = t0r; // absolute start (100 MHz ticks)
+        unsigned xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid;
+    }
+}
+
+static int num_cus_v4()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int K, int D, int WPS, int CH>
+static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
+                              hipStream_t s, unsigned long long *dbg)
+{
+    using G = FirGeomV<K, D, 4>;
+    constexpr int ELEMS = G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS;
+    constexpr size_t LDS_NEED = (size_t)ELEMS * sizeof(float2);
+    static_assert(4 * WPS * LDS_NEED <= 160 * 1024, "4*WPS waves per CU");
+    // The grid is exactly one wave per residency slot.  Ask for 1/(4*WPS) of the CU's LDS (minus a
+    // margin for allocation granularity) so that a CU can NOT take more than 4*WPS waves: without this
+    // the dispatcher packs up to 12-13 of these small workgroups on some CUs and leaves others
+    // half empty, and the launch ends when the most crowded CU does (measured: wave lifetimes 320-570 us).
+    constexpr size_t LDS = (160 * 1024 / (4 * WPS)) - 480 > LDS_NEED ? (160 * 1024 / (4 * WPS)) - 480 : LDS_NEED;
+    static_assert((4 * WPS + 1) * LDS > 160 * 1024, "one more wave must not fit");
+    long waves = 4L * WPS * num_cus_v4();
+    if (waves > nblocks) waves = nblocks;
+    const long bpw = (nblocks + waves - 1) / waves;
+    const long grid = (nblocks + bpw - 1) / bpw;
+    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, int wps,
+                           hipStream_t s, unsigned long long *dbg)
+{
+    if (wps == 3) return launch_v4_t<127, 5, 3, 6>(x, taps, tw, out, nblocks, fused, s, dbg);
+    return launch_v4_t<127, 5, 2, 8>(x, taps, tw, out, nblocks, fused, s, dbg);
+}
+
+} // namespace redio

@@ -284,6 +284,7 @@ struct redio_chain {
     int fused_ok;
     int force_unfused;
     int variant; // fused kernel generation: 0 = v3 (wave per block), 1 = v1, 2 = v2 (kept for A/B runs)
+    unsigned *d_queue; // work-queue head of the fused kernel (zeroed on the stream before every launch)
     float2 *d_mid; // intermediate for the two-kernel path
     size_t mid_elems;
 };
@@ -300,6 +301,7 @@ extern "C" int redio_chain_create(redio_chain **h, const float *taps, size_t nta
     if (rc) { redio_fir_destroy(c->fir); redio_fft_destroy(c->fft); delete c; return rc; }
     c->nfft = nfft;
     c->fused_ok = chain_supported((int)ntaps, (long)decim, nfft) ? 1 : 0;
+    if (hipMalloc((void **)&c->d_queue, 256) != hipSuccess) c->d_queue = nullptr; // the fused kernel falls back to static ranges
     *h = c;
     return REDIO_OK;
 }
@@ -309,6 +311,7 @@ extern "C" int redio_chain_destroy(redio_chain *h)
     redio_fir_destroy(h->fir);
     redio_fft_destroy(h->fft);
     if (h->d_mid) hipFree(h->d_mid);
+    if (h->d_queue) hipFree(h->d_queue);
     delete h;
     return REDIO_OK;
 }
@@ -324,9 +327,12 @@ extern "C" int redio_chain_set_unfused(redio_chain *h, int unfused)
     h->force_unfused = unfused ? 1 : 0;
     return REDIO_OK;
 }
+namespace redio { void chain_set_debug_buffer(unsigned long long *p); }
+// diagnostic: per-wave {shader cycles, 100 MHz ticks} of the v4 chain kernel into a caller buffer (2 x u64 per wave)
+extern "C" int redio_debug_chain_stamps(void *d_buf) { chain_set_debug_buffer((unsigned long long *)d_buf); return REDIO_OK; }
 extern "C" int redio_chain_set_variant(redio_chain *h, int variant)
 {
-    if (!h || variant < 0 || variant > 17) return REDIO_ERR_ARG;
+    if (!h || variant < 0 || variant > 30) return REDIO_ERR_ARG;
     h->variant = variant;
     return REDIO_OK;
 }
@@ -340,7 +346,7 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     const bool fused_math = (h->fir->flags & REDIO_FIR_FUSED) != 0;
     if (redio_chain_is_fused(h)) {
         return hip_rc(launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
-                                   (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, h->variant, (hipStream_t)stream));
+                                   (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, h->variant, (hipStream_t)stream, h->d_queue));
     }
     // two kernels through a plan-owned intermediate (allocated on first use / growth)
     size_t ny = nblk * (size_t)h->nfft;

@@ -28,7 +28,7 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
-                        float2 *out, long nblocks, bool fused, int variant, hipStream_t s);
+                        float2 *out, long nblocks, bool fused, int variant, hipStream_t s, unsigned *queue = nullptr);
 
 // misc_kernels.hip
 hipError_t launch_synth_iq(float2 *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
