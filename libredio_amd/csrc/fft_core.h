@@ -339,3 +339,48 @@ RD_HD float2 fft_generic_output(SrcPtr src, TwPtr tw, FftStage s, int nfft, int 
 }
 
 } // namespace redio
+
+// ============================================================================================
+// 65536-point transform (4^8) in two passes over global memory, four radix-4 stages each, same
+// butterflies and twiddle table as the one-stage-per-launch path (bit-identical results).
+// Position P = 256 G + p after the decimation-in-time leaf copy holds input n = rev4(G) + 256 rev4(p)
+// (rev4 = reversal of four base-4 digits).
+//   pass 0: stages m = 1, 4, 16, 64 act inside each group G of 256 consecutive positions;
+//   pass 1: stages m = 256 ... 16384 act, for each k0 = P mod 256, on the 256 positions k0 + 256 G.
+// A workgroup takes a tile of 256 rows x F64K_COLS columns whose rows are F64K_COLS contiguous
+// samples in memory (pass 0: columns = consecutive rev4(G); pass 1: columns = consecutive k0), keeps
+// it in LDS with a row stride of F64K_LD float2 and runs the four stages along the row index.
+// ============================================================================================
+namespace redio {
+
+constexpr int F64K_N = 65536;
+constexpr int F64K_COLS = 16;
+constexpr int F64K_LD = F64K_COLS + 1;
+
+RD_HD int rev4_of_8bit(int v) { return ((v & 3) << 6) | (((v >> 2) & 3) << 4) | (((v >> 4) & 3) << 2) | ((v >> 6) & 3); }
+
+// global float2 index of tile element (row, col) of tile `c` (0..15) of a transform
+//   pass 0 load : source n = (16 c + col) + 256 * row                 -> LDS row rev4(row)
+//   pass 0 store: position P = 256 * rev4(16 c + col) + row
+//   pass 1 load/store: position P = (16 c + col) + 256 * row
+RD_HD int f64k_p0_src(int c, int row, int col) { return F64K_COLS * c + col + 256 * row; }
+RD_HD int f64k_p0_dst(int c, int row, int col) { return 256 * rev4_of_8bit(F64K_COLS * c + col) + row; }
+RD_HD int f64k_p1_pos(int c, int row, int col) { return F64K_COLS * c + col + 256 * row; }
+
+// butterfly b (0..63) of in-tile stage t (sub-length 4^t along the row index) for column `col`
+template <bool INV, typename Ptr, typename TwPtr>
+RD_HD void f64k_tile_butterfly(Ptr L, TwPtr tw, int pass, int t, int col, int b, int k0)
+{
+    const int m = 1 << (2 * t);
+    const int grp = b >> (2 * t), kk = b & (m - 1);
+    const int base = grp * 4 * m + kk;
+    const int k = pass == 0 ? kk : k0 + 256 * kk;
+    const int fs = pass == 0 ? (16384 >> (2 * t)) : (64 >> (2 * t));
+    float2 a0 = L[(base)*F64K_LD + col], a1 = L[(base + m) * F64K_LD + col];
+    float2 a2 = L[(base + 2 * m) * F64K_LD + col], a3 = L[(base + 3 * m) * F64K_LD + col];
+    bfly4<INV>(a0, a1, a2, a3, tw[k * fs], tw[2 * k * fs], tw[3 * k * fs]);
+    L[(base)*F64K_LD + col] = a0; L[(base + m) * F64K_LD + col] = a1;
+    L[(base + 2 * m) * F64K_LD + col] = a2; L[(base + 3 * m) * F64K_LD + col] = a3;
+}
+
+} // namespace redio

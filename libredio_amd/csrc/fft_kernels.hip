@@ -80,6 +80,57 @@ __global__ __launch_bounds__(256) void fft_global_stage_kernel(FftPlanDev p, int
     fft_stage_butterfly<INV>(data + b * p.nfft, p.tw, st, bf);
 }
 
+// ---- N = 65536: two passes of four in-LDS radix-4 stages (fft_core.h, "65536-point transform") ----
+// One workgroup per 256 x 16 tile; rows are 128 contiguous bytes in memory.  PASS 0 gathers the
+// digit-reversed input (in -> out), PASS 1 works in place on out.  32 B of HBM traffic per sample
+// (twice the one-pass minimum; a 512 KiB transform does not fit LDS).
+template <bool INV, int PASS>
+__global__ __launch_bounds__(256) void fft64k_pass_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw,
+                                                          long in_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const long xf = blockIdx.x >> 4; // transform
+    const int c = blockIdx.x & 15;   // tile
+    const float2 *src = PASS == 0 ? in + xf * in_stride : out + xf * F64K_N;
+    float2 *dst = out + xf * F64K_N;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, row = e >> 4, col = e & 15;
+        if (PASS == 0) L[rev4_of_8bit(row) * F64K_LD + col] = src[f64k_p0_src(c, row, col)];
+        else L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
+    }
+    __syncthreads();
+    const int col = tid & 15;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<INV>(L, tw, PASS, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+        __syncthreads();
+    }
+    if (PASS == 0) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) dst[f64k_p0_dst(c, tid, it)] = L[tid * F64K_LD + it]; // 2 KiB runs per column
+    } else {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
+            dst[f64k_p1_pos(c, row, cc)] = L[row * F64K_LD + cc];
+        }
+    }
+}
+
+template <bool INV>
+static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
+{
+    const size_t lds = 256 * F64K_LD * sizeof(float2);
+    const unsigned grid = (unsigned)(nbatch * 16);
+    hipLaunchKernelGGL((fft64k_pass_kernel<INV, 0>), dim3(grid), dim3(256), lds, s, in, out, tw, in_stride);
+    hipLaunchKernelGGL((fft64k_pass_kernel<INV, 1>), dim3(grid), dim3(256), lds, s, in, out, tw, in_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride)
 {
     if (in_stride <= 0) in_stride = p.nfft; // consecutive messages; smaller strides give overlapping blocks (overlap-save)
@@ -91,6 +142,10 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
+    }
+    if (p.nfft == F64K_N) {
+        if (in == out) return hipErrorNotSupported; // pass 0 is a global transposition: the C-ABI layer stages in-place calls
+        return inv ? launch_fft64k<true>(in, out, p.tw, nbatch, in_stride, s) : launch_fft64k<false>(in, out, p.tw, nbatch, in_stride, s);
     }
     bool generic = false;
     for (int i = 0; i < p.nstages; ++i) generic |= p.st[i].p > 5;

@@ -10,6 +10,14 @@ from . import REDIO_FIR_COMPLEX, REDIO_FIR_FUSED, check, lib
 _pf = C.POINTER(C.c_float)
 
 
+def _safe_destroy(fn, h):
+    """Plan destructors also run at interpreter shutdown, when module globals may already be gone."""
+    try:
+        getattr(lib(), fn)(h)
+    except Exception:
+        pass
+
+
 def current_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -52,7 +60,7 @@ class Fir:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().redio_fir_destroy(self._h)
+            _safe_destroy("redio_fir_destroy", self._h)
             self._h = None
 
 
@@ -74,7 +82,7 @@ class Fft:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().redio_fft_destroy(self._h)
+            _safe_destroy("redio_fft_destroy", self._h)
             self._h = None
 
 
@@ -114,7 +122,7 @@ class Chain:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().redio_chain_destroy(self._h)
+            _safe_destroy("redio_chain_destroy", self._h)
             self._h = None
 
 
@@ -145,7 +153,7 @@ class Src:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().redio_src_destroy(self._h)
+            _safe_destroy("redio_src_destroy", self._h)
             self._h = None
 
 
@@ -192,7 +200,7 @@ class Channelizer:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().redio_pfb_destroy(self._h)
+            _safe_destroy("redio_pfb_destroy", self._h)
             self._h = None
 
 
@@ -239,5 +247,5 @@ class OverlapSave:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().redio_ovsave_destroy(self._h)
+            _safe_destroy("redio_ovsave_destroy", self._h)
             self._h = None

@@ -280,3 +280,32 @@ extern "C" long emu_pfb(const float2 *x, long n, const float *h, int P, int fuse
     if (P == 4) return fused ? emu_pfb_t<4, true>(x, n, h, out, ngroups) : emu_pfb_t<4, false>(x, n, h, out, ngroups);
     return -1;
 }
+
+// 65536-point two-pass transform: tiles of 256 rows x 16 columns, four in-tile stages per pass
+extern "C" void emu_fft64k(const float2 *in, float2 *out, int inverse)
+{
+    std::vector<float2> tw = make_tw(F64K_N, inverse);
+    std::vector<float2> mid(F64K_N), L(256 * F64K_LD);
+    for (int pass = 0; pass < 2; ++pass) {
+        const float2 *src = pass == 0 ? in : mid.data();
+        float2 *dst = pass == 0 ? mid.data() : out;
+        for (int c = 0; c < 16; ++c) {
+            for (int row = 0; row < 256; ++row)
+                for (int col = 0; col < F64K_COLS; ++col) {
+                    if (pass == 0) L[rev4_of_8bit(row) * F64K_LD + col] = src[f64k_p0_src(c, row, col)];
+                    else L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
+                }
+            for (int t = 0; t < 4; ++t)
+                for (int col = 0; col < F64K_COLS; ++col)
+                    for (int b = 0; b < 64; ++b) {
+                        if (inverse) f64k_tile_butterfly<true>(L.data(), tw.data(), pass, t, col, b, F64K_COLS * c + col);
+                        else f64k_tile_butterfly<false>(L.data(), tw.data(), pass, t, col, b, F64K_COLS * c + col);
+                    }
+            for (int row = 0; row < 256; ++row)
+                for (int col = 0; col < F64K_COLS; ++col) {
+                    if (pass == 0) dst[f64k_p0_dst(c, row, col)] = L[row * F64K_LD + col];
+                    else dst[f64k_p1_pos(c, row, col)] = L[row * F64K_LD + col];
+                }
+        }
+    }
+}
