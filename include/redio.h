@@ -134,6 +134,27 @@ int redio_trigger_destroy(redio_trigger *h);
 int redio_trigger_feed(redio_trigger *h, const void *d_blocks_f32, size_t nblocks, size_t block, void *d_out_f32, size_t out_cap,
                        size_t *lens, size_t lens_cap, size_t *nemit, size_t *total, void *stream);
 
+/* ---- the run-length / bit-field stage downstream of discretize (src/ratpak.rs:77-119) ----
+ * One-byte values (discretize emits 0/1), u64 run lengths, f32 seconds; all device-resident. */
+/* kpn::rle, src/kpn/src/kpn.rs:17-29: a run is emitted when the value changes, so the open run is
+ * carried in the handle across calls and never flushed.  *nruns runs written (<= cap).  Synchronous. */
+typedef struct redio_rle redio_rle;
+int redio_rle_create(redio_rle **h);
+int redio_rle_destroy(redio_rle *h);
+int redio_rle_feed(redio_rle *h, const void *d_in_u8, size_t n, void *d_vals_u8, void *d_counts_u64, size_t cap, size_t *nruns,
+                   void *stream);
+/* kpn::dle, kpn.rs:32-38: seconds = ct as f32 / s_rate as f32 */
+int redio_dle(const void *d_counts_u64, size_t n, size_t s_rate, void *d_seconds_f32, void *stream);
+/* kpn::rld, kpn.rs:50-56: (value, count) -> repeated values; d_scratch: (nruns + 1) u64 */
+int redio_rld(const void *d_vals_u8, const void *d_counts_u64, size_t nruns, void *d_out_u8, size_t cap, void *d_scratch, size_t *nout,
+              void *stream);
+/* kpn::dld, kpn.rs:41-47: n = (dur * s_rate) as usize per run; d_scratch: (2 * nruns + 1) u64 */
+int redio_dld(const void *d_vals_u8, const void *d_seconds_f32, size_t nruns, float s_rate, void *d_out_u8, size_t cap, void *d_scratch,
+              size_t *nout, void *stream);
+/* kpn::binconv = eat (kpn.rs:116-124) per message: nmsg messages of nbits one-byte binary digits ->
+ * nfields u64 each, MSB first (b2d, kpn.rs:111-113); widths overrunning a message -> REDIO_ERR_ASSERT */
+int redio_binconv(const void *d_bits_u8, size_t nmsg, size_t nbits, const size_t *widths, size_t nfields, void *d_out_u64, void *stream);
+
 /* ---- C5: overlap-save FFT convolution (BASELINE.json configs[4]; a new composition) ----
  * The valid-mode correlation of dsputils::convolve (dsputils.rs:30-32) on cf32 with real taps, computed
  * per block of nfft samples: out[b*hop + i] = IFFT(FFT(x[b*hop ..]) .* conj(FFT(taps)))[i] / nfft, i < hop,

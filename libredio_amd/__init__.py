@@ -114,6 +114,13 @@ def lib():
     _sig(L.redio_trigger_create, i, C.POINTER(vp))
     _sig(L.redio_trigger_destroy, i, vp)
     _sig(L.redio_trigger_feed, i, vp, vp, sz, sz, vp, sz, psz, sz, psz, psz, vp)
+    _sig(L.redio_rle_create, i, C.POINTER(vp))
+    _sig(L.redio_rle_destroy, i, vp)
+    _sig(L.redio_rle_feed, i, vp, vp, sz, vp, vp, sz, psz, vp)
+    _sig(L.redio_dle, i, vp, sz, sz, vp, vp)
+    _sig(L.redio_rld, i, vp, vp, sz, vp, sz, vp, psz, vp)
+    _sig(L.redio_dld, i, vp, vp, sz, f, vp, sz, vp, psz, vp)
+    _sig(L.redio_binconv, i, vp, sz, sz, psz, sz, vp, vp)
     _sig(L.redio_pfb_create, i, C.POINTER(vp), pf, i, i, u)
     _sig(L.redio_pfb_destroy, i, vp)
     _sig(L.redio_pfb_nrows, sz, vp, sz)
@@ -173,5 +180,5 @@ def check(code, what="redio"):
         raise RedioError(code, what)
 
 
-from . import bitfount, dsputils, kissfft, plans, samplerate  # noqa: E402,F401
+from . import bitfount, dsputils, kissfft, kpn_dev, plans, samplerate  # noqa: E402,F401
 from .plans import Chain, Channelizer, Fft, Fir, OverlapSave, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401

@@ -306,3 +306,45 @@ class Trigger:
         for i in range(ne):
             n = int(lens[i]); res.append(out[off:off + n].copy()); off += n
         return res
+
+
+# ---- run-length blocks (numpy restatements; integer arithmetic with a single possible result) --------
+class Rle:
+    """kpn::rle, src/kpn/src/kpn.rs:17-29: x = first value, i = 1; for every later y: if y != x emit
+    (x, i) and i = 1 else i += 1; x = y.  The open run is never flushed."""
+
+    def __init__(self):
+        self.x = None
+        self.i = 0
+
+    def feed(self, vals):
+        out = []
+        for y in np.asarray(vals).tolist():
+            if self.x is None:
+                self.x, self.i = y, 1
+                continue
+            if y != self.x:
+                out.append((self.x, self.i))
+                self.i = 1
+            else:
+                self.i += 1
+            self.x = y
+        return out
+
+
+def dle(runs, s_rate):
+    """kpn::dle, kpn.rs:32-38: (x, ct) -> (x, ct as f32 / s_rate as f32)."""
+    return [(x, np.float32(np.float32(ct) / np.float32(s_rate))) for x, ct in runs]
+
+
+def rld(runs):
+    """kpn::rld, kpn.rs:50-56."""
+    return [x for x, ct in runs for _ in range(int(ct))]
+
+
+def dld(runs, s_rate):
+    """kpn::dld, kpn.rs:41-47: repeat x (dur*s_rate) as usize times (f32 product, truncating cast)."""
+    out = []
+    for x, dur in runs:
+        out += [x] * int(np.float32(np.float32(dur) * np.float32(s_rate)))
+    return out

@@ -1,0 +1,72 @@
+"""Run-length / bit-field stage (kpn::rle, dle, rld, dld, binconv) on the MI355X against the numpy /
+C restatements in oracle/: exact integer work."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rle_streaming_state_and_unflushed_last_run(gpu, redio, oracle):
+    rng = np.random.default_rng(3)
+    x = np.repeat(rng.integers(0, 2, 4000), rng.integers(1, 40, 4000)).astype(np.uint8)
+    dev, ref = redio.kpn_dev.Rle(), oracle.Rle()
+    cuts = [0, 1, 2, 5000, 5001, 20000, len(x)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        v, c = dev.feed(gpu.from_numpy(x[lo:hi]).cuda())
+        want = ref.feed(x[lo:hi])
+        assert list(zip(v.cpu().tolist(), c.cpu().tolist())) == want, (lo, hi)
+    # a constant tail emits nothing: the last run is never flushed (kpn.rs:17-29)
+    v, c = dev.feed(gpu.full((1000,), int(x[-1]), dtype=gpu.uint8, device="cuda"))
+    assert v.numel() == 0 and ref.feed(np.full(1000, x[-1])) == []
+    v, c = dev.feed(gpu.tensor([1 - int(x[-1])], dtype=gpu.uint8, device="cuda"))
+    assert list(zip(v.cpu().tolist(), c.cpu().tolist())) == ref.feed([1 - int(x[-1])])
+
+
+def test_rle_large_and_multivalue(gpu, redio, oracle):
+    rng = np.random.default_rng(5)
+    x = np.repeat(rng.integers(0, 256, 300000), rng.integers(1, 9, 300000)).astype(np.uint8)
+    v, c = redio.kpn_dev.Rle().feed(gpu.from_numpy(x).cuda())
+    want = oracle.Rle().feed(x)
+    assert v.numel() == len(want)
+    assert np.array_equal(v.cpu().numpy(), np.array([w[0] for w in want], np.uint8))
+    assert np.array_equal(c.cpu().numpy(), np.array([w[1] for w in want], np.int64))
+
+
+def test_dle_rld_dld_round_trip(gpu, redio, oracle):
+    runs = [(1, 51), (0, 512), (1, 90), (0, 1), (1, 1000)]
+    vals = gpu.tensor([r[0] for r in runs], dtype=gpu.uint8, device="cuda")
+    cts = gpu.tensor([r[1] for r in runs], dtype=gpu.int64, device="cuda")
+    sec = redio.kpn_dev.dle(cts, 256000)                      # ratpak.rs: dle(.., 256000)
+    want = oracle.dle(runs, 256000)
+    assert np.array_equal(sec.cpu().numpy().view(np.uint32), np.array([w[1] for w in want], np.float32).view(np.uint32))
+    assert redio.kpn_dev.rld(vals, cts).cpu().tolist() == oracle.rld(runs)
+    got = redio.kpn_dev.dld(vals, sec, 256000.0, 4096).cpu().tolist()
+    assert got == oracle.dld([(v, s) for (v, _), (_, s) in zip(runs, want)], 256000.0)
+
+
+def test_binconv_ratpak_width_lists(gpu, redio, oracle):
+    rng = np.random.default_rng(9)
+    bits = rng.integers(0, 2, (500, 36)).astype(np.uint8)
+    for widths in ([4, 8, 4, 12, 8], [4, 8, 2, 10, 12]):          # src/ratpak.rs:115,119
+        got = redio.kpn_dev.binconv(gpu.from_numpy(bits).cuda(), widths).cpu().numpy()
+        want = np.array([oracle.eat(b, widths) for b in bits], np.int64)
+        assert np.array_equal(got, want)
+    with pytest.raises(redio.RedioError) as e:
+        redio.kpn_dev.binconv(gpu.from_numpy(bits).cuda(), [30, 10])   # slice out of bounds in the reference
+    assert e.value.code == -5
+    assert redio.kpn_dev.binconv(gpu.tensor([[1, 0, 1]], dtype=gpu.uint8, device="cuda"), [3]).item() == oracle.b2d([1, 0, 1]) == 5
+
+
+def test_shipped_graph_discretize_to_runs(gpu, redio, oracle):
+    """discretize -> rle -> dle, as src/ratpak.rs:73-87 wires them, device-resident end to end."""
+    rng = np.random.default_rng(21)
+    env = np.repeat(rng.integers(0, 2, 400), rng.integers(30, 200, 400)).astype(np.float32)
+    buf = (0.05 * rng.random(len(env)) + env).astype(np.float32)
+    bits_dev = redio.bitfount.discretize(gpu.from_numpy(buf).cuda())
+    bits_ref = oracle.discretize(buf).astype(np.uint8)
+    assert np.array_equal(bits_dev.cpu().numpy(), bits_ref)
+    v, c = redio.kpn_dev.Rle().feed(bits_dev)
+    want = oracle.Rle().feed(bits_ref)
+    assert list(zip(v.cpu().tolist(), c.cpu().tolist())) == want
+    sec = redio.kpn_dev.dle(c, 256000).cpu().numpy()
+    assert np.array_equal(sec.view(np.uint32), np.array([w[1] for w in oracle.dle(want, 256000)], np.float32).view(np.uint32))
