@@ -1,0 +1,163 @@
+// kpn_dev.hpp -- device-resident messages for kpn graphs: the steps either side of
+// every hot block without host round trips.  A message is a kpn::dev::View = shared ownership of a
+// device allocation + (offset, length) in samples, so the reshaping blocks of src/kpn/src/kpn.rs become
+// metadata operations:
+//   fork (kpn.rs:182-189)            clones the handle, not the samples (kpn::fork works unchanged on Views)
+//   shaper (kpn.rs:278-282)          dev::shaper: re-chunks a stream of Views into Views of length l,
+//                                    zero-copy when a chunk lies inside one allocation
+//   unpacketizer / shaper_vecs       the inverse is the identity on a View stream
+// and the hot blocks consume and produce Views through the device plans of include/redio.h.  Channels stay
+// the same unbounded FIFOs; back-pressure is the caller's business exactly as in the reference.
+#pragma once
+#include "kpn.hpp"
+#include <complex>
+#include <memory>
+#include <vector>
+
+namespace kpn {
+namespace dev {
+
+struct Alloc {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    explicit Alloc(size_t b) : bytes(b)
+    {
+        int rc = redio_malloc(&ptr, b ? b : 1);
+        if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc));
+    }
+    ~Alloc() { redio_free(ptr); }
+    Alloc(const Alloc &) = delete;
+    Alloc &operator=(const Alloc &) = delete;
+};
+
+template <typename T>
+struct View {
+    std::shared_ptr<Alloc> mem;
+    size_t off = 0, len = 0; // in elements of T
+    T *data() const { return reinterpret_cast<T *>(mem->ptr) + off; }
+    View sub(size_t o, size_t n) const { return View{mem, off + o, n}; }
+};
+
+template <typename T>
+View<T> make(size_t n) { return View<T>{std::make_shared<Alloc>(n * sizeof(T)), 0, n}; }
+
+inline void check(int rc)
+{
+    if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc));
+}
+
+// host Vec<T> -> device View<T> and back (the only PCIe crossings of a device-resident graph)
+template <typename T>
+void to_device(Receiver<std::vector<T>> u, Sender<View<T>> v)
+{
+    for (;;) {
+        auto x = u.recv();
+        auto d = make<T>(x.size());
+        check(redio_upload(d.data(), x.data(), x.size() * sizeof(T), nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(d));
+    }
+}
+template <typename T>
+void to_host(Receiver<View<T>> u, Sender<std::vector<T>> v)
+{
+    for (;;) {
+        auto d = u.recv();
+        std::vector<T> x(d.len);
+        check(redio_download(x.data(), d.data(), d.len * sizeof(T), nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(x));
+    }
+}
+
+// kpn::shaper on a View stream: chunks of exactly l samples; zero-copy when possible, otherwise the
+// straddling chunk is assembled once on the device.  A trailing partial chunk is dropped at hang-up.
+template <typename T>
+void shaper(Receiver<View<T>> u, Sender<View<T>> v, size_t l)
+{
+    View<T> pend;           // partially filled chunk (owned copy)
+    size_t have = 0;
+    for (;;) {
+        auto d = u.recv();
+        size_t pos = 0;
+        while (pos < d.len) {
+            if (have == 0 && d.len - pos >= l) { // whole chunk inside this message: a view
+                v.send_unwrap(d.sub(pos, l));
+                pos += l;
+                continue;
+            }
+            if (have == 0) pend = make<T>(l);
+            const size_t take = std::min(l - have, d.len - pos);
+            check(redio_copy(pend.data() + have, d.data() + pos, take * sizeof(T), nullptr));
+            have += take;
+            pos += take;
+            if (have == l) {
+                check(redio_stream_sync(nullptr));
+                v.send_unwrap(pend);
+                have = 0;
+            }
+        }
+    }
+}
+
+// dsputils::convolve semantics on device streams (complex samples x real taps, optional decimation)
+inline void fir(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, size_t decim, bool fused)
+{
+    redio_fir *h = nullptr;
+    check(redio_fir_create(&h, taps.data(), taps.size(), decim, REDIO_FIR_COMPLEX | (fused ? REDIO_FIR_FUSED : 0)));
+    struct G { redio_fir *h; ~G() { redio_fir_destroy(h); } } g{h};
+    for (;;) {
+        auto d = u.recv();
+        auto o = make<std::complex<float>>(redio_fir_nout(h, d.len));
+        check(redio_fir_enqueue(h, d.data(), d.len, o.data(), nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(o));
+    }
+}
+
+// kissfft::fft semantics: every message must be a whole number of block_size-sample blocks
+inline void fft(Receiver<View<std::complex<float>>> pin, Sender<View<std::complex<float>>> cout, uint32_t block_size, uint32_t inv)
+{
+    redio_fft *h = nullptr;
+    check(redio_fft_create(&h, (int)block_size, (int)inv));
+    struct G { redio_fft *h; ~G() { redio_fft_destroy(h); } } g{h};
+    for (;;) {
+        auto d = pin.recv();
+        if (d.len % block_size) throw std::runtime_error("assert!(din.len() == block_size) (kissfft.rs:24)");
+        auto o = make<std::complex<float>>(d.len);
+        check(redio_fft_enqueue(h, d.data(), o.data(), d.len / block_size, nullptr));
+        check(redio_stream_sync(nullptr));
+        cout.send_unwrap(std::move(o));
+    }
+}
+
+// the fused north-star chain as one block
+inline void fir_fft_chain(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps,
+                          size_t decim, int nfft, bool fused)
+{
+    redio_chain *h = nullptr;
+    check(redio_chain_create(&h, taps.data(), taps.size(), decim, nfft, fused ? REDIO_FIR_FUSED : 0));
+    struct G { redio_chain *h; ~G() { redio_chain_destroy(h); } } g{h};
+    for (;;) {
+        auto d = u.recv();
+        auto o = make<std::complex<float>>(redio_chain_nblocks(h, d.len) * (size_t)nfft);
+        check(redio_chain_enqueue(h, d.data(), d.len, o.data(), nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(o));
+    }
+}
+
+// the front end of the shipped graph: u8 IQ bytes -> |x| (rtlsdr.rs:159-162 + ratpak.rs:64-68)
+inline void ingest_mag(Receiver<View<uint8_t>> u, Sender<View<float>> v)
+{
+    for (;;) {
+        auto d = u.recv();
+        auto o = make<float>(d.len / 2);
+        check(redio_ingest_u8_mag(d.data(), d.len, o.data(), nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(o));
+    }
+}
+
+} // namespace dev
+} // namespace kpn

@@ -46,6 +46,7 @@ int redio_malloc(void **dptr, size_t bytes);
 int redio_free(void *dptr);
 int redio_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int redio_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int redio_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int redio_stream_create(void **stream);
 int redio_stream_destroy(void *stream);
 int redio_stream_sync(void *stream); /* NULL = default stream */

@@ -65,6 +65,7 @@ def lib():
     _sig(L.redio_free, i, vp)
     _sig(L.redio_upload, i, vp, vp, sz, vp)
     _sig(L.redio_download, i, vp, vp, sz, vp)
+    _sig(L.redio_copy, i, vp, vp, sz, vp)
     _sig(L.redio_stream_create, i, C.POINTER(vp))
     _sig(L.redio_stream_destroy, i, vp)
     _sig(L.redio_stream_sync, i, vp)

@@ -65,6 +65,12 @@ extern "C" int redio_download(void *dst, const void *src, size_t bytes, void *st
     if (!dst || !src) return REDIO_ERR_ARG;
     return hip_rc(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
 }
+extern "C" int redio_copy(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return REDIO_OK;
+    if (!dst || !src) return REDIO_ERR_ARG;
+    return hip_rc(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+}
 extern "C" int redio_stream_create(void **stream)
 {
     if (!stream) return REDIO_ERR_ARG;

@@ -5,6 +5,7 @@
 //   kpn_tests resample in.bin out.bin ratio msg_len   samplerate::resample block over raw f32 messages
 #include "../../include/kpn.hpp"
 #include "../../include/wavio.hpp"
+#include "../../include/kpn_dev.hpp"
 #include <cassert>
 #include <cmath>
 #include <fstream>
@@ -269,6 +270,65 @@ static int resample_graph(const char *in, const char *out, double ratio, size_t 
     return 0;
 }
 
+// device-resident graph: host messages -> to_device -> dev::shaper(5120*nb+126 views) is not needed here;
+// the chain consumes each message whole: bytes/IQ stay in HBM between blocks, fork shares one allocation.
+static int dev_chain_graph(const char *in, const char *out_spec, const char *out_fir, size_t msg)
+{
+    using cf = std::complex<float>;
+    auto x = read_bin<cf>(in);
+    const std::vector<float> taps = dsputils::lpf_corrected(127, 0.08f);
+    auto [s0, r0] = channel<std::vector<cf>>();
+    auto [s1, r1] = channel<dev::View<cf>>();
+    auto [s2a, r2a] = channel<dev::View<cf>>();
+    auto [s2b, r2b] = channel<dev::View<cf>>();
+    auto [s3a, r3a] = channel<dev::View<cf>>();
+    auto [s3b, r3b] = channel<dev::View<cf>>();
+    auto [s4a, r4a] = channel<std::vector<cf>>();
+    auto [s4b, r4b] = channel<std::vector<cf>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x, msg]() mutable {
+        for (size_t o = 0; o + msg <= x.size(); o += msg) s.send(std::vector<cf>(x.begin() + (long)o, x.begin() + (long)(o + msg)));
+    }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { dev::to_device<cf>(std::move(r), std::move(s)); }));
+    std::vector<Sender<dev::View<cf>>> outs;
+    outs.push_back(std::move(s2a)); outs.push_back(std::move(s2b));
+    th.push_back(spawn([r = std::move(r1), o = std::move(outs)]() mutable { fork<dev::View<cf>>(std::move(r), std::move(o)); })); // zero-copy
+    th.push_back(spawn([r = std::move(r2a), s = std::move(s3a), taps]() mutable { dev::fir_fft_chain(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    th.push_back(spawn([r = std::move(r2b), s = std::move(s3b), taps]() mutable { dev::fir(std::move(r), std::move(s), taps, 5, true); }));
+    th.push_back(spawn([r = std::move(r3a), s = std::move(s4a)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r3b), s = std::move(s4b)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    std::vector<cf> spec, fir;
+    while (auto v = r4a.try_recv_blocking()) spec.insert(spec.end(), v->begin(), v->end());
+    while (auto v = r4b.try_recv_blocking()) fir.insert(fir.end(), v->begin(), v->end());
+    for (auto &t : th) t.join();
+    write_bin(out_spec, spec);
+    write_bin(out_fir, fir);
+    return 0;
+}
+
+// dev::shaper: re-chunk a View stream (zero-copy inside a message, assembled across a seam)
+static int dev_shaper_graph(const char *in, const char *out, size_t msg, size_t l)
+{
+    auto x = read_bin<float>(in);
+    auto [s0, r0] = channel<std::vector<float>>();
+    auto [s1, r1] = channel<dev::View<float>>();
+    auto [s2, r2] = channel<dev::View<float>>();
+    auto [s3, r3] = channel<std::vector<float>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x, msg]() mutable {
+        for (size_t o = 0; o < x.size(); o += msg) s.send(std::vector<float>(x.begin() + (long)o, x.begin() + (long)std::min(o + msg, x.size())));
+    }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { dev::to_device<float>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), l]() mutable { dev::shaper<float>(std::move(r), std::move(s), l); }));
+    th.push_back(spawn([r = std::move(r2), s = std::move(s3)]() mutable { dev::to_host<float>(std::move(r), std::move(s)); }));
+    std::vector<float> y;
+    size_t nmsg = 0;
+    while (auto v = r3.try_recv_blocking()) { if (v->size() != l) return 4; y.insert(y.end(), v->begin(), v->end()); ++nmsg; }
+    for (auto &t : th) t.join();
+    write_bin(out, y);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -276,6 +336,8 @@ int main(int argc, char **argv)
         if (mode == "plumbing") return plumbing();
         if (mode == "c1" && argc == 4) return c1(argv[2], argv[3]);
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
+        if (mode == "devchain" && argc == 6) return dev_chain_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
+        if (mode == "devshaper" && argc == 6) return dev_shaper_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]));
         if (mode == "resample" && argc == 6) return resample_graph(argv[2], argv[3], std::atof(argv[4]), (size_t)std::atol(argv[5]));
         std::fprintf(stderr, "usage: see the header of kpn_tests.cpp\n");
         return 2;

@@ -90,3 +90,30 @@ def test_resample_block_in_cpp_graph(exe, gpu, oracle, tmp_path):
     ref = oracle.Resampler(1)
     want = np.concatenate([ref.block(x[i:i + 7000], 0.5) for i in range(0, 28000, 7000)])
     assert np.array_equal(bits(y), bits(want))
+
+
+@pytest.mark.gpu
+def test_device_resident_graph_fork_chain_and_fir(exe, gpu, oracle, tmp_path):
+    """include/kpn_dev.hpp: to_device -> fork (shares the allocation) -> {fused chain, FIR} -> to_host."""
+    msg = 4 * 5120 + 126
+    x = oracle.synth_iq(0x5EED0002, 0, 3 * msg)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "devchain", str(tmp_path / "in.bin"), str(tmp_path / "spec.bin"), str(tmp_path / "fir.bin"), str(msg)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    taps = oracle.lpf_corrected(127, 0.08)
+    spec = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
+    fir = np.fromfile(tmp_path / "fir.bin", dtype=np.complex64)
+    want_spec = np.concatenate([oracle.chain_fir_fft(x[i * msg:(i + 1) * msg], taps, 5, 1024, True).reshape(-1) for i in range(3)])
+    want_fir = np.concatenate([oracle.fir(x[i * msg:(i + 1) * msg], taps, 5, True) for i in range(3)])
+    assert np.array_equal(bits(spec), bits(want_spec)) and np.array_equal(bits(fir), bits(want_fir))
+
+
+@pytest.mark.gpu
+def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
+    x = oracle.synth_f32(3, 0, 10000)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "devshaper", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "3000", "1024"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    assert np.array_equal(bits(y), bits(x[: (10000 // 1024) * 1024]))   # the trailing partial chunk is dropped (kpn.rs:278-282)
