@@ -23,7 +23,9 @@ __device__ __forceinline__ void static_for4(F &&f)
     }
 }
 
-template <int K, int D, bool FUSED, int WPS, int CH>
+// FIR_ONLY: the same data movement and FIR, but the decimated samples are stored instead of transformed
+// (the stand-alone decimating FIR of redio_fir_* for this shape); `out` then holds 1024 outputs per block.
+template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false>
 __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
                                                            const float2 *__restrict__ tw, float2 *__restrict__ out,
                                                            long nblocks, long blocks_per_wave, unsigned long long *dbg)
@@ -81,15 +83,21 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
         int lf = lane; // opaque per sub-tile: keeps LDS address arithmetic out of the loop's live set
         asm volatile("" : "+v"(lf));
         fir_lane_v<K, D, R, FUSED, CH>(xs4, lf, taps, acc);
+        if (FIR_ONLY) { // 32 contiguous bytes per lane, 2 KiB per wave
+            v4f_t *y4 = reinterpret_cast<v4f_t *>(out + (b0 * 4 + j) * SUB_OUT) + 2 * lane;
+            y4[0] = v4f_t{acc[0].x, acc[0].y, acc[1].x, acc[1].y};
+            y4[1] = v4f_t{acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+        } else {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) a[i] = a[i + 4];
+            for (int i = 0; i < 12; ++i) a[i] = a[i + 4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) a[12 + r] = acc[r];
+            for (int r = 0; r < R; ++r) a[12 + r] = acc[r];
+        }
         wave_lds_fence(); // window reads done
         // the last HALO samples of this image are the first HALO samples of the next one
         v4f_t halo = v4f_t{0.f, 0.f, 0.f, 0.f};
         if (more && lf < HALO_V) halo = xs4[G::lds_index(SUB_NEW + 2 * lf) / 2];
-        if ((j & 3) == 3) { // a block is complete in registers: transform it, the image is scratch meanwhile
+        if (!FIR_ONLY && (j & 3) == 3) { // a block is complete in registers: transform it, the image is scratch meanwhile
             wave_lds_fence();
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -126,7 +134,7 @@ static int num_cus_v4()
     return cus;
 }
 
-template <int K, int D, int WPS, int CH>
+template <int K, int D, int WPS, int CH, bool FIR_ONLY = false>
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg)
 {
@@ -144,8 +152,8 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     if (waves > nblocks) waves = nblocks;
     const long bpw = (nblocks + waves - 1) / waves;
     const long grid = (nblocks + bpw - 1) / bpw;
-    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
-    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
     return hipGetLastError();
 }
 
@@ -154,6 +162,12 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
 {
     if (wps == 3) return launch_v4_t<127, 5, 3, 6>(x, taps, tw, out, nblocks, fused, s, dbg);
     return launch_v4_t<127, 5, 2, 8>(x, taps, tw, out, nblocks, fused, s, dbg);
+}
+
+// stand-alone 127-tap decimate-by-5 FIR on whole 1024-output blocks (16-byte aligned cf32 in and out)
+hipError_t launch_fir_v4_127_5(const float2 *x, const float *taps, float2 *y, long nblocks, bool fused, hipStream_t s)
+{
+    return launch_v4_t<127, 5, 2, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
 }
 
 } // namespace redio
