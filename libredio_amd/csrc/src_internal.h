@@ -6,6 +6,9 @@ namespace redio {
 hipError_t launch_src_exact(const float *win, long win_stride, const float *coeffs, int coeff_half_len,
                             const int *pos, const int *start, const int *inc, const double *scale,
                             float *out, long out_stride, long nout, int nchan, hipStream_t s);
+hipError_t launch_src_uniform(const float *win, long win_stride, const double *cl_rev, int ncl, const double *cr_rev, int ncr,
+                              int pos0, int S, double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s);
+size_t src_uniform_lds(int nt, int S, int cl, int cr);
 hipError_t launch_src_copy_rows(const float *src, long src_stride, long src_off, float *dst, long dst_stride, long dst_off,
                                 long n, int nchan, hipStream_t s);
 hipError_t launch_src_fill_rows(float *dst, long dst_stride, long dst_off, long n, int nchan, float v, hipStream_t s);

@@ -78,6 +78,109 @@ hipError_t launch_src_exact(const float *win, long win_stride, const float *coef
     return hipGetLastError();
 }
 
+// ---- uniform-phase fast path -------------------------------------------------------------------
+// When 1/ratio is an integer S and the phase is zero (decimation by S, or ratio 1), every output of an
+// epoch has start_filter_index 0 and the same increment, so the interpolated coefficients are the same
+// for every output: c_left[i] = c(i*inc), c_right[i] = c((i+1)*inc), computed once on the host in
+// double exactly as the per-tap expression would.  One wavefront then produces 64 consecutive outputs
+// from an LDS tile of the 63*S + cl + cr + 2 input samples behind them (coalesced load, one pad float
+// per S samples so the lane stride S+1 is odd -> conflict-free ds_read_b32), each lane running the two
+// wings as two independent, strictly ordered double accumulations -- the library's own order, so the
+// result is bit-identical to the general kernel and to the oracle.  Coefficients are wave-uniform and
+// come through the scalar cache.
+template <int NT> // NT threads = NT consecutive outputs per workgroup tile
+__global__ __launch_bounds__(NT) void src_sinc_uniform_kernel(const float *__restrict__ win, long win_stride,
+                                                              const double *__restrict__ cl_rev, int ncl, // far end first
+                                                              const double *__restrict__ cr_rev, int ncr,
+                                                              int pos0, int S, double scale, float *__restrict__ out,
+                                                              long out_stride, long nout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x;
+    const long k0 = (long)blockIdx.x * NT;
+    const float *x = win + (long)blockIdx.y * win_stride;
+    const int pad = (S & 1) ? 0 : 1;
+    const int cl = ncl - 1, cr = ncr - 1;
+    const long tile_base = (long)pos0 + (long)S * k0 - cl; // buffer index of tile-relative sample 0
+    const int span = (NT - 1) * S + cl + cr + 2;
+    // the last tile may reach past the outputs that exist: clamp the load to what the valid outputs need
+    const long nvalid = (nout - k0 < NT) ? nout - k0 : NT;
+    const int need = (int)((nvalid - 1) * S) + cl + cr + 2;
+    for (int n = tid; n < span; n += NT) xs[n + (pad ? n / S : 0)] = (n < need) ? x[tile_base + n] : 0.0f;
+    __syncthreads();
+    if (k0 + tid >= nout) return;
+    const int lbase = (S + pad) * tid;
+    // the two wings are independent sums, each strictly ordered (far end first): run them side by side
+    // so that two dependent double-precision chains are in flight per lane
+    double left = 0.0, right = 0.0;
+    const int c = cl + 1 + cr;
+    int lrem = 0, lquo = 0;                  // left data index  t      = lquo*S + lrem
+    int rquo = c / S, rrem = c - rquo * S;   // right data index c - t  = rquo*S + rrem
+    const int both = cl < cr ? cl : cr;      // cl == cr or cl == cr + 1
+    int t = 0;
+    for (; t <= both; ++t) {
+        const float xl = xs[lbase + t + (pad ? lquo : 0)];
+        const float xr = xs[lbase + (c - t) + (pad ? rquo : 0)];
+        left += cl_rev[t] * (double)xl;
+        right += cr_rev[t] * (double)xr;
+        if (++lrem == S) { lrem = 0; ++lquo; }
+        if (--rrem < 0) { rrem += S; --rquo; }
+    }
+    for (; t <= cl; ++t) {
+        left += cl_rev[t] * (double)xs[lbase + t + (pad ? lquo : 0)];
+        if (++lrem == S) { lrem = 0; ++lquo; }
+    }
+    for (; t <= cr; ++t) {
+        right += cr_rev[t] * (double)xs[lbase + (c - t) + (pad ? rquo : 0)];
+        if (--rrem < 0) { rrem += S; --rquo; }
+    }
+    out[(long)blockIdx.y * out_stride + k0 + tid] = (float)(scale * (left + right));
+}
+
+template <int NT>
+static hipError_t launch_uniform_t(const float *win, long win_stride, const double *cl_rev, int ncl, const double *cr_rev, int ncr,
+                                   int pos0, int S, double scale, float *out, long out_stride, long nout, int nchan, size_t lds_bytes,
+                                   hipStream_t s)
+{
+    auto kern = src_sinc_uniform_kernel<NT>;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((nout + NT - 1) / NT), (unsigned)nchan);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes, s, win, win_stride, cl_rev, ncl, cr_rev, ncr, pos0, S, scale, out, out_stride, nout);
+    return hipGetLastError();
+}
+
+// LDS bytes of a tile of nt outputs; 0 if it cannot fit
+size_t src_uniform_lds(int nt, int S, int cl, int cr)
+{
+    const long span = (long)(nt - 1) * S + cl + cr + 2;
+    const size_t b = (size_t)(span + span / S + 2) * sizeof(float);
+    return b <= 150 * 1024 ? b : 0;
+}
+
+hipError_t launch_src_uniform(const float *win, long win_stride, const double *cl_rev, int ncl, const double *cr_rev, int ncr,
+                              int pos0, int S, double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s)
+{
+    if (nout <= 0 || nchan <= 0) return hipSuccess;
+    const int cl = ncl - 1, cr = ncr - 1;
+    // widest tile that still lets two workgroups share a CU, else the widest that fits at all
+    const int cand[3] = {256, 128, 64};
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < 3; ++i) {
+            const size_t b = src_uniform_lds(cand[i], S, cl, cr);
+            if (!b || (pass == 0 && b > 78 * 1024)) continue;
+            switch (cand[i]) {
+            case 256: return launch_uniform_t<256>(win, win_stride, cl_rev, ncl, cr_rev, ncr, pos0, S, scale, out, out_stride, nout, nchan, b, s);
+            case 128: return launch_uniform_t<128>(win, win_stride, cl_rev, ncl, cr_rev, ncr, pos0, S, scale, out, out_stride, nout, nchan, b, s);
+            default: return launch_uniform_t<64>(win, win_stride, cl_rev, ncl, cr_rev, ncr, pos0, S, scale, out, out_stride, nout, nchan, b, s);
+            }
+        }
+    return hipErrorNotSupported;
+}
+
 // window maintenance: dst[c][0..keep) = src[c][from..from+keep) (overlapping allowed: goes through
 // registers in ascending order per thread block stride, keep <= from is NOT assumed -> two-buffer use)
 __global__ __launch_bounds__(256) void src_copy_rows_kernel(const float *__restrict__ src, long src_stride, long src_off,
