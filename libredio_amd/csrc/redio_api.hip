@@ -32,6 +32,7 @@ extern "C" const char *redio_strerror(int code)
     default: break;
     }
     if (code <= REDIO_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(REDIO_ERR_HIP_BASE - code));
+    if (code > 0 && code <= 22) return "libsamplerate-style converter error (see src_strerror in include/samplerate.h)";
     return "unknown redio error";
 }
 extern "C" const char *redio_version(void) { return "libredio 0.1 (gfx950)"; }

@@ -393,7 +393,7 @@ extern "C" int redio_src_process(redio_src *s, const void *d_in, long input_fram
     if (input_frames_used) *input_frames_used = 0;
     if (output_frames_gen) *output_frames_gen = 0;
     if (!s) return REDIO_SRC_ERR_BAD_STATE;
-    if (!d_in || !d_out) return REDIO_SRC_ERR_BAD_DATA_PTR;
+    if ((!d_in && input_frames > 0) || (!d_out && output_frames > 0)) return REDIO_SRC_ERR_BAD_DATA_PTR; // an empty side may be NULL in the batched form
     SRC_TRY(hipSetDevice(s->device));
     SrcInput in = {nullptr, (const float *)d_in, in_stride};
     // pinned-free staging of the per-output parameters means the host arrays must stay untouched until
