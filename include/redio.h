@@ -206,6 +206,14 @@ int redio_src_create(redio_src **h, int converter, int nchan);
 int redio_src_destroy(redio_src *h);
 int redio_src_reset(redio_src *h);
 int redio_src_set_ratio(redio_src *h, double ratio);
+/* arithmetic of the device-resident form.  EXACT (default): double accumulation in the library's
+ * order, bit-identical to the oracle; calls whose phase is uniform (constant ratio, 1/ratio an
+ * integer, no end_of_input) run as one launch.  FAST: those uniform calls use an f32 polyphase
+ * filter bank (taps rounded to f32, f32 accumulation) - NOT bit-identical, error bounded by
+ * ntaps * 2^-23 * sum|h| * max|x|; every other call still runs EXACT.  EPOCHS: EXACT with one
+ * launch per buffer refill, the literal schedule of the library (kept for cross-checks). */
+enum { REDIO_SRC_EXACT = 0, REDIO_SRC_FAST = 1, REDIO_SRC_EPOCHS = 2 };
+int redio_src_set_mode(redio_src *h, int mode);
 /* device-resident: d_in[nchan][in_stride], d_out[nchan][out_stride] f32; synchronises the stream
  * before returning (per-output parameters are produced by the host state machine) */
 int redio_src_process(redio_src *h, const void *d_in, long input_frames, long in_stride, void *d_out, long output_frames,

@@ -98,6 +98,7 @@ def lib():
     _sig(L.redio_src_destroy, i, vp)
     _sig(L.redio_src_reset, i, vp)
     _sig(L.redio_src_set_ratio, i, vp, C.c_double)
+    _sig(L.redio_src_set_mode, i, vp, i)
     _sig(L.redio_src_process, i, vp, vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_double, i, pl, pl, vp)
     _sig(L.redio_src_process_host, i, vp, pf, C.c_long, pf, C.c_long, C.c_double, i, pl, pl)
     _sig(L.redio_src_table, i, i, pf, C.POINTER(i), C.POINTER(i))

@@ -94,6 +94,9 @@ struct redio_src {
     int fast_inc;
     double *d_cl, *d_cr;
     int ncl, ncr;
+    float2 *d_T2; int nm; double fast_scale; // packed f32 tap pairs of the polyphase path
+    int mode;                                // REDIO_SRC_EXACT / REDIO_SRC_FAST
+    int window_ok;                           // single-launch path enabled (off: one launch per buffer refill)
     size_t stage_in_cap, stage_out_cap;
 };
 
@@ -137,6 +140,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
     s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0;
     s->fast_inc = 0; s->d_cl = s->d_cr = nullptr; s->ncl = s->ncr = 0;
+    s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
     s->h_coeffs = coeffs;
     long bl = lrint(2.5 * half / (inc * 1.0) * SRC_MAX_RATIO);
     if (bl < 4096) bl = 4096;
@@ -159,8 +163,17 @@ extern "C" int redio_src_destroy(redio_src *s)
     hipFree(s->d_coeffs); hipFree(s->d_buf[0]); hipFree(s->d_buf[1]);
     hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
     hipFree(s->d_stage_in); hipFree(s->d_stage_out);
-    hipFree(s->d_cl); hipFree(s->d_cr);
+    hipFree(s->d_cl); hipFree(s->d_cr); hipFree(s->d_T2);
     delete s;
+    return REDIO_OK;
+}
+
+extern "C" int redio_src_set_mode(redio_src *s, int mode)
+{
+    if (!s) return REDIO_SRC_ERR_BAD_STATE;
+    if (mode != REDIO_SRC_EXACT && mode != REDIO_SRC_FAST && mode != REDIO_SRC_EPOCHS) return REDIO_ERR_ARG;
+    if (mode == REDIO_SRC_EPOCHS) { s->window_ok = 0; s->mode = REDIO_SRC_EXACT; }
+    else { s->window_ok = 1; s->mode = mode; }
     return REDIO_OK;
 }
 
@@ -282,6 +295,30 @@ static int prepare_uniform(redio_src *f, int inc)
     SRC_TRY(hipMemcpy(f->d_cl, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
     SRC_TRY(hipMemcpy(f->d_cr, R.data(), R.size() * sizeof(double), hipMemcpyHostToDevice));
     f->ncl = cl + 1; f->ncr = cr + 1; f->fast_inc = inc;
+    hipFree(f->d_T2); f->d_T2 = nullptr; f->nm = 0; // rebuilt on demand for the new increment
+    return REDIO_OK;
+}
+
+// packed f32 tap pairs of the polyphase path: H[j] = (float)(scale*icoeff_j) over both wings in data
+// order, T2[m] = (H[m], H[m-S])
+static int prepare_fast_taps(redio_src *f, int S, double scale)
+{
+    if (f->d_T2 && f->fast_scale == scale && f->nm >= 0 && f->nm == ((f->ncl + f->ncr + S + 127) & ~127)) return REDIO_OK;
+    std::vector<double> L((size_t)f->ncl), R((size_t)f->ncr);
+    SRC_TRY(hipMemcpy(L.data(), f->d_cl, L.size() * sizeof(double), hipMemcpyDeviceToHost));
+    SRC_TRY(hipMemcpy(R.data(), f->d_cr, R.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int KH = f->ncl + f->ncr;
+    std::vector<float> H((size_t)KH);
+    for (int j = 0; j < f->ncl; ++j) H[(size_t)j] = (float)(scale * L[(size_t)j]);                       // far end first
+    for (int i = 0; i < f->ncr; ++i) H[(size_t)(f->ncl + i)] = (float)(scale * R[(size_t)(f->ncr - 1 - i)]); // near end first
+    const int nm = (KH + S + 127) & ~127; // zero filled to a whole number of 16-tap steps for each of 8 waves
+    std::vector<float2> T((size_t)nm);
+    for (int m = 0; m < nm; ++m)
+        T[(size_t)m] = make_float2(m < KH ? H[(size_t)m] : 0.0f, (m - S >= 0 && m - S < KH) ? H[(size_t)(m - S)] : 0.0f);
+    hipFree(f->d_T2); f->d_T2 = nullptr;
+    SRC_TRY(hipMalloc((void **)&f->d_T2, T.size() * sizeof(float2)));
+    SRC_TRY(hipMemcpy(f->d_T2, T.data(), T.size() * sizeof(float2), hipMemcpyHostToDevice));
+    f->nm = nm; f->fast_scale = scale;
     return REDIO_OK;
 }
 
@@ -319,6 +356,91 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
     return REDIO_OK;
 }
 
+// ---- single-launch path for uniform phase (constant ratio, 1/ratio an integer, zero phase, no flush) ----
+// Runs the library's control flow on counters only (same decisions, same in_used / out_gen / final
+// buffer state), evaluates every output in one launch over [old image | new input], then rebuilds the
+// part of the buffer image that later calls can read.  Returns 1 when it handled the call, 0 when the
+// call is not eligible (the epoch path then runs), < 0 / error code on failure.
+static int try_uniform_window(redio_src *f, const SrcInput &in, long in_count, float *d_out, long out_stride, long out_count,
+                              double src_ratio_arg, int end_of_input, long *in_used_out, long *out_gen_out, hipStream_t st)
+{
+    if (end_of_input || f->b_real_end >= 0 || !in.dev) return 0;
+    if (fabs(f->last_ratio - src_ratio_arg) > 1e-10) return 0;
+    const double src_ratio = f->last_ratio;
+    const double step = 1.0 / src_ratio;
+    const int S = (int)step;
+    if ((double)S != step || S < 1 || S > 256) return 0;
+    if (fmod_one(f->last_position) != 0.0 || f->last_position != 0.0) return 0;
+    double count = (f->coeff_half_len + 2.0) / f->index_inc;
+    const double minr = f->last_ratio < src_ratio_arg ? f->last_ratio : src_ratio_arg;
+    if (minr < 1.0) count /= minr;
+    const int half = (int)lrint(count) + 1;
+    const double float_increment = f->index_inc * (src_ratio < 1.0 ? src_ratio : 1.0);
+    const int inc = (int)lrint(float_increment * (double)(1 << SRC_SHIFT));
+    const double scale = float_increment / f->index_inc;
+    const int maxf = f->coeff_half_len << SRC_SHIFT;
+    const int cl = maxf / inc, cr = (maxf - inc) / inc;
+    if (!src_uniform_lds(64, S, cl, cr)) return 0;
+
+    // dry run of sinc_mono_vari_process / prepare_data
+    int b_current = f->b_current, b_end = f->b_end;
+    long A0 = 0, a_in0 = -1, in_used = 0, out_gen = 0, a_first = -1;
+    while (out_gen < out_count) {
+        int samples_in_hand = (b_end - b_current + f->b_len) % f->b_len;
+        if (samples_in_hand <= half) {
+            int len;
+            if (b_current == 0) {
+                len = f->b_len - 2 * half;
+                b_current = b_end = half;
+            } else if (b_end + half + 1 < f->b_len) {
+                len = f->b_len - b_current - half;
+                if (len < 0) len = 0;
+            } else {
+                len = b_end - b_current;
+                A0 += b_current - half;
+                b_current = half;
+                b_end = b_current + len;
+                len = f->b_len - b_current - half;
+                if (len < 0) len = 0;
+            }
+            const long avail = in_count - in_used;
+            if (avail < len) len = (int)avail;
+            if (len < 0 || b_end + len > f->b_len) return 0; // let the epoch path report the library's error
+            if (len > 0 && a_in0 < 0) a_in0 = A0 + b_end - in_used;
+            b_end += len;
+            in_used += len;
+            samples_in_hand = (b_end - b_current + f->b_len) % f->b_len;
+            if (samples_in_hand <= half) break;
+        }
+        if (a_first < 0) a_first = A0 + b_current;
+        else if (A0 + b_current != a_first + (long)S * out_gen) return 0; // cannot happen; be safe
+        ++out_gen;
+        b_current = (b_current + S) % f->b_len;
+    }
+    if (a_in0 < 0) a_in0 = A0 + b_end; // no input consumed: every index is served by the old image
+    int rc = prepare_uniform(f, inc);
+    if (rc) return rc;
+    const bool fast = f->mode == REDIO_SRC_FAST;
+    if (fast) { rc = prepare_fast_taps(f, S, scale); if (rc) return rc; }
+    // rebuild [b_current - half, b_end) of the final image into the other buffer
+    const int other = f->cur ^ 1;
+    long j0 = (long)b_current - half, j1 = b_end;
+    if (j0 < 0) j0 = 0;
+    hipError_t e = launch_src_window(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, f->d_cl, f->ncl, f->d_cr, f->ncr,
+                                     f->d_T2, f->nm, fast, a_first < 0 ? 0 : a_first, S, scale, d_out, out_stride, out_gen, f->nchan,
+                                     A0, j0, j1, f->d_buf[other], st);
+    if (e == hipErrorNotSupported) return 0;
+    if (e != hipSuccess) return hip_rc(e);
+    f->cur = other;
+    f->b_current = b_current;
+    f->b_end = b_end;
+    f->last_position = 0.0;
+    f->last_ratio = src_ratio;
+    if (in_used_out) *in_used_out = in_used;
+    if (out_gen_out) *out_gen_out = out_gen;
+    return 1;
+}
+
 // src_process + sinc_mono_vari_process; outputs land in d_out[nchan][out_stride]
 static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames, float *d_out, long out_stride, long output_frames,
                             double src_ratio_arg, int end_of_input, long *in_used_out, long *out_gen_out, hipStream_t st)
@@ -332,6 +454,12 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
     long in_used = 0, out_gen = 0;
     double src_ratio = f->last_ratio;
     if (is_bad_src_ratio(src_ratio)) return REDIO_SRC_ERR_BAD_INTERNAL_STATE;
+    if (f->window_ok) {
+        const int handled = try_uniform_window(f, in, in_count, d_out, out_stride, out_count, src_ratio_arg, end_of_input, in_used_out,
+                                               out_gen_out, st);
+        if (handled == 1) return REDIO_OK;
+        if (handled != 0) return handled;
+    }
     int rc = ensure_scratch(f, (size_t)out_count);
     if (rc) return rc;
     // the scratch upload of an earlier call on another stream must not be overwritten while in
@@ -430,6 +558,16 @@ extern "C" int redio_src_process_host(redio_src *s, const float *data_in, long i
         s->stage_out_cap = (size_t)output_frames + 1024;
     }
     SrcInput in = {data_in, nullptr, 0};
+    if (input_frames > 0) { // one upload of the whole message; the refills then copy on the device
+        if ((size_t)input_frames > s->stage_in_cap) {
+            hipFree(s->d_stage_in);
+            s->d_stage_in = nullptr; s->stage_in_cap = 0;
+            SRC_TRY(hipMalloc((void **)&s->d_stage_in, ((size_t)input_frames + 1024) * sizeof(float)));
+            s->stage_in_cap = (size_t)input_frames + 1024;
+        }
+        SRC_TRY(hipMemcpyAsync(s->d_stage_in, data_in, (size_t)input_frames * sizeof(float), hipMemcpyHostToDevice, nullptr));
+        in = {nullptr, s->d_stage_in, (long)s->stage_in_cap};
+    }
     long used = 0, gen = 0;
     int rc = src_process_impl(s, in, input_frames, s->d_stage_out, (long)s->stage_out_cap, output_frames, src_ratio, end_of_input,
                               &used, &gen, nullptr);

@@ -9,6 +9,10 @@ hipError_t launch_src_exact(const float *win, long win_stride, const float *coef
 hipError_t launch_src_uniform(const float *win, long win_stride, const double *cl_rev, int ncl, const double *cr_rev, int ncr,
                               int pos0, int S, double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s);
 size_t src_uniform_lds(int nt, int S, int cl, int cr);
+hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,
+                             const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, bool fast,
+                             long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,
+                             long A0f, long j0, long j1, float *new_img, hipStream_t s);
 hipError_t launch_src_copy_rows(const float *src, long src_stride, long src_off, float *dst, long dst_stride, long dst_off,
                                 long n, int nchan, hipStream_t s);
 hipError_t launch_src_fill_rows(float *dst, long dst_stride, long dst_off, long n, int nchan, float v, hipStream_t s);

@@ -78,6 +78,148 @@ hipError_t launch_src_exact(const float *win, long win_stride, const float *coef
     return hipGetLastError();
 }
 
+// ---- the stream window of a single-launch call: [old buffer image | new input] by absolute index
+struct SrcWindow {
+    const float *old_img; long old_stride; // [nchan][old_stride]
+    const float *input; long in_stride;    // [nchan][in_stride]
+    long a_in0;                            // first absolute index served by `input`
+};
+__device__ __forceinline__ float win_load(const SrcWindow &w, int ch, long a)
+{
+    return a < w.a_in0 ? w.old_img[(long)ch * w.old_stride + a] : w.input[(long)ch * w.in_stride + (a - w.a_in0)];
+}
+
+// Stage a tile of the stream window into LDS: sample n of the tile goes to xs[n + P*(n / B)] (P pad
+// floats after every B samples, P == 0: plain).  U independent loads per thread are issued before any of
+// them is stored, the source select (old image / new input) is a pointer select so the loads carry no
+// branch, and samples at or past `need` (they belong to no valid output and may not exist) read a
+// clamped address and store zero.
+template <int NT, int U>
+__device__ __forceinline__ void src_tile_load(float *xs, const SrcWindow &w, int ch, long tile_base, int span, int need, int B, int P)
+{
+    const int tid = threadIdx.x;
+    const float *old_row = w.old_img + (long)ch * w.old_stride;
+    const float *in_row = w.input + (long)ch * w.in_stride - w.a_in0;
+    int q = P ? tid / B : 0, r = P ? tid - q * B : 0; // n = q*B + r for this thread's next sample
+    const int dq = NT / B, dr = NT - dq * B;
+    for (int n0 = tid; n0 < span; n0 += NT * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int n = n0 + u * NT;
+            n = n < need ? n : need - 1;
+            const long a = tile_base + n;
+            const float *p = a < w.a_in0 ? old_row + a : in_row + a;
+            v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + u * NT;
+            if (n < span) xs[n + P * q] = n < need ? v[u] : 0.0f;
+            if (P) { q += dq; r += dr; if (r >= B) { r -= B; ++q; } }
+        }
+    }
+}
+
+// The two wings of one output at zero phase: left = sum_t L[t]*x[t], right = sum_t R[t]*x[c-t], each a
+// strictly ordered double sum (far end first, multiply and add rounded separately) exactly as
+// calc_output_single runs them.  The wings are independent chains, so they run side by side, U taps
+// per step; the LDS reads and scalar coefficient loads of step i+1 are issued before the arithmetic of
+// step i (software pipeline: one lgkmcnt(0) per step with a full step of arithmetic to hide it).
+// At zero phase R[t] == L[t] bit for bit for t <= cr when cr == cl - 1 (the right wing starts one
+// increment in; prepare_uniform builds both from the same expression), so the shared part walks ONE
+// coefficient stream and the double-buffered taps fit the SGPR file.
+struct WingCursor { int lrem, lquo, rrem, rquo; };
+
+template <int U, bool PAD>
+__device__ __forceinline__ void wings_fetch(const float *xs, int lbase, int c, int S, const double *__restrict__ tab, int t,
+                                            WingCursor &w, float (&xl)[U], float (&xr)[U], double (&k)[U])
+{
+    if (!PAD) { // plain layout: one base address per wing, the U reads differ by immediate offsets
+        const float *pl = xs + lbase + t, *pr = xs + lbase + (c - t - (U - 1));
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            xl[j] = pl[j];
+            xr[j] = pr[U - 1 - j];
+            k[j] = tab[t + j];
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        xl[j] = xs[lbase + t + j + w.lquo];
+        xr[j] = xs[lbase + (c - t - j) + w.rquo];
+        k[j] = tab[t + j];
+        if (++w.lrem == S) { w.lrem = 0; ++w.lquo; }
+        if (--w.rrem < 0) { w.rrem += S; --w.rquo; }
+    }
+}
+
+// one pad float per S samples only when the lane stride S would put 8 or more lanes on a bank
+// (S % 8 == 0); a 2- or 4-way ds_read_b32 conflict costs less than the f64 arithmetic it feeds
+__host__ __device__ __forceinline__ int src_tile_pad(int S) { return (S % 8 == 0) ? 1 : 0; }
+
+template <int U, bool PAD>
+__device__ __forceinline__ void sinc_wings(const float *xs, int lbase, int S, const double *__restrict__ cl_rev,
+                                           const double *__restrict__ cr_rev, int cl, int cr, double &left, double &right)
+{
+    constexpr int pad = PAD ? 1 : 0;
+    const int c = cl + 1 + cr;
+    WingCursor w;
+    w.lrem = 0; w.lquo = 0;                  // left data index  t      = lquo*S + lrem
+    w.rquo = c / S; w.rrem = c - w.rquo * S; // right data index c - t  = rquo*S + rrem
+    const int both = cl < cr ? cl : cr;
+    int t = 0;
+    if (cr == cl - 1) {
+        const int nsteps = (both + 1) / U;
+        float xl[U], xr[U];
+        double k[U];
+        if (nsteps > 0) wings_fetch<U, PAD>(xs, lbase, c, S, cl_rev, 0, w, xl, xr, k);
+#pragma unroll
+        for (int j = 0; j < U; ++j) { // land the first fetch before the loop so the loop header carries no pending load
+            asm volatile("" : "+v"(xl[j]), "+v"(xr[j]));
+            asm volatile("" : "+s"(k[j]));
+        }
+        for (int i = 0; i < nsteps; ++i) {
+            float nxl[U], nxr[U];
+            double nk[U];
+            if (i + 1 < nsteps) wings_fetch<U, PAD>(xs, lbase, c, S, cl_rev, (i + 1) * U, w, nxl, nxr, nk);
+            RD_SCHED_BARRIER();
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                left += k[j] * (double)xl[j];
+                right += k[j] * (double)xr[j];
+            }
+            RD_SCHED_BARRIER();
+            // land the prefetch here (the one lgkmcnt(0) of the step), not after the next issue
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                asm volatile("" : "+v"(nxl[j]), "+v"(nxr[j]));
+                asm volatile("" : "+s"(nk[j]));
+                xl[j] = nxl[j]; xr[j] = nxr[j]; k[j] = nk[j];
+            }
+        }
+        t = nsteps * U;
+    }
+    const double *__restrict__ kr_tab = (cr == cl - 1) ? cl_rev : cr_rev;
+    for (; t <= both; ++t) {
+        const float xl = xs[lbase + t + (pad ? w.lquo : 0)];
+        const float xr = xs[lbase + (c - t) + (pad ? w.rquo : 0)];
+        left += cl_rev[t] * (double)xl;
+        right += kr_tab[t] * (double)xr;
+        if (++w.lrem == S) { w.lrem = 0; ++w.lquo; }
+        if (--w.rrem < 0) { w.rrem += S; --w.rquo; }
+    }
+    for (; t <= cl; ++t) {
+        left += cl_rev[t] * (double)xs[lbase + t + (pad ? w.lquo : 0)];
+        if (++w.lrem == S) { w.lrem = 0; ++w.lquo; }
+    }
+    for (; t <= cr; ++t) {
+        right += cr_rev[t] * (double)xs[lbase + (c - t) + (pad ? w.rquo : 0)];
+        if (--w.rrem < 0) { w.rrem += S; --w.rquo; }
+    }
+}
+
 // ---- uniform-phase fast path -------------------------------------------------------------------
 // When 1/ratio is an integer S and the phase is zero (decimation by S, or ratio 1), every output of an
 // epoch has start_filter_index 0 and the same increment, so the interpolated coefficients are the same
@@ -99,42 +241,23 @@ __global__ __launch_bounds__(NT) void src_sinc_uniform_kernel(const float *__res
     float *xs = reinterpret_cast<float *>(smem);
     const int tid = threadIdx.x;
     const long k0 = (long)blockIdx.x * NT;
-    const float *x = win + (long)blockIdx.y * win_stride;
-    const int pad = (S & 1) ? 0 : 1;
+    const int pad = src_tile_pad(S);
     const int cl = ncl - 1, cr = ncr - 1;
     const long tile_base = (long)pos0 + (long)S * k0 - cl; // buffer index of tile-relative sample 0
     const int span = (NT - 1) * S + cl + cr + 2;
     // the last tile may reach past the outputs that exist: clamp the load to what the valid outputs need
     const long nvalid = (nout - k0 < NT) ? nout - k0 : NT;
     const int need = (int)((nvalid - 1) * S) + cl + cr + 2;
-    for (int n = tid; n < span; n += NT) xs[n + (pad ? n / S : 0)] = (n < need) ? x[tile_base + n] : 0.0f;
+    {
+        const SrcWindow w = {win, win_stride, win, win_stride, 1L << 40}; // everything is 'old image': the live buffer
+        src_tile_load<NT, 8>(xs, w, blockIdx.y, tile_base, span, need, S, pad);
+    }
     __syncthreads();
     if (k0 + tid >= nout) return;
     const int lbase = (S + pad) * tid;
-    // the two wings are independent sums, each strictly ordered (far end first): run them side by side
-    // so that two dependent double-precision chains are in flight per lane
     double left = 0.0, right = 0.0;
-    const int c = cl + 1 + cr;
-    int lrem = 0, lquo = 0;                  // left data index  t      = lquo*S + lrem
-    int rquo = c / S, rrem = c - rquo * S;   // right data index c - t  = rquo*S + rrem
-    const int both = cl < cr ? cl : cr;      // cl == cr or cl == cr + 1
-    int t = 0;
-    for (; t <= both; ++t) {
-        const float xl = xs[lbase + t + (pad ? lquo : 0)];
-        const float xr = xs[lbase + (c - t) + (pad ? rquo : 0)];
-        left += cl_rev[t] * (double)xl;
-        right += cr_rev[t] * (double)xr;
-        if (++lrem == S) { lrem = 0; ++lquo; }
-        if (--rrem < 0) { rrem += S; --rquo; }
-    }
-    for (; t <= cl; ++t) {
-        left += cl_rev[t] * (double)xs[lbase + t + (pad ? lquo : 0)];
-        if (++lrem == S) { lrem = 0; ++lquo; }
-    }
-    for (; t <= cr; ++t) {
-        right += cr_rev[t] * (double)xs[lbase + (c - t) + (pad ? rquo : 0)];
-        if (--rrem < 0) { rrem += S; --rquo; }
-    }
+    if (pad) sinc_wings<8, true>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
+    else sinc_wings<8, false>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
     out[(long)blockIdx.y * out_stride + k0 + tid] = (float)(scale * (left + right));
 }
 
@@ -179,6 +302,181 @@ hipError_t launch_src_uniform(const float *win, long win_stride, const double *c
             }
         }
     return hipErrorNotSupported;
+}
+
+// ---- single-launch uniform-phase path ------------------------------------------------------------
+// The whole call as ONE launch: the stream window is [old buffer image | new input] addressed by an
+// absolute index a (a < a_in0 -> old image, else input), output k sits at a0 + S*k.  Same arithmetic
+// as src_sinc_uniform_kernel (bit-identical), no per-refill launches.
+template <int NT>
+__global__ __launch_bounds__(NT) void src_window_exact_kernel(SrcWindow w, const double *__restrict__ cl_rev, int ncl,
+                                                              const double *__restrict__ cr_rev, int ncr, long a0, int S, double scale,
+                                                              float *__restrict__ out, long out_stride, long nout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const long k0 = (long)blockIdx.x * NT;
+    const int pad = src_tile_pad(S);
+    const int cl = ncl - 1, cr = ncr - 1;
+    const long tile_base = a0 + (long)S * k0 - cl;
+    const int span = (NT - 1) * S + cl + cr + 2;
+    const long nvalid = (nout - k0 < NT) ? nout - k0 : NT;
+    const int need = (int)((nvalid - 1) * S) + cl + cr + 2;
+    src_tile_load<NT, 8>(xs, w, ch, tile_base, span, need, S, pad);
+    __syncthreads();
+    if (k0 + tid >= nout) return;
+    const int lbase = (S + pad) * tid;
+    double left = 0.0, right = 0.0;
+    if (pad) sinc_wings<8, true>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
+    else sinc_wings<8, false>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
+    out[(long)ch * out_stride + k0 + tid] = (float)(scale * (left + right));
+}
+
+typedef float src_v2f __attribute__((ext_vector_type(2))); // one 64-bit register pair (v_pk_fma_f32 operand)
+
+// ---- f32 polyphase decimator (REDIO_SRC_FAST): the same uniform-phase filter as ONE real FIR
+// H[j] = (float)(scale * icoeff_j), j = 0 .. KH-1 (left wing far end first, then the right wing near
+// end first), evaluated with f32 FMAs.  A lane owns two consecutive outputs (2l, 2l+1) that share every
+// LDS read: acc.xy += (x, x) * (H[m], H[m-S]) -- one v_pk_fma_f32 per sample with the tap pair as a
+// wave-uniform SGPR operand from the packed table T2[m] = (H[m], H[m-S]), m = 0 .. nm-1 (nm = KH + S
+// rounded up to a multiple of 128, zero filled).  The eight waves of a workgroup split the tap range
+// (K-split) over one shared 128-output tile and are summed in wave order.  Eight taps per step, the
+// next step's LDS reads and scalar loads in flight under the current step's FMAs.
+// LDS layout: lane stride 2S floats; ds_read_b64 is conflict-free when (stride/2) is odd, so an even S
+// gets two pad floats per 2S samples (PAD), an odd S none.
+// Tolerance vs the exact path: |d| <= (KH + 1) * 2^-24 * sum|H| * max|x| (tested).
+enum { SRC_FAST_WAVES = 8, SRC_FAST_STEP = 8 }; // K-split width and taps per pipeline step; nm % (WAVES*STEP) == 0
+
+template <bool PAD>
+__global__ __launch_bounds__(64 * SRC_FAST_WAVES) void src_window_fast_kernel(SrcWindow w, const float2 *__restrict__ T2, int nm, int KH,
+                                                                              int cl, long a0, int S, float *__restrict__ out,
+                                                                              long out_stride, long nout)
+{
+    constexpr int NW = SRC_FAST_WAVES, ST = SRC_FAST_STEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const long k0 = (long)blockIdx.x * 128;
+    const long tile_base = a0 + (long)S * k0 - cl;
+    const int S2 = 2 * S;
+    const int span = 126 * S + nm;
+    const long nvalid = (nout - k0 < 128) ? nout - k0 : 128;
+    const int need = (int)((nvalid - 1) * S) + KH; // samples past this belong to no valid output (and may not exist)
+    src_tile_load<64 * NW, 8>(xs, w, ch, tile_base, span, need, S2, PAD ? 2 : 0);
+    float2 *red = reinterpret_cast<float2 *>(xs + ((span + (PAD ? 2 * (span / S2) : 0) + 5) & ~1)); // [NW][64] partial sums
+    __syncthreads();
+    const int per = nm / NW; // multiple of ST
+    const int m0 = wave * per, nsteps = per / ST;
+    const int lbase = (S2 + (PAD ? 2 : 0)) * lane;
+    int quo = PAD ? m0 / S2 : 0, rem = PAD ? m0 - quo * S2 : 0;
+    src_v2f acc = {0.f, 0.f};
+    src_v2f x[ST / 2], t[ST];
+    auto fetch = [&](int m, src_v2f(&fx)[ST / 2], src_v2f(&ft)[ST]) {
+#pragma unroll
+        for (int h = 0; h < ST / 4; ++h) { // four samples never straddle a pad (S2 % 4 == 0 when PAD)
+            const float *p = xs + lbase + m + 4 * h + 2 * quo;
+            fx[2 * h] = *reinterpret_cast<const src_v2f *>(p);
+            fx[2 * h + 1] = *reinterpret_cast<const src_v2f *>(p + 2);
+            if (PAD) { rem += 4; if (rem >= S2) { rem -= S2; ++quo; } }
+        }
+#pragma unroll
+        for (int j = 0; j < ST; ++j) { const float2 v = T2[m + j]; ft[j] = src_v2f{v.x, v.y}; }
+    };
+    if (nsteps > 0) fetch(m0, x, t);
+#pragma unroll
+    for (int j = 0; j < ST / 2; ++j) asm volatile("" : "+v"(x[j]));
+#pragma unroll
+    for (int j = 0; j < ST; ++j) asm volatile("" : "+s"(t[j]));
+    for (int i = 0; i < nsteps; ++i) {
+        src_v2f nx[ST / 2], nt[ST];
+        if (i + 1 < nsteps) fetch(m0 + ST * (i + 1), nx, nt);
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int j = 0; j < ST / 2; ++j) {
+            acc = __builtin_elementwise_fma(src_v2f{x[j].x, x[j].x}, t[2 * j], acc);
+            acc = __builtin_elementwise_fma(src_v2f{x[j].y, x[j].y}, t[2 * j + 1], acc);
+        }
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int j = 0; j < ST / 2; ++j) { asm volatile("" : "+v"(nx[j])); x[j] = nx[j]; }
+#pragma unroll
+        for (int j = 0; j < ST; ++j) { asm volatile("" : "+s"(nt[j])); t[j] = nt[j]; }
+    }
+    red[wave * 64 + lane] = make_float2(acc.x, acc.y);
+    __syncthreads();
+    if (wave == 0) {
+        float2 s = red[lane];
+        for (int q = 1; q < NW; ++q) { s.x = add_rn(s.x, red[q * 64 + lane].x); s.y = add_rn(s.y, red[q * 64 + lane].y); }
+        const long k = k0 + 2 * lane;
+        if (k < nout) out[(long)ch * out_stride + k] = s.x;
+        if (k + 1 < nout) out[(long)ch * out_stride + k + 1] = s.y;
+    }
+}
+
+// rebuild the library's buffer image after a single-launch call: dst[j] = window(A0 + j), j in [j0, j1)
+__global__ __launch_bounds__(256) void src_window_image_kernel(SrcWindow w, long A0, long j0, long j1, float *__restrict__ dst, long dst_stride)
+{
+    const long j = j0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < j1) dst[(long)blockIdx.y * dst_stride + j] = win_load(w, blockIdx.y, A0 + j);
+}
+
+hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,
+                             const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, bool fast,
+                             long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,
+                             long A0f, long j0, long j1, float *new_img, hipStream_t s)
+{
+    SrcWindow w = {old_img, old_stride, input, in_stride, a_in0};
+    const int cl = ncl - 1, cr = ncr - 1;
+    if (nout > 0) {
+        if (fast) {
+            const int KH = ncl + ncr;
+            const bool padded = (S % 2) == 0;
+            const long span = 126L * S + nm;
+            const size_t lds = (size_t)(span + (padded ? 2 * (span / (2 * S)) : 0) + 8) * sizeof(float) + SRC_FAST_WAVES * 64 * sizeof(float2);
+            if (lds > 150 * 1024 || nm % (SRC_FAST_WAVES * SRC_FAST_STEP) != 0) return hipErrorNotSupported;
+            dim3 grid((unsigned)((nout + 127) / 128), (unsigned)nchan);
+#define LAUNCH_F(P)                                                                                                               \
+    {                                                                                                                             \
+        auto kern = src_window_fast_kernel<P>;                                                                                    \
+        if (lds > 48 * 1024) {                                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                        \
+        }                                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * SRC_FAST_WAVES), lds, s, w, T2, nm, KH, cl, a0, S, out, out_stride, nout);                       \
+    }
+            if (padded) LAUNCH_F(true) else LAUNCH_F(false)
+#undef LAUNCH_F
+        } else {
+            const int cand[3] = {256, 128, 64};
+            bool done = false;
+            for (int pass = 0; pass < 2 && !done; ++pass)
+                for (int i = 0; i < 3 && !done; ++i) {
+                    const size_t b = src_uniform_lds(cand[i], S, cl, cr);
+                    if (!b || (pass == 0 && b > 78 * 1024)) continue;
+                    dim3 grid((unsigned)((nout + cand[i] - 1) / cand[i]), (unsigned)nchan);
+#define LAUNCH_W(NT)                                                                                                              \
+    {                                                                                                                             \
+        auto kern = src_window_exact_kernel<NT>;                                                                                  \
+        if (b > 48 * 1024) {                                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b); \
+            if (e != hipSuccess) return e;                                                                                        \
+        }                                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), b, s, w, cl_rev, ncl, cr_rev, ncr, a0, S, scale, out, out_stride, nout);         \
+    }
+                    if (cand[i] == 256) LAUNCH_W(256) else if (cand[i] == 128) LAUNCH_W(128) else LAUNCH_W(64)
+#undef LAUNCH_W
+                    done = true;
+                }
+            if (!done) return hipErrorNotSupported;
+        }
+    }
+    if (j1 > j0) {
+        dim3 grid((unsigned)((j1 - j0 + 255) / 256), (unsigned)nchan);
+        hipLaunchKernelGGL(src_window_image_kernel, grid, dim3(256), 0, s, w, A0f, j0, j1, new_img, old_stride);
+    }
+    return hipGetLastError();
 }
 
 // window maintenance: dst[c][0..keep) = src[c][from..from+keep) (overlapping allowed: goes through

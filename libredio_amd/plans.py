@@ -130,10 +130,19 @@ class Src:
     """redio_src_*: nchan independent mono streams through the libsamplerate-style sinc converter
     (samplerate.rs:59-87 semantics per stream), device-resident rows [nchan][frames]."""
 
-    def __init__(self, nchan, converter=1):
+    EXACT, FAST, EPOCHS = 0, 1, 2
+
+    def __init__(self, nchan, converter=1, mode=0):
         self.nchan = int(nchan)
         self._h = C.c_void_p()
         check(lib().redio_src_create(C.byref(self._h), int(converter), self.nchan), "src_create")
+        if mode:
+            self.set_mode(mode)
+
+    def set_mode(self, mode):
+        """EXACT (bit-identical, default) / FAST (f32 polyphase for uniform-phase calls) / EPOCHS
+        (EXACT, one launch per buffer refill)."""
+        check(lib().redio_src_set_mode(self._h, int(mode)), "src_set_mode")
 
     def process(self, x, ratio, output_frames=None, end_of_input=False):
         """x: float32 CUDA tensor [nchan, frames]. Returns (out[nchan, gen], input_frames_used)."""

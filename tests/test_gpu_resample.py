@@ -141,3 +141,74 @@ def test_tone_in_tone_out_and_dc_gain(gpu, redio, oracle):
     assert np.abs(y[200:] - ref[200:]).max() < 2e-5     # zero-phase, unity gain in the pass band
     dc = samplerate.State().block(np.ones(400000, np.float32), 0.02)
     assert np.abs(dc[200:] - 1.0).max() < 2e-5
+
+
+SEGS = ((0, 25000), (25000, 25001), (25001, 60000), (60000, 60000), (60000, 200000))
+
+
+@pytest.mark.parametrize("ratio,conv", [(0.02, 1), (0.5, 1), (1.0, 1), (1 / 256, 2), (0.1, 0), (0.25, 2)])
+def test_single_launch_uniform_path_is_the_epoch_schedule(gpu, redio, oracle, ratio, conv):
+    # the one-launch form (default) against the literal one-launch-per-refill schedule and the oracle:
+    # same counts, same bits, same carried state across messages of awkward lengths
+    nch, n = 3, 200000
+    x = np.stack([oracle.synth_f32(300 + c, 0, n) for c in range(nch)])
+    d = gpu.from_numpy(x).cuda()
+    one, lit = redio.Src(nch, conv), redio.Src(nch, conv, mode=redio.Src.EPOCHS)
+    refs = [oracle.Resampler(conv) for _ in range(nch)]
+    for lo, hi in SEGS:
+        a, ua = one.process(d[:, lo:hi].contiguous(), ratio)
+        b, ub = lit.process(d[:, lo:hi].contiguous(), ratio)
+        assert ua == ub and a.shape == b.shape
+        a = a.cpu().numpy()
+        assert np.array_equal(bits(a), bits(b.cpu().numpy())), (lo, hi)
+        for c in range(nch):
+            err, want, wused = refs[c].process(x[c, lo:hi], ratio, int(ratio * (hi - lo) + 1.0))
+            assert err == 0 and wused == ua       # the library may leave input unread when the output side fills first
+            assert np.array_equal(bits(a[c]), bits(want)), (c, lo, hi)
+
+
+def test_single_launch_then_flush_and_ratio_change(gpu, redio, oracle):
+    # a uniform message, then a varying-ratio one, then end_of_input: the image rebuilt by the
+    # one-launch form must be exactly what the per-refill schedule would have left behind
+    n = 90000
+    x = oracle.synth_f32(77, 0, n)
+    d = gpu.from_numpy(x[None, :]).cuda()
+    plan, ref = redio.Src(1, 1), oracle.Resampler(1)
+    steps = [(0, 40000, 0.05, 0), (40000, 70000, 0.07, 0), (70000, 90000, 0.07, 1)]
+    for lo, hi, r, eoi in steps:
+        cap = int(r * (hi - lo) + 1.0) + 400
+        got, used = plan.process(d[:, lo:hi].contiguous(), r, output_frames=cap, end_of_input=bool(eoi))
+        err, want, wused = ref.process(x[lo:hi], r, cap, bool(eoi))
+        assert err == 0 and used == wused and got.shape[1] == len(want)
+        assert np.array_equal(bits(got.cpu().numpy()[0]), bits(want)), (lo, hi, r)
+
+
+def test_fast_mode_error_bound_and_state(gpu, redio, oracle):
+    # FAST: f32 polyphase taps and accumulation for uniform-phase calls.  Tolerance: each of the
+    # K = cl+cr+2 products carries one f32 tap rounding and the f32 sum at most K roundings:
+    # |err| <= (K + 1) * 2^-24 * sum|h| * max|x| (loose first-order bound), checked against EXACT.
+    nch, n, ratio = 4, 400000, 0.02
+    x = np.stack([oracle.synth_f32(500 + c, 0, n) for c in range(nch)])
+    d = gpu.from_numpy(x).cuda()
+    exact, fast = redio.Src(nch, 1), redio.Src(nch, 1, mode=redio.Src.FAST)
+    tab, half, inc = oracle.src_table(1)
+    pos = np.arange(0.0, half, inc * ratio)                       # filter positions one wing visits
+    K = 2 * len(pos)
+    sum_h = 2 * ratio * np.abs(np.interp(pos, np.arange(half + 2), tab.astype(np.float64))).sum()
+    bound = (K + 1) * 2.0 ** -24 * max(sum_h, 1.0) * np.abs(x).max()
+    for lo, hi in ((0, 150000), (150000, 150003), (150003, 400000)):
+        a, ua = exact.process(d[:, lo:hi].contiguous(), ratio)
+        b, ub = fast.process(d[:, lo:hi].contiguous(), ratio)
+        assert ua == ub and a.shape == b.shape
+        if a.numel() == 0:
+            continue
+        err = (a - b).abs().max().item()
+        assert err <= bound, (err, bound)
+        assert err < 2e-5
+    # the state FAST leaves behind is input samples only: switching back to EXACT continues bit-exactly
+    fast.set_mode(redio.Src.EXACT)
+    y = np.stack([oracle.synth_f32(900 + c, 0, 50000) for c in range(nch)])
+    dy = gpu.from_numpy(y).cuda()
+    a, _ = exact.process(dy, ratio)
+    b, _ = fast.process(dy, ratio)
+    assert np.array_equal(bits(a.cpu().numpy()), bits(b.cpu().numpy()))
