@@ -131,6 +131,101 @@ static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw,
     return hipGetLastError();
 }
 
+// ---- overlap-save at N = 65536 in three passes instead of six ------------------------------------
+// forward pass 1, the spectrum product and inverse pass 0 touch the same 256 x 16 tile (column k0 of the
+// forward output IS the stride-256 leaf set of the inverse transform: f64k_p1_pos == f64k_p0_src), so
+// they run back to back in LDS; inverse pass 1 scales and writes only the `hop` valid outputs.  Same
+// butterflies, same C_MUL, same scale as transform -> multiply -> transform -> copy: bit-identical.
+__global__ __launch_bounds__(256) void ovsave64k_mid_kernel(const float2 *__restrict__ a, float2 *__restrict__ b,
+                                                            const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
+                                                            const float2 *__restrict__ Hc)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const long xf = blockIdx.x >> 4;
+    const int c = blockIdx.x & 15;
+    const float2 *src = a + xf * F64K_N;
+    float2 *dst = b + xf * F64K_N;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, row = e >> 4, col = e & 15;
+        L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
+    }
+    __syncthreads();
+    const int col = tid & 15;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) { // forward stages m = 256 .. 16384
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<false>(L, tw_f, 1, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+        __syncthreads();
+    }
+    float2 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
+        v[it] = cmul_rn(L[row * F64K_LD + cc], Hc[f64k_p1_pos(c, row, cc)]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) { // the inverse transform's leaf order along the row index
+        const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
+        L[rev4_of_8bit(row) * F64K_LD + cc] = v[it];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) { // inverse stages m = 1 .. 64
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<true>(L, tw_i, 0, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+        __syncthreads();
+    }
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) dst[f64k_p0_dst(c, tid, it)] = L[tid * F64K_LD + it];
+}
+
+__global__ __launch_bounds__(256) void ovsave64k_last_kernel(const float2 *__restrict__ b, float2 *__restrict__ out,
+                                                             const float2 *__restrict__ tw_i, long hop, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const long xf = blockIdx.x >> 4;
+    const int c = blockIdx.x & 15;
+    const float2 *src = b + xf * F64K_N;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, row = e >> 4, col = e & 15;
+        L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
+    }
+    __syncthreads();
+    const int col = tid & 15;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<true>(L, tw_i, 1, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+        __syncthreads();
+    }
+    float2 *dst = out + xf * hop;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
+        const int pos = f64k_p1_pos(c, row, cc);
+        const float2 y = L[row * F64K_LD + cc];
+        if (pos < hop) dst[pos] = make_float2(mul_rn(y.x, scale), mul_rn(y.y, scale));
+    }
+}
+
+hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
+                            float2 *out, long nblk, float scale, hipStream_t s)
+{
+    const size_t lds = 256 * F64K_LD * sizeof(float2);
+    const unsigned grid = (unsigned)(nblk * 16);
+    hipLaunchKernelGGL((fft64k_pass_kernel<false, 0>), dim3(grid), dim3(256), lds, s, x, a, tw_f, hop);
+    hipLaunchKernelGGL(ovsave64k_mid_kernel, dim3(grid), dim3(256), lds, s, a, b, tw_f, tw_i, Hc);
+    hipLaunchKernelGGL(ovsave64k_last_kernel, dim3(grid), dim3(256), lds, s, b, out, tw_i, hop, scale);
+    return hipGetLastError();
+}
+
 hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride)
 {
     if (in_stride <= 0) in_stride = p.nfft; // consecutive messages; smaller strides give overlapping blocks (overlap-save)

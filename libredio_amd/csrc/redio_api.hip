@@ -283,6 +283,8 @@ extern "C" int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d
     return hip_rc(e);
 }
 
+const float2 *redio_fft_twiddles_dev(const redio_fft *h) { return h ? h->dev.tw : nullptr; }
+
 // ---------------------------------------------------------------- chain plan
 struct redio_chain {
     redio_fir *fir;

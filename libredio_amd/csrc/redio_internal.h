@@ -25,6 +25,10 @@ struct FftPlanDev {
 // by the global-memory path
 hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0);
 
+// overlap-save at nfft 65536: x (block b at x + b*hop) -> out (hop valid samples per block), work buffers a, b
+hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
+                            float2 *out, long nblk, float scale, hipStream_t s);
+
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
@@ -35,3 +39,7 @@ hipError_t launch_synth_iq(float2 *out, uint32_t seed, uint64_t first, long n, h
 hipError_t launch_synth_f32(float *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
 
 } // namespace redio
+
+// redio_api.hip: the device twiddle table behind a public FFT handle (library-internal)
+struct redio_fft;
+const float2 *redio_fft_twiddles_dev(const redio_fft *h);

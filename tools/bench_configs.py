@@ -57,3 +57,20 @@ if "c3" in which:
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         b = nch * frames * 4 * (1 + 0.02)
         print(f"C3 resample 1/50 x{nch} ch, {frames} frames each ({name}): {best*1e3:.2f} ms  {nch*frames/best/1e9:.2f} GS/s  {b/best/1e9:.0f} GB/s algorithmic ({b/best/8e12:.1%} of 8 TB/s)")
+if "c5" in which:
+    for k in (8193, 127):
+        taps = R.dsputils.lpf_corrected(k, 0.08)
+        x = R.synth_iq(0x5EED0005, 0, n)
+        plan = R.OverlapSave(taps, 65536)
+        out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan(x, out=out), n=10, warm=3)
+        hop = 65536 - k + 1
+        b = 8 * 65536 / hop + 8
+        print(f"C5 overlap-save N=65536 K={k}: {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  {b*out.numel()/ms/1e6:.0f} GB/s algorithmic ({b*out.numel()/ms/1e6/8000:.1%})")
+if "hipfft" in which:
+    # same-hardware yardstick: the vendor FFT through torch.fft, same sizes, same batch
+    for nfft in (1024, 64, 4096, 65536):
+        x = R.synth_iq(2, 0, n if nfft != 65536 else 1 << 24).view(-1, nfft)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: torch.fft.fft(x, dim=1, out=out), n=20, warm=3)
+        print(f"vendor FFT (torch.fft -> hipFFT) {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  ({16*x.numel()/ms/1e6/8000:.1%} of 8 TB/s)")
