@@ -167,14 +167,16 @@ def main():
         if a.traffic_json and os.path.exists(a.traffic_json) and a.variant == 0 and not a.unfused and a.log2_samples == 28:
             traffic = json.load(open(a.traffic_json)).get("traffic")
         rec = {
-            "metric": "MSamples/s through FIR+FFT chain (127-tap FIR decimate-by-5 -> 1024-pt FFT, cf32 IQ)",
+            "metric": "MSamples/s through FIR+FFT+resample chain",
             "value": world * used * a.steps / dt / 1e6,
             "unit": "MSamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: single f32 IQ stream, 1024-pt FFT + 127-tap FIR decimate-by-5",
+            "config": {"workload": "BASELINE.json configs[1]: single f32 IQ stream, 1024-pt kissfft + 127-tap FIR decimate-by-5, 1 MI355X "
+                                   "(input samples/s; the 5:1 resample step is the polyphase decimation of the FIR: only every "
+                                   "fifth FIR output is computed, then consecutive 1024-sample blocks are transformed)",
                        "samples_per_gpu": n, "ntaps": NTAPS, "decim": DECIM, "nfft": NFFT,
                        "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else {0: "chain_v4_kernel (fused, wave per block run, halo carried in LDS)", 1: "chain_fir_fft1k_kernel (fused, v1)", 2: "chain_v2_kernel (fused, v2)", 6: "chain_v3_kernel (fused, v3)", 7: "chain_v5_kernel (fused, dynamic queue)"}.get(a.variant, f"fused kernel tuning {a.variant}"),
                        "fir_rounding": "mul+add (reference)" if a.exact else "fmaf, reference order",

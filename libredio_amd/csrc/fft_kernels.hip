@@ -24,6 +24,201 @@ __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float
     fft1k_wave<INV>(in + b * in_stride, out + b * 1024, ex, tw, lane);
 }
 
+// ---- N = 4096 = 4 x 1024: one workgroup per transform -------------------------------------------
+// The outermost kissfft stage (radix 4, m = 1024, fstride 1) combines four 1024-point transforms of
+// the decimated inputs x[4 i + j]; their twiddles are every fourth entry of the 4096 table, which the
+// library computes to the same doubles ((-2 pi * 4 i) / 4096 == (-2 pi * i) / 1024: exact scalings),
+// so each wavefront runs the one-wave 1024-point transform of fft_wave.h on its own block and the
+// workgroup finishes with the 1024 outer butterflies.  Coalesced load -> de-interleaved LDS regions
+// (region stride 1096 float2 = 8 mod 32 bank pairs: the four interleaved streams land on disjoint
+// banks) -> per-wave transform in place in its region -> barrier -> outer stage -> coalesced store.
+constexpr int FFT4K_REGION = 1096; // float2; >= FFT1K_LDS
+struct TwEvery4 {
+    const float2 *p;
+    __device__ __forceinline__ float2 operator[](int i) const { return p[4 * i]; }
+};
+
+template <bool INV>
+__global__ __launch_bounds__(256) void fft4k_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+{
+    static_assert(FFT4K_REGION >= FFT1K_LDS, "a region doubles as the wave's exchange image");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *src = in + (long)blockIdx.x * in_stride;
+    float2 *dst = out + (long)blockIdx.x * 4096;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int n = tid + 256 * it;
+        L[(n & 3) * FFT4K_REGION + (n >> 2)] = src[n];
+    }
+    __syncthreads();
+    float2 *mine = L + wave * FFT4K_REGION;
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
+    const TwEvery4 tw1k = {tw};
+    Fft1kTw t;
+    fft1k_load_tw(t, lane, tw1k);
+    fft1k_wave_regs<INV>(v, mine, mine, tw1k, t, lane);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        float2 a0 = L[k], a1 = L[FFT4K_REGION + k], a2 = L[2 * FFT4K_REGION + k], a3 = L[3 * FFT4K_REGION + k];
+        bfly4<INV>(a0, a1, a2, a3, tw[k], tw[2 * k], tw[3 * k]);
+        dst[k] = a0; dst[k + 1024] = a1; dst[k + 2048] = a2; dst[k + 3072] = a3;
+    }
+}
+
+// ---- N = 16384 = 16 x 1024: one 1024-thread workgroup per transform --------------------------------
+// Two outer kissfft stages (m = 1024 with fstride 4, m = 4096 with fstride 1) over sixteen 1024-point
+// transforms of x[r + 16 i]; leaf block g = 4 j0 + j1 holds the stream r = j0 + 4 j1.  Sixteen waves,
+// one block each (region stride 1090 float2 = 2 mod 32 bank pairs for the de-interleaving store), then
+// every thread finishes one column k of the 16 x 1024 array in registers.
+constexpr int FFT16K_REGION = 1090;
+struct TwEvery16 {
+    const float2 *p;
+    __device__ __forceinline__ float2 operator[](int i) const { return p[16 * i]; }
+};
+
+template <bool INV>
+__global__ __launch_bounds__(1024) void fft16k_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+{
+    static_assert(FFT16K_REGION >= FFT1K_LDS, "a region doubles as the wave's exchange image");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *src = in + (long)blockIdx.x * in_stride;
+    float2 *dst = out + (long)blockIdx.x * 16384;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int n = tid + 1024 * it, r = n & 15;
+        L[((r & 3) * 4 + (r >> 2)) * FFT16K_REGION + (n >> 4)] = src[n];
+    }
+    __syncthreads();
+    float2 *mine = L + wave * FFT16K_REGION;
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
+    const TwEvery16 tw1k = {tw};
+    {
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw1k);
+        fft1k_wave_regs<INV>(v, mine, mine, tw1k, t, lane);
+    }
+    __syncthreads();
+    const int k = tid;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = L[g * FFT16K_REGION + k];
+    {
+        const float2 w1 = tw[4 * k], w2 = tw[8 * k], w3 = tw[12 * k];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) bfly4<INV>(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w1, w2, w3); // m = 1024
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { // m = 4096: index k + 1024 b inside the 4096-block
+        const int kk = k + 1024 * b;
+        bfly4<INV>(v[b], v[b + 4], v[b + 8], v[b + 12], tw[kk], tw[2 * kk], tw[3 * kk]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dst[k + 1024 * g] = v[g];
+}
+
+// ---- N = 256: four transforms per wavefront -------------------------------------------------------
+// Four independent 256-point transforms are exactly the four leaf blocks of the 1024-point flow without
+// its last stage: block j works on the virtual input x[4 i + j] = X_j[i] with every fourth twiddle of the
+// 1024 table, which is the 256 table entry for entry (exact scalings of the phase).  So a wave loads
+// v[t] = X_{lane & 3}[(lane >> 2) + 16 t] (128-byte runs), runs stages m = 1 .. 64 of fft_wave.h and
+// stores block j as transform j.
+struct TwShift {
+    const float2 *p; int sh;
+    __device__ __forceinline__ float2 operator[](int i) const { return p[i >> sh]; }
+};
+
+template <bool INV>
+__global__ __launch_bounds__(256) void fft256_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch,
+                                                     long in_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
+    const long b0 = ((long)blockIdx.x * 4 + wave) * 4;
+    if (b0 >= nbatch) return; // wave-uniform
+    const long bj = (b0 + (lane & 3) < nbatch) ? b0 + (lane & 3) : nbatch - 1;
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = in[bj * in_stride + (lane >> 2) + 16 * t];
+    const TwShift tw1k = {tw, 2};
+    Fft1kTw t;
+    fft1k_load_tw(t, lane, tw1k); // the last-stage entries are loaded but unused (indices stay inside the table)
+    fft1k_wave_stages0to3<INV>(v, ex, tw1k, t, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b0 + j >= nbatch) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[(b0 + j) * 256 + lane + 64 * q] = v[4 * q + j];
+    }
+}
+
+// ---- N = 64: sixteen transforms per wavefront -----------------------------------------------------
+// The same embedding one level down: sixteen 64-point transforms are the sixteen 64-position leaf blocks
+// of the 1024-point flow after its first three stages (m = 1, 4, 16); block d1 + 4 d0 works on the
+// virtual input x[d0 + 4 d1 + 16 i] with every sixteenth twiddle of the 1024 table (= the 64 table).
+// The wave stages its 16 x 64 inputs through LDS (512-byte coalesced loads; row stride 66 float2 makes
+// the per-lane gather conflict-free) and stores block b as transform b in 128-byte runs.
+constexpr int FFT64_ROW = 66;
+template <bool INV>
+__global__ __launch_bounds__(256) void fft64_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch,
+                                                    long in_stride)
+{
+    static_assert(16 * FFT64_ROW <= FFT1K_LDS, "the staging image reuses the wave's exchange area");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
+    const long b0 = ((long)blockIdx.x * 4 + wave) * 16;
+    if (b0 >= nbatch) return; // wave-uniform
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const long b = (b0 + t < nbatch) ? b0 + t : nbatch - 1;
+        v[t] = in[b * in_stride + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) ex[t * FFT64_ROW + lane] = v[t];
+    wave_lds_fence();
+    const int blk = (lane & 3) * 4 + ((lane >> 2) & 3); // transform of virtual sample n = lane + 64 t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = ex[blk * FFT64_ROW + (lane >> 4) + 4 * t];
+    const TwShift tw1k = {tw, 4};
+    fft1k_passA<INV>(v, tw1k);
+    wave_lds_fence();
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; ++k3) ex[fft1k_A_store(lane, k3, k4)] = v[k3 + 4 * k4];
+    wave_lds_fence();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = ex[fft1k_B_load(lane, e)];
+    const int k = lane >> 2; // stage m = 16: k = k4 + 4 k3
+    const float2 w1 = tw[k], w2 = tw[2 * k], w3 = tw[3 * k];
+#pragma unroll
+    for (int d1 = 0; d1 < 4; ++d1) bfly4<INV>(v[d1], v[d1 + 4], v[d1 + 8], v[d1 + 12], w1, w2, w3);
+    // v[d1 + 4 k2] is output k + 16 k2 of transform d1 + 4 d0, d0 = lane & 3
+#pragma unroll
+    for (int d1 = 0; d1 < 4; ++d1) {
+        const long b = b0 + d1 + 4 * (lane & 3);
+        if (b < nbatch) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) out[b * 64 + k + 16 * k2] = v[d1 + 4 * k2];
+        }
+    }
+}
+
 // ---- any N that fits LDS: one workgroup per transform ----------------------------------------
 template <bool INV>
 __global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2 *in,
@@ -236,6 +431,36 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         const unsigned grid = (unsigned)((nbatch + 3) / 4);
         if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        return hipGetLastError();
+    }
+    if (p.nfft == 64) {
+        const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
+        const unsigned grid = (unsigned)((nbatch + 63) / 64);
+        if (inv) hipLaunchKernelGGL(fft64_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft64_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        return hipGetLastError();
+    }
+    if (p.nfft == 256) {
+        const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
+        const unsigned grid = (unsigned)((nbatch + 15) / 16);
+        if (inv) hipLaunchKernelGGL(fft256_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft256_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        return hipGetLastError();
+    }
+    if (p.nfft == 4096) {
+        const size_t lds = 4 * FFT4K_REGION * sizeof(float2);
+        if (inv) hipLaunchKernelGGL(fft4k_kernel<true>, dim3((unsigned)nbatch), dim3(256), lds, s, in, out, p.tw, in_stride);
+        else hipLaunchKernelGGL(fft4k_kernel<false>, dim3((unsigned)nbatch), dim3(256), lds, s, in, out, p.tw, in_stride);
+        return hipGetLastError();
+    }
+    if (p.nfft == 16384) {
+        const size_t lds = 16 * FFT16K_REGION * sizeof(float2);
+        auto kf = fft16k_kernel<false>;
+        auto ki = fft16k_kernel<true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)nbatch), dim3(1024), lds, s, in, out, p.tw, in_stride);
+        else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(1024), lds, s, in, out, p.tw, in_stride);
         return hipGetLastError();
     }
     if (p.nfft == F64K_N) {

@@ -14,12 +14,11 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Everything after the input load of a 1024-point transform by the calling wavefront: v[t] holds
-// x[lane + 64 t] on entry.  ex: FFT1K_LDS float2 of LDS owned by this wave; dst: natural-order
-// output in global memory.
-template <bool INV>
-__device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], float2 *dst, float2 *ex,
-                                                const float2 *__restrict__ tw, const Fft1kTw &t, int lane)
+// Stages m = 1, 4, 16, 64 of the 1024-point flow by the calling wavefront: v[t] holds x[lane + 64 t] on
+// entry; on return v[4 q + j] holds leaf-block j (positions 256 j .. 256 j + 255) at index lane + 64 q,
+// i.e. the four 256-point transforms of x[4 i + j] -- the input of the last stage.
+template <bool INV, typename TwPtr>
+__device__ __forceinline__ void fft1k_wave_stages0to3(float2 (&v)[16], float2 *ex, TwPtr tw, const Fft1kTw &t, int lane)
 {
     fft1k_passA<INV>(v, tw);
     wave_lds_fence(); // every lane has read its inputs before anyone overwrites ex
@@ -41,6 +40,15 @@ __device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], float2 *dst, fl
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * q + j] = ex[fft1k_C_load(lane, q, j)];
+}
+
+// Everything after the input load of a 1024-point transform by the calling wavefront: v[t] holds
+// x[lane + 64 t] on entry.  ex: FFT1K_LDS float2 of LDS owned by this wave; dst: natural-order
+// output (global memory, or LDS -- it may alias ex: LDS operations of a wave complete in order).
+template <bool INV, typename DstPtr, typename TwPtr>
+__device__ __forceinline__ void fft1k_wave_regs(float2 (&v)[16], DstPtr dst, float2 *ex, TwPtr tw, const Fft1kTw &t, int lane)
+{
+    fft1k_wave_stages0to3<INV>(v, ex, tw, t, lane);
     fft1k_passC<INV>(v, t);
 #pragma unroll
     for (int q = 0; q < 4; ++q)

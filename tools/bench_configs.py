@@ -37,11 +37,11 @@ if "fir" in which:
         b = 8 + 8 / d
         print(f"FIR 127 taps /{d}: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {b*n/ms/1e6:.0f} GB/s algorithmic ({b*n/ms/1e6/8000:.1%})")
 if "fft" in which:
-    for nfft in (1024, 64, 4096, 65536):
-        x = R.synth_iq(2, 0, n if nfft != 65536 else 1 << 24)
+    for nfft in (1024, 64, 256, 4096, 16384, 65536, 2048, 1000):
+        x = R.synth_iq(2, 0, n if nfft < 16384 else 1 << 24)[: (n if nfft < 16384 else 1 << 24) // nfft * nfft]
         plan = R.Fft(nfft)
         out = torch.empty_like(x)
-        ms = timeit(lambda: plan(x, out=out), n=20 if nfft != 65536 else 5, warm=3)
+        ms = timeit(lambda: plan(x, out=out), n=20 if nfft < 16384 else 5, warm=3)
         print(f"FFT {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  {16*x.numel()/ms/1e6:.0f} GB/s algorithmic ({16*x.numel()/ms/1e6/8000:.1%})")
 if "c3" in which:
     import time
