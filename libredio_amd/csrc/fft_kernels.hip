@@ -12,16 +12,32 @@
 
 namespace redio {
 
+constexpr int FFT1K_PER_WAVE = 8; // transforms per wavefront: the 27 lane-dependent twiddles are loaded once and reused
 template <bool INV>
 __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float2 *out,
                                                          const float2 *__restrict__ tw, long nbatch, long in_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
-    const long b = (long)blockIdx.x * 4 + wave;
-    if (b >= nbatch) return; // wave-uniform
-    fft1k_wave<INV>(in + b * in_stride, out + b * 1024, ex, tw, lane);
+    const long b0 = ((long)blockIdx.x * 4 + wave) * FFT1K_PER_WAVE;
+    if (b0 >= nbatch) return; // wave-uniform
+    const long b1 = (b0 + FFT1K_PER_WAVE < nbatch) ? b0 + FFT1K_PER_WAVE : nbatch;
+    Fft1kTw t;
+    fft1k_load_tw(t, lane, tw);
+    float2 v[16], nx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = in[b0 * in_stride + lane + 64 * i];
+    for (long b = b0; b < b1; ++b) {
+        const long bn = (b + 1 < b1) ? b + 1 : b; // prefetch the next transform's input under this one's arithmetic
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nx[i] = in[bn * in_stride + lane + 64 * i];
+        fft1k_wave_regs<INV>(v, out + b * 1024, ex, tw, t, lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = nx[i];
+    }
 }
 
 // ---- N = 4096 = 4 x 1024: one workgroup per transform -------------------------------------------
@@ -428,7 +444,7 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     const bool inv = p.inverse != 0;
     if (p.nfft == 1024) {
         const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
-        const unsigned grid = (unsigned)((nbatch + 3) / 4);
+        const unsigned grid = (unsigned)((nbatch + 4 * FFT1K_PER_WAVE - 1) / (4 * FFT1K_PER_WAVE));
         if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
