@@ -53,3 +53,17 @@ def channelizer_exchange_layout(world, nchan):
     """Channels per destination rank for the all-to-all (equal groups; nchan % world == 0)."""
     assert nchan % world == 0, "channel count must divide evenly across ranks"
     return nchan // world
+
+
+def overlap_save_shard(rank, world, n_in, ntaps, nfft):
+    """C5: overlap-save blocks are independent given their ntaps - 1 samples of input overlap, so the
+    blocks are dealt contiguously and a shard reads exactly the input span of its blocks.
+    Returns (first_sample, n_samples, first_out, n_out)."""
+    hop = nfft - ntaps + 1
+    nblk = 0 if n_in < nfft else (n_in - nfft) // hop + 1
+    base, extra = divmod(nblk, world)
+    mine = base + (1 if rank < extra else 0)
+    first_block = rank * base + min(rank, extra)
+    if mine == 0:
+        return 0, 0, first_block * hop, 0
+    return first_block * hop, (mine - 1) * hop + nfft, first_block * hop, mine * hop

@@ -121,3 +121,30 @@ def test_channelizer_all_to_all_regroups_time_shards_into_channel_shards():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_overlap_save_and_channel_shards_concatenate():
+    """C5 / C3 partitions (no collective): the shards' outputs, concatenated in rank order,
+    are the unsharded result, bit for bit (oracle on both sides: this checks the partition arithmetic)."""
+    import oracle as O
+    from libredio_amd import sharding as S
+    nfft, k = 256, 33
+    taps = O.lpf_corrected(k, 0.1)
+    x = O.synth_iq(5, 0, 256 * 40 + 17)
+    whole = O.overlap_save(x, taps, nfft)
+    for world in (1, 2, 3, 8, 64):
+        parts, nxt = [], 0
+        for r in range(world):
+            first, n, first_out, n_out = S.overlap_save_shard(r, world, len(x), k, nfft)
+            assert first_out == nxt
+            nxt += n_out
+            if n:
+                y = O.overlap_save(x[first:first + n], taps, nfft)
+                assert len(y) == n_out
+                parts.append(y)
+        got = np.concatenate(parts)
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), world
+    for world in (1, 2, 3, 8):
+        shards = [S.channel_shard(r, world, 256) for r in range(world)]
+        assert sum(n for _, n in shards) == 256 and shards[0][0] == 0
+        assert all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(world - 1))
