@@ -159,5 +159,83 @@ inline void ingest_mag(Receiver<View<uint8_t>> u, Sender<View<float>> v)
     }
 }
 
+// kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231) with the constant vector resident on the device
+namespace detail {
+inline int zip_call(bool add, const float *a, const float *b, float *o, size_t n) { return add ? redio_add_f32(a, b, o, n, nullptr) : redio_mul_f32(a, b, o, n, nullptr); }
+inline int zip_call(bool add, const std::complex<float> *a, const std::complex<float> *b, std::complex<float> *o, size_t n)
+{
+    return add ? redio_add_c32(a, b, o, n, nullptr) : redio_mul_c32(a, b, o, n, nullptr);
+}
+template <typename T>
+void zip_vecs(Receiver<View<T>> u, Sender<View<T>> v, const std::vector<T> &c, bool add)
+{
+    auto dc = make<T>(c.size());
+    check(redio_upload(dc.data(), c.data(), c.size() * sizeof(T), nullptr));
+    check(redio_stream_sync(nullptr));
+    for (;;) {
+        auto x = u.recv();
+        const size_t n = x.len < c.size() ? x.len : c.size();
+        auto o = make<T>(n);
+        check(zip_call(add, x.data(), dc.data(), o.data(), n));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(o));
+    }
+}
+} // namespace detail
+template <typename T>
+void mul_vecs(Receiver<View<T>> u, Sender<View<T>> v, std::vector<T> c) { detail::zip_vecs<T>(std::move(u), std::move(v), c, false); }
+template <typename T>
+void sum_vecs(Receiver<View<T>> u, Sender<View<T>> v, std::vector<T> c) { detail::zip_vecs<T>(std::move(u), std::move(v), c, true); }
+
+// samplerate::resample semantics (samplerate.rs:59-87) on a device stream: one converter state for the
+// life of the block, output capacity floor(ratio*len + 1) per message, output_frames_gen samples sent
+inline void resample(Receiver<View<float>> din, Sender<View<float>> dout, double ratio)
+{
+    redio_src *h = nullptr;
+    int rc = redio_src_create(&h, 1 /* SRC_SINC_MEDIUM_QUALITY, samplerate.rs:27 */, 1);
+    if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc));
+    struct G { redio_src *h; ~G() { redio_src_destroy(h); } } g{h};
+    for (;;) {
+        auto d = din.recv();
+        const long lout = (long)(ratio * (double)d.len + 1.0);
+        auto o = make<float>((size_t)lout);
+        long used = 0, gen = 0;
+        rc = redio_src_process(h, d.data(), (long)d.len, (long)d.len, o.data(), lout, lout, ratio, 0, &used, &gen, nullptr);
+        if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc)); // the reference panics with src_strerror's text
+        dout.send_unwrap(o.sub(0, (size_t)gen));
+    }
+}
+
+// the 64-channel polyphase filterbank (BASELINE configs[3]) as a block: rows of 64 channel samples out
+inline void channelizer(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> proto, int nchan,
+                        int taps_per_branch, bool fused)
+{
+    redio_pfb *h = nullptr;
+    check(redio_pfb_create(&h, proto.data(), nchan, taps_per_branch, fused ? REDIO_FIR_FUSED : 0));
+    struct G { redio_pfb *h; ~G() { redio_pfb_destroy(h); } } g{h};
+    for (;;) {
+        auto d = u.recv();
+        auto o = make<std::complex<float>>(redio_pfb_nrows(h, d.len) * (size_t)nchan);
+        check(redio_pfb_enqueue(h, d.data(), d.len, o.data(), 1, nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(o));
+    }
+}
+
+// overlap-save FFT convolution (BASELINE configs[4]) with dsputils::convolve's valid-mode semantics per message
+inline void overlap_save(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, int nfft)
+{
+    redio_ovsave *h = nullptr;
+    check(redio_ovsave_create(&h, taps.data(), taps.size(), nfft));
+    struct G { redio_ovsave *h; ~G() { redio_ovsave_destroy(h); } } g{h};
+    for (;;) {
+        auto d = u.recv();
+        auto o = make<std::complex<float>>(redio_ovsave_nout(h, d.len));
+        check(redio_ovsave_enqueue(h, d.data(), d.len, o.data(), nullptr));
+        check(redio_stream_sync(nullptr));
+        v.send_unwrap(std::move(o));
+    }
+}
+
 } // namespace dev
 } // namespace kpn

@@ -225,6 +225,14 @@ int redio_src_process_host(redio_src *h, const float *data_in, long input_frames
 /* the coefficient table of a converter (coeffs_out may be NULL; it holds half_len + 2 floats) */
 int redio_src_table(int converter, float *coeffs_out, int *half_len, int *increment);
 
+/* ---- kpn vector maps on device: mul_vecs (src/kpn/src/kpn.rs:254-258) and sum_vecs (:227-231) ----
+ * out[i] = a[i] * b[i] / a[i] + b[i] for i < n (the caller passes n = min of the two lengths, as zip does);
+ * f32 and Complex<f32> ((ar*br - ai*bi, ar*bi + ai*br), every operation rounded on its own). */
+int redio_mul_f32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+int redio_add_f32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+int redio_mul_c32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+int redio_add_c32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+
 /* ---- synthetic input: hash-generated cf32 / f32 in [-1, 1), device side ---- */
 int redio_synth_iq(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);
 int redio_synth_f32(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);

@@ -123,6 +123,8 @@ def lib():
     _sig(L.redio_rld, i, vp, vp, sz, vp, sz, vp, psz, vp)
     _sig(L.redio_dld, i, vp, vp, sz, f, vp, sz, vp, psz, vp)
     _sig(L.redio_binconv, i, vp, sz, sz, psz, sz, vp, vp)
+    for f in (L.redio_mul_f32, L.redio_add_f32, L.redio_mul_c32, L.redio_add_c32):
+        _sig(f, i, vp, vp, vp, sz, vp)
     _sig(L.redio_pfb_create, i, C.POINTER(vp), pf, i, i, u)
     _sig(L.redio_pfb_destroy, i, vp)
     _sig(L.redio_pfb_nrows, sz, vp, sz)

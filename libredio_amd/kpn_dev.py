@@ -72,3 +72,24 @@ def binconv(bits, widths):
     out = torch.empty((nmsg, len(widths)), dtype=torch.int64, device=bits.device)
     check(lib().redio_binconv(_dev_ptr(bits), nmsg, nbits, w, len(widths), _dev_ptr(out), current_stream()), "binconv")
     return out
+
+
+def _zip(name_f32, name_c32, x, c):
+    import torch
+    assert x.dtype == c.dtype and x.dtype in (torch.float32, torch.complex64) and x.dim() == 1 and c.dim() == 1
+    assert x.is_contiguous() and c.is_contiguous()
+    n = min(x.numel(), c.numel())
+    out = torch.empty(n, dtype=x.dtype, device=x.device)
+    f = getattr(lib(), name_f32 if x.dtype == torch.float32 else name_c32)
+    check(f(_dev_ptr(x), _dev_ptr(c), _dev_ptr(out), n, current_stream()), name_f32)
+    return out
+
+
+def mul_vecs(x, c):
+    """kpn::mul_vecs (kpn.rs:254-258) on device tensors: x[i] * c[i] over the shorter length."""
+    return _zip("redio_mul_f32", "redio_mul_c32", x, c)
+
+
+def sum_vecs(x, c):
+    """kpn::sum_vecs (kpn.rs:227-231) on device tensors: x[i] + c[i] over the shorter length."""
+    return _zip("redio_add_f32", "redio_add_c32", x, c)

@@ -85,6 +85,8 @@ def lib():
     L.orc_trigger_feed.restype = sz
     L.orc_block_sum.argtypes = [_f32p, sz]; L.orc_block_sum.restype = C.c_float
     L.orc_norm_c32.argtypes = [_c64p, sz, _f32p]; L.orc_norm_c32.restype = None
+    L.orc_zip_f32.argtypes = [_f32p, _f32p, sz, C.c_int, _f32p]; L.orc_zip_f32.restype = None
+    L.orc_zip_c32.argtypes = [_c64p, _c64p, sz, C.c_int, _c64p]; L.orc_zip_c32.restype = None
     _lib = L
     return L
 
@@ -347,4 +349,16 @@ def dld(runs, s_rate):
     out = []
     for x, dur in runs:
         out += [x] * int(np.float32(np.float32(dur) * np.float32(s_rate)))
+    return out
+
+
+def zip_vecs(a, b, add=False):
+    """kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231): elementwise over the shorter length."""
+    n = min(len(a), len(b))
+    if np.iscomplexobj(a) or np.iscomplexobj(b):
+        a, b = _c64(a[:n]), _c64(b[:n]); out = np.empty(n, np.complex64)
+        lib().orc_zip_c32(a, b, n, int(add), out)
+    else:
+        a, b = _f32(a[:n]), _f32(b[:n]); out = np.empty(n, np.float32)
+        lib().orc_zip_f32(a, b, n, int(add), out)
     return out

@@ -329,6 +329,69 @@ static int dev_shaper_graph(const char *in, const char *out, size_t msg, size_t 
     return 0;
 }
 
+// device-resident elementwise + resampler + channelizer blocks: f32 stream -> sum_vecs -> mul_vecs -> resample
+static int dev_mix_graph(const char *in, const char *out, size_t msg, double ratio)
+{
+    auto x = read_bin<float>(in);
+    std::vector<float> c(msg), c2(msg);
+    for (size_t i = 0; i < msg; ++i) { c[i] = (float)(i % 7) * 0.25f - 0.5f; c2[i] = 1.0f + (float)(i % 5) * 0.125f; }
+    auto [s0, r0] = channel<std::vector<float>>();
+    auto [s1, r1] = channel<dev::View<float>>();
+    auto [s2, r2] = channel<dev::View<float>>();
+    auto [s3, r3] = channel<dev::View<float>>();
+    auto [s4, r4] = channel<dev::View<float>>();
+    auto [s5, r5] = channel<std::vector<float>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x, msg]() mutable {
+        for (size_t o = 0; o < x.size(); o += msg) s.send(std::vector<float>(x.begin() + (long)o, x.begin() + (long)std::min(o + msg, x.size())));
+    }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { dev::to_device<float>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), c]() mutable { dev::sum_vecs<float>(std::move(r), std::move(s), c); }));
+    th.push_back(spawn([r = std::move(r2), s = std::move(s3), c2]() mutable { dev::mul_vecs<float>(std::move(r), std::move(s), c2); }));
+    th.push_back(spawn([r = std::move(r3), s = std::move(s4), ratio]() mutable { dev::resample(std::move(r), std::move(s), ratio); }));
+    th.push_back(spawn([r = std::move(r4), s = std::move(s5)]() mutable { dev::to_host<float>(std::move(r), std::move(s)); }));
+    std::vector<float> y;
+    while (auto v = r5.try_recv_blocking()) y.insert(y.end(), v->begin(), v->end());
+    for (auto &t : th) t.join();
+    write_bin(out, y);
+    return 0;
+}
+
+// cf32 stream -> 64-channel channelizer and -> overlap-save, both device-resident, from one forked View
+static int dev_bank_graph(const char *in, const char *out_pfb, const char *out_ovs, size_t msg)
+{
+    using cf = std::complex<float>;
+    auto x = read_bin<cf>(in);
+    const std::vector<float> proto = dsputils::lpf_corrected(64 * 16, 0.45f / 64.0f), taps = dsputils::lpf_corrected(127, 0.08f);
+    auto [s0, r0] = channel<std::vector<cf>>();
+    auto [s1, r1] = channel<dev::View<cf>>();
+    auto [s2a, r2a] = channel<dev::View<cf>>();
+    auto [s2b, r2b] = channel<dev::View<cf>>();
+    auto [s3a, r3a] = channel<dev::View<cf>>();
+    auto [s3b, r3b] = channel<dev::View<cf>>();
+    auto [s4a, r4a] = channel<std::vector<cf>>();
+    auto [s4b, r4b] = channel<std::vector<cf>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x, msg]() mutable {
+        for (size_t o = 0; o + msg <= x.size(); o += msg) s.send(std::vector<cf>(x.begin() + (long)o, x.begin() + (long)(o + msg)));
+    }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { dev::to_device<cf>(std::move(r), std::move(s)); }));
+    std::vector<Sender<dev::View<cf>>> outs;
+    outs.push_back(std::move(s2a)); outs.push_back(std::move(s2b));
+    th.push_back(spawn([r = std::move(r1), o = std::move(outs)]() mutable { fork<dev::View<cf>>(std::move(r), std::move(o)); }));
+    th.push_back(spawn([r = std::move(r2a), s = std::move(s3a), proto]() mutable { dev::channelizer(std::move(r), std::move(s), proto, 64, 16, true); }));
+    th.push_back(spawn([r = std::move(r2b), s = std::move(s3b), taps]() mutable { dev::overlap_save(std::move(r), std::move(s), taps, 4096); }));
+    th.push_back(spawn([r = std::move(r3a), s = std::move(s4a)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r3b), s = std::move(s4b)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    std::vector<cf> a, b;
+    while (auto v = r4a.try_recv_blocking()) a.insert(a.end(), v->begin(), v->end());
+    while (auto v = r4b.try_recv_blocking()) b.insert(b.end(), v->begin(), v->end());
+    for (auto &t : th) t.join();
+    write_bin(out_pfb, a);
+    write_bin(out_ovs, b);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -338,6 +401,8 @@ int main(int argc, char **argv)
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
         if (mode == "devchain" && argc == 6) return dev_chain_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
         if (mode == "devshaper" && argc == 6) return dev_shaper_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]));
+        if (mode == "devmix" && argc == 6) return dev_mix_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), std::atof(argv[5]));
+        if (mode == "devbank" && argc == 6) return dev_bank_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
         if (mode == "resample" && argc == 6) return resample_graph(argv[2], argv[3], std::atof(argv[4]), (size_t)std::atol(argv[5]));
         std::fprintf(stderr, "usage: see the header of kpn_tests.cpp\n");
         return 2;

@@ -70,3 +70,21 @@ def test_shipped_graph_discretize_to_runs(gpu, redio, oracle):
     assert list(zip(v.cpu().tolist(), c.cpu().tolist())) == want
     sec = redio.kpn_dev.dle(c, 256000).cpu().numpy()
     assert np.array_equal(sec.view(np.uint32), np.array([w[1] for w in oracle.dle(want, 256000)], np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 1023, 4096, 100003])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_mul_vecs_sum_vecs_bit_exact(gpu, redio, oracle, n, cplx):
+    # kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231): zip over the shorter length; aligned and unaligned views
+    from libredio_amd import kpn_dev
+    gen = oracle.synth_iq if cplx else oracle.synth_f32
+    x, c = gen(31, 0, n + 5), gen(32, 0, n + 9)
+    dx, dc = gpu.from_numpy(x).cuda(), gpu.from_numpy(c).cuda()
+    for off in (0, 1):          # off = 1: 4- or 8-byte aligned only -> scalar path
+        a, b = dx[off:off + n], dc[off:off + n + 2]
+        got_m, got_s = kpn_dev.mul_vecs(a, b).cpu().numpy(), kpn_dev.sum_vecs(a, b).cpu().numpy()
+        want_m = oracle.zip_vecs(x[off:off + n], c[off:off + n + 2], add=False)
+        want_s = oracle.zip_vecs(x[off:off + n], c[off:off + n + 2], add=True)
+        assert len(got_m) == n and len(got_s) == n
+        assert np.array_equal(got_m.view(np.uint32), want_m.view(np.uint32))
+        assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))

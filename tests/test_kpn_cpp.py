@@ -117,3 +117,37 @@ def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
     assert out.returncode == 0, out.stderr
     y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     assert np.array_equal(bits(y), bits(x[: (10000 // 1024) * 1024]))   # the trailing partial chunk is dropped (kpn.rs:278-282)
+
+
+@pytest.mark.gpu
+def test_device_vector_maps_and_resampler_blocks(exe, gpu, oracle, tmp_path):
+    # f32 stream -> dev::sum_vecs -> dev::mul_vecs -> dev::resample, all in HBM between the PCIe crossings
+    msg, ratio = 4000, 0.5
+    x = oracle.synth_f32(21, 0, 5 * msg + 123)          # the last message is short: zip truncates to it
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "devmix", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(msg), str(ratio)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    i = np.arange(msg)
+    c = ((i % 7).astype(np.float32) * np.float32(0.25) - np.float32(0.5)).astype(np.float32)
+    c2 = (np.float32(1.0) + (i % 5).astype(np.float32) * np.float32(0.125)).astype(np.float32)
+    ref, want = oracle.Resampler(1), []
+    for o in range(0, len(x), msg):
+        m = oracle.zip_vecs(oracle.zip_vecs(x[o:o + msg], c, add=True), c2, add=False)
+        want.append(ref.block(m, ratio))
+    y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    assert np.array_equal(bits(y), bits(np.concatenate(want)))
+
+
+@pytest.mark.gpu
+def test_device_channelizer_and_overlap_save_blocks(exe, gpu, oracle, tmp_path):
+    msg = 64 * 300
+    x = oracle.synth_iq(22, 0, 2 * msg)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "devbank", str(tmp_path / "in.bin"), str(tmp_path / "pfb.bin"), str(tmp_path / "ovs.bin"), str(msg)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    proto, taps = oracle.lpf_corrected(64 * 16, 0.45 / 64), oracle.lpf_corrected(127, 0.08)
+    want_pfb = np.concatenate([oracle.pfb_channelizer(x[i * msg:(i + 1) * msg], proto, 64, 16, True).reshape(-1) for i in range(2)])
+    want_ovs = np.concatenate([oracle.overlap_save(x[i * msg:(i + 1) * msg], taps, 4096) for i in range(2)])
+    assert np.array_equal(bits(np.fromfile(tmp_path / "pfb.bin", dtype=np.complex64)), bits(want_pfb))
+    assert np.array_equal(bits(np.fromfile(tmp_path / "ovs.bin", dtype=np.complex64)), bits(want_ovs))
