@@ -1,0 +1,9 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/p_stats.json 2> $R/gpurun_out/p_stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p_write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_cfg -- python3 $R/tools/bench_configs.py c3 c4 c5 fir fft > $R/gpurun_out/p_cfg.txt 2>&1
+cd $R
+python3 profiles/pmc_summary.py chain_v4 gpurun_out/p_fetch gpurun_out/p_write
+cat gpurun_out/p_stats.json | cut -c1-400
