@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--exact", action="store_true", help="reference rounding (mul+add) instead of fmaf in the FIR")
     ap.add_argument("--variant", type=int, default=0, help="fused kernel generation (0 = current, 1 = first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=25)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
     return ap.parse_args()
@@ -80,12 +82,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (libredio has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and local_rank >= ndev:
+        sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} HIP devices are visible")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.backend)
 
     lib = R.lib()
     n = 1 << a.log2_samples
