@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void ingest_mag_kernel(const uint8_t *__restri
 }
 
 // per-block sums in sample order (bitfount.rs:48): one lane per block; a wave stages 64 blocks'
-// chunks through LDS so that global reads stay coalesced (row padded by one float: lane stride 65)
-__global__ __launch_bounds__(64) void block_sum_kernel(const float *__restrict__ x, float *__restrict__ sums, long nblocks, int block)
+// chunks through LDS so that global reads stay coalesced (row padded by one float: lane stride 65).
+// Any block length and alignment.
+__global__ __launch_bounds__(64) void block_sum_generic_kernel(const float *__restrict__ x, float *__restrict__ sums, long nblocks, int block)
 {
     __shared__ float tile[64 * 65];
     const int lane = threadIdx.x;
@@ -80,29 +81,98 @@ __global__ __launch_bounds__(64) void block_sum_kernel(const float *__restrict__
     if (b0 + lane < nblocks) sums[b0 + lane] = s;
 }
 
+// The same with 16-byte accesses end to end (block % 64 == 0, x 16-byte aligned -- the reference's 512):
+// per 64-sample chunk a wave issues sixteen 1 KiB loads (4 rows x 256 B each) before it stores any of
+// them to LDS, then every lane walks its own row with ds_read_b128 (row stride 68 floats: the 16-lane
+// groups of a b128 access cover all 64 banks) and adds the samples in order.
+__global__ __launch_bounds__(64) void block_sum_kernel(const float *__restrict__ x, float *__restrict__ sums, long nblocks, int block)
+{
+    constexpr int LD = 68;
+    __shared__ __attribute__((aligned(16))) float tile[64 * LD];
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x;
+    const long b0 = (long)blockIdx.x * 64;
+    const int rsub = lane >> 4, c4 = 4 * (lane & 15);
+    float s = 0.0f;
+    for (int c0 = 0; c0 < block; c0 += 64) {
+        v4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            long b = b0 + 4 * k + rsub;
+            if (b >= nblocks) b = nblocks - 1; // read a valid row; its lane never stores a result
+            v[k] = *reinterpret_cast<const v4 *>(x + b * block + c0 + c4);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<v4 *>(&tile[(4 * k + rsub) * LD + c4]) = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v4 t = *reinterpret_cast<const v4 *>(&tile[lane * LD + 4 * q]);
+            s = add_rn(s, t.x); s = add_rn(s, t.y); s = add_rn(s, t.z); s = add_rn(s, t.w);
+        }
+        __syncthreads();
+    }
+    if (b0 + lane < nblocks) sums[b0 + lane] = s;
+}
+
 // discretize pass 1: max = fold(0.0, f32::max): NaN operands are ignored, negatives never win, so the
 // result is a non-negative float whose bit pattern orders like an unsigned integer
 __global__ __launch_bounds__(256) void max_kernel(const float *__restrict__ x, long n, unsigned *max_bits)
 {
+    typedef float v4 __attribute__((ext_vector_type(4)));
     float m = 0.0f;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = x[i];
-        if (v > m) m = v; // false for NaN
+    const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long head = (n < 4 || ((uintptr_t)x & 15) == 0) ? 0 : (16 - ((uintptr_t)x & 15)) / 4; // scalars before the first aligned 16 bytes
+    const long n4 = n >= head ? (n - head) / 4 : 0;
+    const v4 *x4 = reinterpret_cast<const v4 *>(x + head);
+    for (long i = tid; i < n4; i += stride) {
+        const v4 v = x4[i];
+        if (v.x > m) m = v.x; // false for NaN
+        if (v.y > m) m = v.y;
+        if (v.z > m) m = v.z;
+        if (v.w > m) m = v.w;
+    }
+    for (long i = tid; i < n - 4 * n4; i += stride) { // head and tail scalars
+        const float v = x[i < head ? i : 4 * n4 + i];
+        if (v > m) m = v;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_xor(m, off);
         if (o > m) m = o;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
+    // one atomic per workgroup (same-address atomics serialise in L2)
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (wmax[w] > m) m = wmax[w];
+        atomicMax(max_bits, __float_as_uint(m));
+    }
 }
 
+// discretize pass 2: 16 samples per thread step (four 16-byte loads, one 16-byte store of 0/1 bytes)
 __global__ __launch_bounds__(256) void slice_kernel(const float *__restrict__ x, long n, const unsigned *max_bits, uint8_t *__restrict__ out)
 {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const float thr = __uint_as_float(*max_bits) / 2.0f;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = x[i] > thr ? 1 : 0;
+    const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    const long n16 = aligned ? n / 16 : 0;
+    const v4 *x4 = reinterpret_cast<const v4 *>(x);
+    u4 *o4 = reinterpret_cast<u4 *>(out);
+    for (long i = tid; i < n16; i += stride) {
+        u4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4 v = x4[4 * i + q];
+            w[q] = (v.x > thr ? 1u : 0u) | (v.y > thr ? 0x100u : 0u) | (v.z > thr ? 0x10000u : 0u) | (v.w > thr ? 0x1000000u : 0u);
+        }
+        o4[i] = w;
+    }
+    for (long i = 16 * n16 + tid; i < n; i += stride) out[i] = x[i] > thr ? 1 : 0;
 }
 
 // gather whole blocks (trigger's push_all of triggered blocks): seg = (src_block, dst_offset)
@@ -160,8 +230,9 @@ extern "C" int redio_block_sums(const void *d_in, size_t nblocks, size_t block, 
 {
     if (nblocks == 0) return REDIO_OK;
     if (!d_in || !d_sums || block == 0 || block > (1u << 30)) return REDIO_ERR_ARG;
-    hipLaunchKernelGGL(block_sum_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float *)d_in,
-                       (float *)d_sums, (long)nblocks, (int)block);
+    const bool vec = block % 64 == 0 && ((uintptr_t)d_in & 15) == 0;
+    hipLaunchKernelGGL(vec ? block_sum_kernel : block_sum_generic_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0,
+                       (hipStream_t)stream, (const float *)d_in, (float *)d_sums, (long)nblocks, (int)block);
     return hip_rc(hipGetLastError());
 }
 
@@ -171,7 +242,7 @@ extern "C" int redio_discretize(const void *d_in, size_t n, void *d_out_u8, void
     if (!d_in || !d_out_u8 || !d_scratch_u32) return REDIO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     IN_TRY(hipMemsetAsync(d_scratch_u32, 0, sizeof(unsigned), st)); // fold starts at 0.0
-    hipLaunchKernelGGL(max_kernel, dim3(grid_for((long)n, 1024)), dim3(256), 0, st, (const float *)d_in, (long)n, (unsigned *)d_scratch_u32);
+    hipLaunchKernelGGL(max_kernel, dim3(grid_for((long)n, 1024) > 2048 ? 2048 : grid_for((long)n, 1024)), dim3(256), 0, st, (const float *)d_in, (long)n, (unsigned *)d_scratch_u32);
     hipLaunchKernelGGL(slice_kernel, dim3(grid_for((long)n)), dim3(256), 0, st, (const float *)d_in, (long)n, (const unsigned *)d_scratch_u32,
                        (uint8_t *)d_out_u8);
     return hip_rc(hipGetLastError());

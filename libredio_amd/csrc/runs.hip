@@ -21,16 +21,33 @@ __device__ __forceinline__ int is_change(const uint8_t *__restrict__ x, long i, 
     return x[i] != x[i - 1];
 }
 
-// pass 1: number of value changes per tile
+// change flags of the 8 consecutive elements i0 .. i0+7 as a bit mask (bit k: element i0+k differs from
+// its predecessor).  One 8-byte load when the group is whole and x + i0 is 8-byte aligned.
+__device__ __forceinline__ unsigned change_mask8(const uint8_t *__restrict__ x, long i0, long n, int have_prev, uint8_t prev, bool aligned)
+{
+    if (i0 >= n) return 0;
+    if (aligned && i0 + 8 <= n) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(x + i0);
+        const unsigned long long before = i0 == 0 ? (have_prev ? prev : (w & 0xff)) : x[i0 - 1];
+        const unsigned long long d = w ^ ((w << 8) | before);
+        // byte k of d is non-zero  <=>  bit 7 of byte k of nz is set
+        const unsigned long long nz = (((d & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | d) & 0x8080808080808080ull;
+        // gather the eight bit-7s into one byte: (nz >> 7) has bit 8k set; multiply packs them into the top byte
+        return (unsigned)(((nz >> 7) * 0x0102040810204080ull) >> 56);
+    }
+    unsigned m = 0;
+    for (int k = 0; k < 8; ++k)
+        if (i0 + k < n && is_change(x, i0 + k, have_prev, prev)) m |= 1u << k;
+    return m;
+}
+
+// pass 1: number of value changes per tile (thread t owns elements 8 t .. 8 t + 7 of the tile, as pass 3 does)
 __global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t *__restrict__ x, long n, int have_prev, uint8_t prev,
                                                         unsigned *__restrict__ tile_counts)
 {
-    const long base = (long)blockIdx.x * RUN_TILE;
-    int c = 0;
-    for (int k = 0; k < RUN_TILE / 256; ++k) {
-        const long i = base + threadIdx.x + 256 * k;
-        if (i < n) c += is_change(x, i, have_prev, prev);
-    }
+    const long i0 = (long)blockIdx.x * RUN_TILE + (long)threadIdx.x * 8;
+    const bool aligned = ((uintptr_t)x & 7) == 0;
+    int c = __popc(change_mask8(x, i0, n, have_prev, prev, aligned));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     __shared__ int ws[4];
@@ -75,12 +92,8 @@ __global__ __launch_bounds__(256) void rle_positions_kernel(const uint8_t *__res
     const long base = (long)blockIdx.x * RUN_TILE;
     // each thread owns 8 CONSECUTIVE elements so that ranks follow stream order
     const long i0 = base + (long)threadIdx.x * 8;
-    int f[8], c = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        f[k] = (i0 + k < n) ? is_change(x, i0 + k, have_prev, prev) : 0;
-        c += f[k];
-    }
+    const unsigned mask = change_mask8(x, i0, n, have_prev, prev, ((uintptr_t)x & 7) == 0);
+    const int c = __popc(mask);
     int incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(256) void rle_positions_kernel(const uint8_t *__res
     long r = (long)tile_offsets[blockIdx.x] + woff + incl - c;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-        if (f[k]) pos[r++] = i0 + k;
+        if (mask & (1u << k)) pos[r++] = i0 + k;
 }
 
 // pass 4: run k = (value before change k, distance to the previous change); the carried run length of

@@ -25,7 +25,7 @@ class Rle:
         check(lib().redio_rle_feed(self._h, _dev_ptr(x), n, _dev_ptr(vals), _dev_ptr(counts), max(n, 1), C.byref(nr), current_stream()), "rle_feed")
         return vals[: nr.value], counts[: nr.value]
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_rle_destroy", self._h)
             self._h = None

@@ -58,7 +58,7 @@ class Fir:
         check(lib().redio_fir_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "fir_enqueue")
         return out[:n]
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_fir_destroy", self._h)
             self._h = None
@@ -80,7 +80,7 @@ class Fft:
         check(lib().redio_fft_enqueue(self._h, _dev_ptr(x), _dev_ptr(out), x.numel() // self.nfft, current_stream()), "fft_enqueue")
         return out
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_fft_destroy", self._h)
             self._h = None
@@ -120,7 +120,7 @@ class Chain:
         check(lib().redio_chain_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "chain_enqueue")
         return out
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_chain_destroy", self._h)
             self._h = None
@@ -160,7 +160,7 @@ class Src:
     def reset(self):
         check(lib().redio_src_reset(self._h), "src_reset")
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_src_destroy", self._h)
             self._h = None
@@ -207,7 +207,7 @@ class Channelizer:
         check(lib().redio_pfb_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), int(ngroups), current_stream()), "pfb_enqueue")
         return out
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_pfb_destroy", self._h)
             self._h = None
@@ -254,7 +254,7 @@ class OverlapSave:
         check(lib().redio_ovsave_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "ovsave_enqueue")
         return out[:n]
 
-    def __del__(self):
+    def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_ovsave_destroy", self._h)
             self._h = None

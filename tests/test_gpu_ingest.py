@@ -45,6 +45,18 @@ def test_discretize_bit_exact(gpu, redio, oracle):
         x[n // 2] = 3.0
         got = redio.bitfount.discretize(gpu.from_numpy(x).cuda()).cpu().numpy()
         assert np.array_equal(got, oracle.discretize(x).astype(np.uint8))
+    # views that start off a 16-byte boundary, lengths around the 4- and 16-sample vector steps, the max in the head / tail
+    base = np.abs(oracle.synth_f32(9, 0, 5000)).astype(np.float32)
+    d = gpu.from_numpy(base).cuda()
+    for off in (0, 1, 2, 3):
+        for n in (2, 3, 4, 5, 15, 16, 17, 31, 33, 4097):
+            for peak in (0, n // 2, n - 1):
+                x = base[off:off + n].copy()
+                x[peak] = 7.0
+                d[off + peak] = 7.0
+                got = redio.bitfount.discretize(d[off:off + n]).cpu().numpy()
+                d[off + peak] = float(base[off + peak])
+                assert np.array_equal(got, oracle.discretize(x).astype(np.uint8)), (off, n, peak)
     # NaN is ignored by f32::max; all-negative input keeps max = 0.0 (the fold's seed)
     x = np.array([np.nan, -1.0, 0.5, 2.0, np.nan, 1.1], np.float32)
     assert redio.bitfount.discretize(gpu.from_numpy(x).cuda()).cpu().numpy().tolist() == oracle.discretize(x).tolist() == [0, 0, 0, 1, 0, 1]

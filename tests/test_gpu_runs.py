@@ -32,6 +32,18 @@ def test_rle_large_and_multivalue(gpu, redio, oracle):
     assert np.array_equal(c.cpu().numpy(), np.array([w[1] for w in want], np.int64))
 
 
+@pytest.mark.parametrize("off", [1, 3, 7])
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 2047, 2048, 2049, 70001])
+def test_rle_views_off_the_8_byte_grid(gpu, redio, oracle, off, n):
+    # the change detection reads 8 elements per load when it can: views that start anywhere, ragged ends
+    rng = np.random.default_rng(off * 100 + n)
+    x = np.repeat(rng.integers(0, 3, n + 8), rng.integers(1, 5, n + 8)).astype(np.uint8)[: off + n]
+    d = gpu.from_numpy(x).cuda()
+    v, c = redio.kpn_dev.Rle().feed(d[off:])
+    want = oracle.Rle().feed(x[off:])
+    assert list(zip(v.cpu().tolist(), c.cpu().tolist())) == want
+
+
 def test_dle_rld_dld_round_trip(gpu, redio, oracle):
     runs = [(1, 51), (0, 512), (1, 90), (0, 1), (1, 1000)]
     vals = gpu.tensor([r[0] for r in runs], dtype=gpu.uint8, device="cuda")

@@ -74,3 +74,25 @@ if "hipfft" in which:
         out = torch.empty_like(x)
         ms = timeit(lambda: torch.fft.fft(x, dim=1, out=out), n=20, warm=3)
         print(f"vendor FFT (torch.fft -> hipFFT) {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  ({16*x.numel()/ms/1e6/8000:.1%} of 8 TB/s)")
+if "ingest" in which:
+    # the u8 front end of the shipped graph and the run-length stage
+    from libredio_amd import bitfount as B, kpn_dev as K
+    nb = 1 << 29                                            # bytes = 2^28 IQ samples
+    raw = torch.randint(0, 256, (nb,), dtype=torch.uint8, device="cuda")
+    ns = nb // 2
+    ms = timeit(lambda: B.data_to_samples(raw), n=10, warm=2)
+    print(f"data_to_samples u8->cf32: {ms:.3f} ms  {ns/ms/1e6:.1f} GS/s  {10*ns/ms/1e6:.0f} GB/s algorithmic ({10*ns/ms/1e6/8000:.1%})")
+    ms = timeit(lambda: B.ingest_mag(raw), n=10, warm=2)
+    print(f"ingest u8->|x| fused: {ms:.3f} ms  {ns/ms/1e6:.1f} GS/s  {6*ns/ms/1e6:.0f} GB/s algorithmic ({6*ns/ms/1e6/8000:.1%})")
+    mag = B.ingest_mag(raw)
+    ms = timeit(lambda: B.block_sums(mag, 512), n=10, warm=2)
+    print(f"block sums (512, sequential order): {ms:.3f} ms  {ns/ms/1e6:.1f} GS/s  {4*ns/ms/1e6:.0f} GB/s ({4*ns/ms/1e6/8000:.1%})")
+    ms = timeit(lambda: B.discretize(mag), n=10, warm=2)
+    print(f"discretize (max + threshold): {ms:.3f} ms  {ns/ms/1e6:.1f} GS/s  {(4+4+1)*ns/ms/1e6:.0f} GB/s ({9*ns/ms/1e6/8000:.1%})")
+    bits = (torch.rand(ns, device="cuda") > 0.97).to(torch.uint8)   # sparse changes, like a sliced burst
+    r = K.Rle()
+    ms = timeit(lambda: r.feed(bits), n=10, warm=2)
+    print(f"rle (u8 stream, ~6% changes): {ms:.3f} ms  {ns/ms/1e6:.1f} G values/s")
+    c = R.synth_f32(5, 0, ns)
+    ms = timeit(lambda: K.mul_vecs(mag, c), n=10, warm=2)
+    print(f"mul_vecs f32: {ms:.3f} ms  {ns/ms/1e6:.1f} GS/s  {12*ns/ms/1e6:.0f} GB/s ({12*ns/ms/1e6/8000:.1%})")
