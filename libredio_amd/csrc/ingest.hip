@@ -17,18 +17,33 @@
 
 namespace redio {
 
-__device__ __forceinline__ float i2f(unsigned b) { return (float)b / 127.0f - 1.0f; } // rtlsdr.rs:159
+// rtlsdr.rs:159: i as f32 / 127.0 - 1.0.  The IEEE quotient without the division sequence: q0 = b*r with
+// r = fl(1/127), one residual step e = b - 127*q0 (exact in an FMA), q = q0 + e*r.  This is the correctly
+// rounded b/127 for every byte b -- the domain has 256 points and tests/test_gpu_ingest.py checks all of
+// them against the oracle's plain division.
+__device__ __forceinline__ float i2f(unsigned b)
+{
+    const float fb = (float)b, r = 1.0f / 127.0f;
+    const float q0 = mul_rn(fb, r);
+    const float e = fma_rn(-q0, 127.0f, fb);
+    return sub_rn(fma_rn(e, r, q0), 1.0f);
+}
 __device__ __forceinline__ float norm_f32(float re, float im)
 {
     return (float)sqrt((double)re * (double)re + (double)im * (double)im);
 }
 
-// 4 samples (8 bytes) per thread iteration
+// two samples per lane step: one 4-byte load, one 16-byte store (1 KiB contiguous per wave instruction)
 __global__ __launch_bounds__(256) void data_to_samples_kernel(const uint8_t *__restrict__ d, float2 *__restrict__ out, long nsamp)
 {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nsamp; i += stride)
-        out[i] = make_float2(i2f(d[2 * i]), i2f(d[2 * i + 1]));
+    const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = ((uintptr_t)d & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    const long n2 = aligned ? nsamp / 2 : 0;
+    for (long q = tid; q < n2; q += stride) {
+        const unsigned w = reinterpret_cast<const unsigned *>(d)[q];
+        reinterpret_cast<float4 *>(out)[q] = make_float4(i2f(w & 255u), i2f((w >> 8) & 255u), i2f((w >> 16) & 255u), i2f(w >> 24));
+    }
+    for (long i = 2 * n2 + tid; i < nsamp; i += stride) out[i] = make_float2(i2f(d[2 * i]), i2f(d[2 * i + 1]));
 }
 
 __global__ __launch_bounds__(256) void norm_kernel(const float2 *__restrict__ x, float *__restrict__ out, long n)
