@@ -50,6 +50,17 @@ int redio_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int redio_stream_create(void **stream);
 int redio_stream_destroy(void *stream);
 int redio_stream_sync(void *stream); /* NULL = default stream */
+/* Launch graphs for launch-bound pipelines (many small messages): every *_enqueue below only launches
+ * kernels on the given stream -- no allocation, no synchronisation -- so a sequence of them can be
+ * recorded once between redio_graph_begin/end on a stream created by redio_stream_create and replayed
+ * with one submission.  Pointers and sizes are baked in: replay on the same buffers.  Run the sequence
+ * once un-captured first: plans size their internal scratch on first use.
+ * (redio_src_process synchronises and is not capturable; redio_*_create / *_destroy never are.) */
+typedef struct redio_graph redio_graph;
+int redio_graph_begin(void *stream);
+int redio_graph_end(void *stream, redio_graph **g);
+int redio_graph_launch(redio_graph *g, void *stream);
+int redio_graph_destroy(redio_graph *g);
 int redio_event_create(void **event);
 int redio_event_destroy(void *event);
 int redio_event_record(void *event, void *stream);

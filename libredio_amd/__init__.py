@@ -94,6 +94,10 @@ def lib():
     _sig(L.redio_chain_set_variant, i, vp, i)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
     pl = C.POINTER(C.c_long)
+    _sig(L.redio_graph_begin, i, vp)
+    _sig(L.redio_graph_end, i, vp, C.POINTER(vp))
+    _sig(L.redio_graph_launch, i, vp, vp)
+    _sig(L.redio_graph_destroy, i, vp)
     _sig(L.redio_src_create, i, C.POINTER(vp), i, i)
     _sig(L.redio_src_destroy, i, vp)
     _sig(L.redio_src_reset, i, vp)
@@ -185,4 +189,4 @@ def check(code, what="redio"):
 
 
 from . import bitfount, dsputils, kissfft, kpn_dev, plans, samplerate  # noqa: E402,F401
-from .plans import Chain, Channelizer, Fft, Fir, OverlapSave, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from .plans import Chain, Channelizer, Fft, Fir, Graph, OverlapSave, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401

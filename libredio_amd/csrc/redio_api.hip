@@ -82,6 +82,45 @@ extern "C" int redio_stream_create(void **stream)
 }
 extern "C" int redio_stream_destroy(void *stream) { return stream ? hip_rc(hipStreamDestroy((hipStream_t)stream)) : REDIO_OK; }
 extern "C" int redio_stream_sync(void *stream) { return hip_rc(hipStreamSynchronize((hipStream_t)stream)); }
+// ---- launch graphs: record the *_enqueue calls of a block pipeline once, replay them with one submission ----
+struct redio_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+extern "C" int redio_graph_begin(void *stream)
+{
+    if (!stream) return REDIO_ERR_ARG; // the default stream cannot be captured
+    return hip_rc(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+}
+extern "C" int redio_graph_end(void *stream, redio_graph **g)
+{
+    if (!stream || !g) return REDIO_ERR_ARG;
+    *g = nullptr;
+    hipGraph_t graph = nullptr;
+    RD_TRY(hipStreamEndCapture((hipStream_t)stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(graph); return hip_rc(e); }
+    redio_graph *r = new (std::nothrow) redio_graph();
+    if (!r) { hipGraphExecDestroy(exec); hipGraphDestroy(graph); return REDIO_ERR_NOMEM; }
+    r->graph = graph; r->exec = exec;
+    *g = r;
+    return REDIO_OK;
+}
+extern "C" int redio_graph_launch(redio_graph *g, void *stream)
+{
+    if (!g) return REDIO_ERR_ARG;
+    return hip_rc(hipGraphLaunch(g->exec, (hipStream_t)stream));
+}
+extern "C" int redio_graph_destroy(redio_graph *g)
+{
+    if (!g) return REDIO_OK;
+    hipGraphExecDestroy(g->exec);
+    hipGraphDestroy(g->graph);
+    delete g;
+    return REDIO_OK;
+}
+
 extern "C" int redio_event_create(void **event)
 {
     if (!event) return REDIO_ERR_ARG;

@@ -166,6 +166,50 @@ class Src:
             self._h = None
 
 
+class Graph:
+    """redio_graph_*: record the enqueue calls issued inside the `with` block on a side stream and replay
+    them with one submission (launch-bound pipelines of many small messages).  Allocate every output
+    before entering and run the sequence once un-captured first.
+
+        g = Graph()
+        with g:                      # torch's current stream is the capture stream inside the block
+            for i in range(64):
+                fir(x[i], out=y[i]); fft(y[i], out=z[i])
+        g.launch(); g.launch()
+    """
+
+    def __init__(self):
+        import torch
+        self.stream = torch.cuda.Stream()
+        self._g = C.c_void_p()
+        self._ctx = None
+
+    def __enter__(self):
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        check(lib().redio_graph_begin(C.c_void_p(self.stream.cuda_stream)), "graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().redio_graph_end(C.c_void_p(self.stream.cuda_stream), C.byref(self._g))
+        self._ctx.__exit__(et, ev, tb)
+        self._ctx = None
+        if et is None:
+            check(rc, "graph_end")
+        return False
+
+    def launch(self, stream=None):
+        """Replay on `stream` (default: torch's current stream)."""
+        check(lib().redio_graph_launch(self._g, current_stream() if stream is None else C.c_void_p(stream.cuda_stream)), "graph_launch")
+
+    def __del__(self, _safe_destroy=_safe_destroy):
+        if getattr(self, "_g", None):
+            _safe_destroy("redio_graph_destroy", self._g)
+            self._g = None
+
+
 def synth_iq(seed, first, n, device="cuda"):
     """Hash-generated cf32 IQ in [-1,1), generated on the device."""
     import torch

@@ -96,3 +96,24 @@ if "ingest" in which:
     c = R.synth_f32(5, 0, ns)
     ms = timeit(lambda: K.mul_vecs(mag, c), n=10, warm=2)
     print(f"mul_vecs f32: {ms:.3f} ms  {ns/ms/1e6:.1f} GS/s  {12*ns/ms/1e6:.0f} GB/s ({12*ns/ms/1e6/8000:.1%})")
+if "graph" in which:
+    # launch-bound: 256 messages of one 1024-point block each, FIR kernel + FFT kernel per message
+    import time
+    taps = R.dsputils.lpf_corrected(127, 0.08)
+    nmsg, n_in = 256, 5120 + 126
+    d = R.synth_iq(7, 0, nmsg * n_in).view(nmsg, n_in)
+    fir, fft = R.Fir(taps, 5, fused=True), R.Fft(1024)
+    y = torch.empty((nmsg, 1024), dtype=torch.complex64, device="cuda"); z = torch.empty_like(y)
+    def run():
+        for i in range(nmsg):
+            fir(d[i], out=y[i]); fft(y[i], out=z[i])
+    run(); torch.cuda.synchronize()
+    g = R.Graph()
+    with g:
+        run()
+    def wall(f, n=20):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): f()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+    a, b = wall(run), wall(g.launch)
+    print(f"{2*nmsg} small launches: direct {a*1e3:.2f} ms ({a/nmsg/2*1e6:.1f} us per launch), graph replay {b*1e3:.3f} ms ({b/nmsg/2*1e6:.2f} us per launch)")
