@@ -391,6 +391,7 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
         if (variant == 0 && aligned) return launch_chain_v4(x, taps, p.tw, out, nblocks, fused, 2, s, g_chain_dbg);
         if (variant >= 7 && variant <= 10 && aligned && queue) return launch_chain_v5(x, taps, p.tw, out, nblocks, fused, variant - 7, queue, s);
         if (variant == 5 && aligned) return launch_chain_v4(x, taps, p.tw, out, nblocks, fused, 3, s, g_chain_dbg);
+        if (variant == 31 && aligned) return launch_chain_v4(x, taps, p.tw, out, nblocks, fused, 12, s, g_chain_dbg);
         if (variant == 6 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
         if (variant == 3 && aligned) return launch_chain_v3<127, 5, 3, 6>(p, x, taps, out, nblocks, fused, s);
         if (variant == 4 && aligned) return launch_chain_v3<127, 5, 3, 8>(p, x, taps, out, nblocks, fused, s);

@@ -25,7 +25,7 @@ __device__ __forceinline__ void static_for4(F &&f)
 
 // FIR_ONLY: the same data movement and FIR, but the decimated samples are stored instead of transformed
 // (the stand-alone decimating FIR of redio_fir_* for this shape); `out` then holds 1024 outputs per block.
-template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false>
+template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false>
 __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
                                                            const float2 *__restrict__ tw, float2 *__restrict__ out,
                                                            long nblocks, long blocks_per_wave, unsigned long long *dbg)
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     float2 a[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = make_float2(0.f, 0.f);
+    // the 15 lane-dependent twiddles of the last two stages stay in registers for the life of the wave
+    Fft1knTw34 t34;
+    if (!FIR_ONLY && TWP) fft1kn_load_tw34(t34, lane, tw);
 #pragma unroll 1
     for (long j = 0; j < nsub; ++j) {
         const bool more = j + 1 < nsub;
@@ -101,7 +104,10 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
             wave_lds_fence();
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            fft1kn_wave<false>(a, ex, tw, out + (b0 + (j >> 2)) * 1024, ln);
+            Fft1knTw12 t12;
+            fft1kn_load_tw12(t12, ln, tw);
+            if (!TWP) fft1kn_load_tw34(t34, ln, tw);
+            fft1kn_wave_tw<false>(a, ex, tw, t12, t34, out + (b0 + (j >> 2)) * 1024, ln);
             wave_lds_fence();
         }
         if (more) {
@@ -134,7 +140,7 @@ static int num_cus_v4()
     return cus;
 }
 
-template <int K, int D, int WPS, int CH, bool FIR_ONLY = false>
+template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false>
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg)
 {
@@ -152,8 +158,8 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     if (waves > nblocks) waves = nblocks;
     const long bpw = (nblocks + waves - 1) / waves;
     const long grid = (nblocks + bpw - 1) / bpw;
-    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
-    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
     return hipGetLastError();
 }
 
@@ -161,7 +167,8 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
                            hipStream_t s, unsigned long long *dbg)
 {
     if (wps == 3) return launch_v4_t<127, 5, 3, 6>(x, taps, tw, out, nblocks, fused, s, dbg);
-    return launch_v4_t<127, 5, 2, 8>(x, taps, tw, out, nblocks, fused, s, dbg);
+    if (wps == 12) return launch_v4_t<127, 5, 2, 8, false, false>(x, taps, tw, out, nblocks, fused, s, dbg); // twiddles reloaded per block (A/B)
+    return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg); // last-stage twiddles resident
 }
 
 // stand-alone 127-tap decimate-by-5 FIR on whole 1024-output blocks (16-byte aligned cf32 in and out)

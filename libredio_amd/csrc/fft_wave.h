@@ -78,15 +78,14 @@ namespace redio {
 // y[256 s + 4 lane + r] on entry (the FIR's own register layout), ex is FFT1KN_LDS float2 of LDS owned
 // by this wave, dst the block's spectrum in global memory (natural order).
 template <bool INV>
-__device__ __forceinline__ void fft1kn_wave(float2 (&a)[16], float2 *ex, const float2 *__restrict__ tw, float2 *dst, int ln)
+__device__ __forceinline__ void fft1kn_wave_tw(float2 (&a)[16], float2 *ex, const float2 *__restrict__ tw, const Fft1knTw12 &t12,
+                                               const Fft1knTw34 &t34, float2 *dst, int ln)
 {
     fft1kn_stage0<INV>(a, tw);
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
         for (int d0 = 0; d0 < 4; ++d0) ex[fft1kn_x1_store(ln, k4, d0)] = a[4 * k4 + d0];
-    Fft1knTw12 t12;
-    fft1kn_load_tw12(t12, ln, tw);
     wave_lds_fence();
 #pragma unroll
     for (int e = 0; e < 16; ++e) a[e] = ex[fft1kn_x1_load(ln, e)];
@@ -96,8 +95,6 @@ __device__ __forceinline__ void fft1kn_wave(float2 (&a)[16], float2 *ex, const f
     for (int k3 = 0; k3 < 4; ++k3)
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) ex[fft1kn_x2_store(ln, k2, k3)] = a[k2 + 4 * k3];
-    Fft1knTw34 t34;
-    fft1kn_load_tw34(t34, ln, tw);
     wave_lds_fence();
 #pragma unroll
     for (int f = 0; f < 16; ++f) a[f] = ex[fft1kn_x2_load(ln, f)];
@@ -107,6 +104,18 @@ __device__ __forceinline__ void fft1kn_wave(float2 (&a)[16], float2 *ex, const f
     for (int k0 = 0; k0 < 4; ++k0)
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) dst[ln + 64 * k1 + 256 * k0] = a[k1 + 4 * k0];
+}
+
+// the same with the 30 lane-dependent twiddles loaded here (callers that transform many blocks load them
+// once and call fft1kn_wave_tw)
+template <bool INV>
+__device__ __forceinline__ void fft1kn_wave(float2 (&a)[16], float2 *ex, const float2 *__restrict__ tw, float2 *dst, int ln)
+{
+    Fft1knTw12 t12;
+    Fft1knTw34 t34;
+    fft1kn_load_tw12(t12, ln, tw);
+    fft1kn_load_tw34(t34, ln, tw);
+    fft1kn_wave_tw<INV>(a, ex, tw, t12, t34, dst, ln);
 }
 
 } // namespace redio
