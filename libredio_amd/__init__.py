@@ -189,4 +189,4 @@ def check(code, what="redio"):
 
 
 from . import bitfount, dsputils, kissfft, kpn_dev, plans, samplerate  # noqa: E402,F401
-from .plans import Chain, Channelizer, Fft, Fir, Graph, OverlapSave, Src, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from .plans import Chain, Channelizer, Fft, Fir, Graph, OverlapSave, Src, channelizer_all_to_all, current_stream, synth_f32, synth_iq  # noqa: E402,F401

@@ -66,3 +66,25 @@ def test_channelizer_full_size_properties(gpu, redio, oracle):
     s1 = gpu.view_as_real(out).view(gpu.int32).sum(dtype=gpu.int64).item()
     assert gpu.equal(plan(x * 0.5), out * 0.5)
     assert gpu.view_as_real(plan(x)).view(gpu.int32).sum(dtype=gpu.int64).item() == s1
+
+
+def test_exchange_runs_on_rccl_with_device_tensors(gpu, redio, oracle):
+    """The channelizer's one collective on the real backend: torch.distributed "nccl" IS RCCL on ROCm.  One
+    GPU here, so world_size 1 (the multi-rank regrouping itself is covered with gloo in test_multi_rank_cpu.py);
+    this checks that the device-tensor path through RCCL works: grouped kernel output in, [rows][channels] out."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu.device("cuda", 0))
+    try:
+        M, P = 64, 16
+        h = oracle.lpf_corrected(M * P, 0.45 / M)
+        x = oracle.synth_iq(0x5EED0004, 0, M * 200)
+        plan = redio.Channelizer(h)
+        grouped = plan(gpu.from_numpy(x).cuda(), ngroups=1).reshape(1, -1, M)
+        mine = redio.channelizer_all_to_all(grouped)
+        want = oracle.pfb_channelizer(x, h, M, P, True)
+        assert np.array_equal(mine.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    finally:
+        dist.destroy_process_group()
