@@ -53,6 +53,87 @@ __global__ __launch_bounds__(NT) void fir_tiled_kernel(const T *__restrict__ x, 
     }
 }
 
+// ---- chunked tiled kernel: ANY tap count, decimation from a small compile-time set ---------------
+// The register blocking of fir_core.h needs compile-time tap indices; here the taps are walked in chunks of
+// CH = 16 with a run-time chunk count instead: per chunk a lane reads the CH + (R-1)*D samples its R outputs
+// need for these taps (statically indexed registers), the 16 taps arrive as one scalar load, and the
+// multiply-adds are fully unrolled inside the chunk.  Every accumulator still receives its products in
+// ascending tap order (chunks ascending, taps ascending inside a chunk), so results are bit-identical to the
+// reference fold.  The last, partial chunk runs the same code with a wave-uniform guard per tap.
+template <typename T, int D, int R, bool FUSED, bool GUARD>
+__device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, int K, const float *__restrict__ taps, T (&acc)[R])
+{
+    constexpr int CH = 16, WIN = CH + (R - 1) * D, LSTR = R * D;
+    constexpr bool PAD = (LSTR % 2) == 0;
+    T xv[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+        const int m = j0 + i; // wave-uniform
+        xv[i] = xs[base + (PAD ? m + m / LSTR : m)];
+    }
+    float h[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) h[j] = (!GUARD || j0 + j < K) ? taps[j0 + j] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < WIN; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = i - r * D;
+            if (j >= 0 && j < CH) {
+                if (!GUARD || j0 + j < K) acc[r] = mac<FUSED>(xv[i], h[j], acc[r]);
+            }
+        }
+}
+
+template <typename T, int D, int R, bool FUSED>
+__global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ x, long n_in, const float *__restrict__ taps, int K,
+                                                          T *__restrict__ y, long n_out)
+{
+    constexpr int NT = 256, CH = 16, TILE_OUT = NT * R, LSTR = R * D;
+    constexpr bool PAD = (LSTR % 2) == 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *xs = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x;
+    const int kc = (K + CH - 1) / CH * CH;
+    const int tile_in = (TILE_OUT - 1) * D + kc;
+    const long in0 = (long)blockIdx.x * TILE_OUT * D;
+#pragma unroll 4
+    for (int n = tid; n < tile_in; n += NT) {
+        T v{};
+        if (in0 + n < n_in) v = x[in0 + n];
+        xs[PAD ? n + n / LSTR : n] = v;
+    }
+    __syncthreads();
+    T acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = T{};
+    const int base = tid * (LSTR + (PAD ? 1 : 0));
+    const int nfull = K / CH;
+    for (int c = 0; c < nfull; ++c) fir_chunk<T, D, R, FUSED, false>(xs, base, c * CH, K, taps, acc);
+    if (nfull * CH < K) fir_chunk<T, D, R, FUSED, true>(xs, base, nfull * CH, K, taps, acc);
+    const long o0 = (long)blockIdx.x * TILE_OUT + (long)tid * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (o0 + r < n_out) y[o0 + r] = acc[r];
+}
+
+template <typename T, int D, int R, bool FUSED>
+static hipError_t launch_chunked(const T *x, long n_in, const float *taps, int K, T *y, long n_out, hipStream_t s)
+{
+    constexpr int TILE_OUT = 256 * R, LSTR = R * D;
+    const int kc = (K + 15) / 16 * 16;
+    const long tile_in = (long)(TILE_OUT - 1) * D + kc;
+    const size_t lds = (size_t)(tile_in + ((LSTR % 2) == 0 ? tile_in / LSTR : 0) + 2) * sizeof(T);
+    if (lds > 150 * 1024) return hipErrorNotSupported;
+    auto kern = fir_chunked_kernel<T, D, R, FUSED>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_out + TILE_OUT - 1) / TILE_OUT)), dim3(256), lds, s, x, n_in, taps, K, y, n_out);
+    return hipGetLastError();
+}
+
 // ---- direct kernel: any K and D, no tile (L1/L2 serve the overlap); one output per thread -------
 template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void fir_direct_kernel(const T *__restrict__ x, const float *__restrict__ taps,
@@ -94,6 +175,20 @@ static hipError_t launch_fir_t(const T *x, long n_in, const float *taps, int K, 
     if (K == 127 && D == 1) return launch_tiled<T, 127, 1, 8, FUSED>(x, n_in, taps, y, n_out, s);
     if (K == 63 && D == 1) return launch_tiled<T, 63, 1, 8, FUSED>(x, n_in, taps, y, n_out, s);
     if (K == 63 && D == 5) return launch_tiled<T, 63, 5, 4, FUSED>(x, n_in, taps, y, n_out, s);
+    {   // any tap count with a common decimation: the chunked tiled kernel (falls through if the tile cannot fit LDS)
+        hipError_t e = hipErrorNotSupported;
+        switch (D) {
+        case 1: e = launch_chunked<T, 1, 8, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 2: e = launch_chunked<T, 2, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 3: e = launch_chunked<T, 3, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 4: e = launch_chunked<T, 4, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 5: e = launch_chunked<T, 5, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 8: e = launch_chunked<T, 8, 2, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 10: e = launch_chunked<T, 10, 2, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        default: break;
+        }
+        if (e != hipErrorNotSupported) return e;
+    }
     const long nb = (n_out + 255) / 256;
     hipLaunchKernelGGL((fir_direct_kernel<T, FUSED>), dim3((unsigned)nb), dim3(256), 0, s, x, taps, K, D, y, n_out);
     return hipGetLastError();

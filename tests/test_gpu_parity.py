@@ -55,7 +55,9 @@ def test_convolve_with_quirk_lpf_taps_nan_position(gpu, redio, oracle):
 
 
 # ---------------------------------------------------------------- device FIR
-FIR_CASES = [(127, 5), (127, 1), (63, 1), (63, 5), (3, 1), (33, 2), (200, 7), (1, 1)]
+FIR_CASES = [(127, 5), (127, 1), (63, 1), (63, 5), (3, 1), (33, 2), (200, 7), (1, 1),
+             # the chunked kernel: whole and partial 16-tap chunks for every compiled decimation, and its neighbours
+             (64, 1), (16, 1), (15, 1), (17, 1), (100, 3), (48, 4), (31, 5), (129, 8), (255, 10), (2, 2), (40, 6), (1000, 1)]
 
 
 @pytest.mark.parametrize("k,d", FIR_CASES)

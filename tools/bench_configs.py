@@ -117,3 +117,16 @@ if "graph" in which:
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
     a, b = wall(run), wall(g.launch)
     print(f"{2*nmsg} small launches: direct {a*1e3:.2f} ms ({a/nmsg/2*1e6:.1f} us per launch), graph replay {b*1e3:.3f} ms ({b/nmsg/2*1e6:.2f} us per launch)")
+if "firshapes" in which:
+    # generality of the FIR: specialised shapes vs the direct kernel (any K, D)
+    m = 1 << 26
+    xc = R.synth_iq(1, 0, m); xr = R.synth_f32(1, 0, m)
+    for (k, d, cplx) in ((127, 5, True), (127, 1, True), (63, 5, True), (63, 5, False), (127, 1, False), (63, 1, False), (63, 1, True), (64, 1, True), (101, 3, True), (31, 2, True), (255, 10, True), (1023, 1, True), (8193, 1, True)):
+        taps = R.dsputils.lpf_corrected(k, 0.4 / d if d > 1 else 0.2)
+        plan = R.Fir(taps, d, complex_input=cplx, fused=True)
+        x = xc if cplx else xr
+        out = torch.empty(plan.nout(m), dtype=x.dtype, device="cuda")
+        ms = timeit(lambda: plan(x, out=out), n=5, warm=2)
+        b = (8 if cplx else 4) * (1 + 1 / d)
+        fl = (4 if cplx else 2) * k / d
+        print(f"FIR K={k} D={d} {'cf32' if cplx else 'f32'}: {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  {b*m/ms/1e6/8000:.1%} of HBM roofline, {fl*m/ms/1e9:.1f} TFLOP/s")
