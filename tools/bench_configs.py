@@ -130,3 +130,15 @@ if "firshapes" in which:
         b = (8 if cplx else 4) * (1 + 1 / d)
         fl = (4 if cplx else 2) * k / d
         print(f"FIR K={k} D={d} {'cf32' if cplx else 'f32'}: {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  {b*m/ms/1e6/8000:.1%} of HBM roofline, {fl*m/ms/1e9:.1f} TFLOP/s")
+if "srcgen" in which:
+    # the general (non-uniform phase) resampler path: arbitrary ratios, one launch per buffer refill
+    import time
+    nch, frames = 64, 1 << 18
+    x = torch.stack([R.synth_f32(100 + c, 0, frames) for c in range(nch)])
+    for ratio in (0.02, 0.0213, 0.5, 48000 / 44100, 2.0):
+        plan = R.Src(nch, 1)
+        plan.process(x, ratio)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out, used = plan.process(x, ratio)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"resample ratio {ratio:.5f} x{nch} ch, {frames} frames: {dt*1e3:.2f} ms  {nch*used/dt/1e9:.3f} GS/s in, {out.shape[1]} out per channel")
