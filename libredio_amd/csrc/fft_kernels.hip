@@ -235,6 +235,142 @@ __global__ __launch_bounds__(256) void fft64_kernel(const float2 *in, float2 *ou
     }
 }
 
+// ---- small powers of two and N = 2 * 4^L (2, 4, 8, 16, 32, 128, 512, 2048, 8192): compile-time stages in LDS
+// kissfft factors 2 * 4^L as 4, 4, ..., 4, 2 with the radix-2 stage innermost.  One 256-thread workgroup
+// handles 4096 points (8192 for the largest size): max(1, 4096 / N) transforms.  Coalesced load with the
+// digit reversal applied on the LDS side, then register passes over LDS (one pad float2 per 8 keeps the
+// 8-point first pass conflict-free): [radix-2 + radix-4 on 8 consecutive positions], then pairs of radix-4
+// stages on 16 points per thread, a single radix-4 stage if one is left, coalesced store.  Every index is
+// a compile-time shift; butterflies, twiddle indices and stage order are kissfft's (bit-identical).
+template <int LOG2N>
+struct FftP2 {
+    static constexpr int N = 1 << LOG2N, L4 = LOG2N / 2;
+    static constexpr bool ODD = (LOG2N & 1) != 0; // a radix-2 stage innermost
+    static constexpr int E = N >= 4096 ? N : 4096; // points per workgroup
+    static constexpr int T = E / N;                // transforms per workgroup
+    __device__ static __forceinline__ int phys(int e) { return e + (e >> 3); }
+    static constexpr int LDS_ELEMS = E + (E >> 3) + 8;
+    // leaf position of input index n: the top bit is the radix-2 digit, base-4 digits reverse onto N/4, N/16, ...
+    __device__ static __forceinline__ int leaf_pos(int n)
+    {
+        int P = ODD ? n >> (2 * L4) : 0;
+#pragma unroll
+        for (int i = 0; i < L4; ++i) P += ((n >> (2 * i)) & 3) * (N >> (2 * i + 2));
+        return P;
+    }
+};
+
+template <int LOG2N, bool INV, int M>
+__device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict__ tw, int tid)
+{
+    using F = FftP2<LOG2N>;
+    constexpr int N = F::N, E = F::E;
+    if constexpr (M * 4 <= N / 4) { // two stages: sub-lengths M and 4M on 16 points base + j*M
+        constexpr int FS = N / (4 * M), FS2 = N / (16 * M);
+#pragma unroll 1
+        for (int g = tid; g < E / 16; g += 256) {
+            const int xf = g / (N / 16), gl = g % (N / 16);
+            const int blk = gl / M, kk = gl % M;
+            const int base = xf * N + blk * 16 * M + kk;
+            float2 a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = Ls[F::phys(base + j * M)];
+            const float2 t1 = tw[kk * FS], t2 = tw[2 * kk * FS], t3 = tw[3 * kk * FS];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k2 = kk + u * M;
+                bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k2 * FS2], tw[2 * k2 * FS2], tw[3 * k2 * FS2]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Ls[F::phys(base + j * M)] = a[j];
+        }
+        __syncthreads();
+        fftp2_rest<LOG2N, INV, 16 * M>(Ls, tw, tid);
+    } else if constexpr (M <= N / 4) { // one stage left
+        constexpr int FS = N / (4 * M);
+#pragma unroll 1
+        for (int g = tid; g < E / 4; g += 256) {
+            const int xf = g / (N / 4), gl = g % (N / 4);
+            const int blk = gl / M, kk = gl % M;
+            const int base = xf * N + blk * 4 * M + kk;
+            float2 a0 = Ls[F::phys(base)], a1 = Ls[F::phys(base + M)], a2 = Ls[F::phys(base + 2 * M)], a3 = Ls[F::phys(base + 3 * M)];
+            bfly4<INV>(a0, a1, a2, a3, tw[kk * FS], tw[2 * kk * FS], tw[3 * kk * FS]);
+            Ls[F::phys(base)] = a0; Ls[F::phys(base + M)] = a1; Ls[F::phys(base + 2 * M)] = a2; Ls[F::phys(base + 3 * M)] = a3;
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOG2N, bool INV>
+__global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch, long in_stride)
+{
+    using F = FftP2<LOG2N>;
+    constexpr int N = F::N, E = F::E, T = F::T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *Ls = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const long b0 = (long)blockIdx.x * T;
+#pragma unroll 4
+    for (int e = tid; e < E; e += 256) {
+        const int xf = e / N, n = e % N;
+        const long b = (b0 + xf < nbatch) ? b0 + xf : nbatch - 1;
+        Ls[F::phys(xf * N + F::leaf_pos(n))] = in[b * in_stride + n];
+    }
+    __syncthreads();
+    if constexpr (!F::ODD) {
+        fftp2_rest<LOG2N, INV, 1>(Ls, tw, tid); // powers of four: stages m = 1, 4, ... straight away
+    } else if constexpr (N == 2) {
+        for (int g = tid; g < E / 2; g += 256) {
+            float2 a0 = Ls[F::phys(2 * g)], a1 = Ls[F::phys(2 * g + 1)];
+            bfly2(a0, a1, tw[0]);
+            Ls[F::phys(2 * g)] = a0; Ls[F::phys(2 * g + 1)] = a1;
+        }
+        __syncthreads();
+    } else {
+        // first pass: radix-2 (m = 1) then radix-4 (m = 2) on 8 consecutive positions
+        constexpr int FS = N / 8;
+        const float2 one = tw[0], w1 = tw[FS], w2 = tw[2 * FS], w3 = tw[3 * FS];
+#pragma unroll 1
+        for (int g = tid; g < E / 8; g += 256) {
+            float2 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = Ls[F::phys(8 * g + j)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bfly2(a[2 * q], a[2 * q + 1], one);
+            bfly4<INV>(a[0], a[2], a[4], a[6], one, one, one);
+            bfly4<INV>(a[1], a[3], a[5], a[7], w1, w2, w3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ls[F::phys(8 * g + j)] = a[j];
+        }
+        __syncthreads();
+        fftp2_rest<LOG2N, INV, 8>(Ls, tw, tid);
+    }
+#pragma unroll 4
+    for (int e = tid; e < E; e += 256) {
+        const int xf = e / N;
+        if (b0 + xf < nbatch) out[(b0 + xf) * N + (e % N)] = Ls[F::phys(e)];
+    }
+}
+
+template <int LOG2N>
+static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, bool inv, hipStream_t s)
+{
+    using F = FftP2<LOG2N>;
+    const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
+    auto kf = fft_p2_kernel<LOG2N, false>;
+    auto ki = fft_p2_kernel<LOG2N, true>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned grid = (unsigned)((nbatch + F::T - 1) / F::T);
+    if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, tw, nbatch, in_stride);
+    else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, tw, nbatch, in_stride);
+    return hipGetLastError();
+}
+
 // ---- any N that fits LDS: one workgroup per transform ----------------------------------------
 template <bool INV>
 __global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2 *in,
@@ -448,6 +584,18 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
+    }
+    switch (p.nfft) { // 2 * 4^L, and the two powers of four below 64
+    case 2: return launch_fft_p2<1>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 4: return launch_fft_p2<2>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 8: return launch_fft_p2<3>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 16: return launch_fft_p2<4>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 32: return launch_fft_p2<5>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 128: return launch_fft_p2<7>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 512: return launch_fft_p2<9>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 2048: return launch_fft_p2<11>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 8192: return launch_fft_p2<13>(in, out, p.tw, nbatch, in_stride, inv, s);
+    default: break;
     }
     if (p.nfft == 64) {
         const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
