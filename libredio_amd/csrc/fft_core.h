@@ -383,4 +383,31 @@ RD_HD void f64k_tile_butterfly(Ptr L, TwPtr tw, int pass, int t, int col, int b,
     L[(base + 2 * m) * F64K_LD + col] = a2; L[(base + 3 * m) * F64K_LD + col] = a3;
 }
 
+// two in-tile stages t and t+1 (t = 0 or 2) in registers: group grp (0..15) of column `col` = the 16 rows
+// base + j*m, base = blk*16m + kk.  Same butterflies and twiddles as two calls of f64k_tile_butterfly per row.
+template <bool INV, typename Ptr, typename TwPtr>
+RD_HD void f64k_tile_macro(Ptr L, TwPtr tw, int pass, int t, int col, int grp, int k0)
+{
+    const int m = 1 << (2 * t);
+    const int blk = grp >> (2 * t), kk = grp & (m - 1);
+    const int base = blk * 16 * m + kk;
+    float2 a[16];
+    for (int j = 0; j < 16; ++j) a[j] = L[(base + j * m) * F64K_LD + col];
+    {
+        const int k = pass == 0 ? kk : k0 + 256 * kk;
+        const int fs = pass == 0 ? (16384 >> (2 * t)) : (64 >> (2 * t));
+        const float2 t1 = tw[k * fs], t2 = tw[2 * k * fs], t3 = tw[3 * k * fs];
+        for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+    }
+    {
+        const int fs = pass == 0 ? (16384 >> (2 * t + 2)) : (64 >> (2 * t + 2));
+        for (int u = 0; u < 4; ++u) {
+            const int k1 = kk + u * m; // index inside the 4m-block
+            const int k = pass == 0 ? k1 : k0 + 256 * k1;
+            bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs]);
+        }
+    }
+    for (int j = 0; j < 16; ++j) L[(base + j * m) * F64K_LD + col] = a[j];
+}
+
 } // namespace redio

@@ -450,10 +450,10 @@ __global__ __launch_bounds__(256) void fft64k_pass_kernel(const float2 *in, floa
     }
     __syncthreads();
     const int col = tid & 15;
+    // four stages as two register passes of two stages each (16 rows per thread)
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<INV>(L, tw, PASS, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+    for (int t = 0; t < 4; t += 2) {
+        f64k_tile_macro<INV>(L, tw, PASS, t, col, tid >> 4, F64K_COLS * c + col);
         __syncthreads();
     }
     if (PASS == 0) {
@@ -501,10 +501,10 @@ __global__ __launch_bounds__(256) void ovsave64k_mid_kernel(const float2 *__rest
     }
     __syncthreads();
     const int col = tid & 15;
+    // four stages as two register passes of two stages each (16 rows per thread)
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) { // forward stages m = 256 .. 16384
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<false>(L, tw_f, 1, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+    for (int t = 0; t < 4; t += 2) {
+        f64k_tile_macro<false>(L, tw_f, 1, t, col, tid >> 4, F64K_COLS * c + col);
         __syncthreads();
     }
     float2 v[16];
@@ -520,10 +520,10 @@ __global__ __launch_bounds__(256) void ovsave64k_mid_kernel(const float2 *__rest
         L[rev4_of_8bit(row) * F64K_LD + cc] = v[it];
     }
     __syncthreads();
+    // four stages as two register passes of two stages each (16 rows per thread)
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) { // inverse stages m = 1 .. 64
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<true>(L, tw_i, 0, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+    for (int t = 0; t < 4; t += 2) {
+        f64k_tile_macro<true>(L, tw_i, 0, t, col, tid >> 4, F64K_COLS * c + col);
         __syncthreads();
     }
 #pragma unroll 4
@@ -546,10 +546,10 @@ __global__ __launch_bounds__(256) void ovsave64k_last_kernel(const float2 *__res
     }
     __syncthreads();
     const int col = tid & 15;
+    // four stages as two register passes of two stages each (16 rows per thread)
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f64k_tile_butterfly<true>(L, tw_i, 1, t, col, (tid >> 4) + 16 * u, F64K_COLS * c + col);
+    for (int t = 0; t < 4; t += 2) {
+        f64k_tile_macro<true>(L, tw_i, 1, t, col, tid >> 4, F64K_COLS * c + col);
         __syncthreads();
     }
     float2 *dst = out + xf * hop;
