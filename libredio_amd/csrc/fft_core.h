@@ -294,10 +294,10 @@ inline int fft_plan_stages(int n, FftStage *st, int max_stages)
     return cnt;
 }
 
+// butterfly (g, k) of a stage: group g of p*m positions, index k inside the sub-length m
 template <bool INV, typename Ptr, typename TwPtr>
-RD_HD void fft_stage_butterfly(Ptr F, TwPtr tw, FftStage s, int b)
+RD_HD void fft_stage_butterfly_gk(Ptr F, TwPtr tw, FftStage s, int g, int k)
 {
-    const int g = b / s.m, k = b - g * s.m;
     const int base = g * s.p * s.m + k;
     const int m = s.m, fs = s.fstride;
     if (s.p == 4) {
@@ -317,6 +317,13 @@ RD_HD void fft_stage_butterfly(Ptr F, TwPtr tw, FftStage s, int b)
         bfly5(a0, a1, a2, a3, a4, tw[k * fs], tw[2 * k * fs], tw[3 * k * fs], tw[4 * k * fs], tw[fs * m], tw[fs * 2 * m]);
         F[base] = a0; F[base + m] = a1; F[base + 2 * m] = a2; F[base + 3 * m] = a3; F[base + 4 * m] = a4;
     } // p == 1 (nfft == 1): kf_bfly_generic with one input is the identity
+}
+
+template <bool INV, typename Ptr, typename TwPtr>
+RD_HD void fft_stage_butterfly(Ptr F, TwPtr tw, FftStage s, int b)
+{
+    const int g = b / s.m;
+    fft_stage_butterfly_gk<INV>(F, tw, s, g, b - g * s.m);
 }
 
 // kf_bfly_generic, one OUTPUT element per call: out position base + q1*m of butterfly (g,u).

@@ -404,6 +404,43 @@ __global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2
     for (int P = tid; P < n; P += nt) dst[P] = A[P];
 }
 
+// ---- any N with radices 2/3/4/5 whose batch fits LDS: several transforms per workgroup --------------------
+// The table-driven kernel above with the launch-bound parts removed: T transforms per 256-thread workgroup
+// (about 2048 points), coalesced load with the digit reversal on the LDS side (inverse table leaf_pos), thread
+// groups of G lanes per transform, and the stage's (g, k) split by a multiply-high with the plan's reciprocal
+// instead of an integer division.  Same butterflies in the same order.
+template <bool INV>
+__global__ __launch_bounds__(256) void fft_lds_batched_kernel(FftPlanDev p, const float2 *in, float2 *out, long nbatch, long in_stride,
+                                                              int T, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    const int n = p.nfft, tid = threadIdx.x, E = T * n;
+    const long b0 = (long)blockIdx.x * T;
+    for (int e = tid; e < E; e += 256) {
+        const int xf = p.magic_n ? (int)__umulhi((unsigned)e, p.magic_n) : e, nn = e - xf * n; // magic 0: divisor 1
+        const long b = (b0 + xf < nbatch) ? b0 + xf : nbatch - 1;
+        A[xf * n + p.leaf_pos[nn]] = in[b * in_stride + nn];
+    }
+    __syncthreads();
+    const int grp = tid / G, lg = tid - grp * G, ngrp = 256 / G;
+    for (int s = p.nstages - 1; s >= 0; --s) {
+        const FftStage st = p.st[s];
+        const unsigned magic = p.magic_m[s];
+        const int nb = n / st.p;
+        for (int xf = grp; xf < T; xf += ngrp)
+            for (int b = lg; b < nb; b += G) {
+                const int g = magic ? (int)__umulhi((unsigned)b, magic) : b;
+                fft_stage_butterfly_gk<INV>(A + xf * n, p.tw, st, g, b - g * st.m);
+            }
+        __syncthreads();
+    }
+    for (int e = tid; e < E; e += 256) {
+        const int xf = p.magic_n ? (int)__umulhi((unsigned)e, p.magic_n) : e;
+        if (b0 + xf < nbatch) out[(b0 + xf) * n + (e - xf * n)] = A[e];
+    }
+}
+
 // ---- large N: global-memory stages -----------------------------------------------------------
 __global__ __launch_bounds__(256) void fft_global_leaf_kernel(FftPlanDev p, const float2 *__restrict__ in,
                                                               float2 *__restrict__ out, long total, long in_stride)
@@ -633,6 +670,24 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     }
     bool generic = false;
     for (int i = 0; i < p.nstages; ++i) generic |= p.st[i].p > 5;
+    if (!generic && p.nfft <= 8192) {
+        int T = 2048 / p.nfft;
+        if (T < 1) T = 1;
+        if (T > nbatch) T = (int)nbatch;
+        int G = 256; // lanes per transform: the power of two at or above a quarter of its points
+        while (G > 1 && G / 2 >= (p.nfft + 3) / 4) G /= 2;
+        const size_t lds = (size_t)T * p.nfft * sizeof(float2);
+        auto kf = fft_lds_batched_kernel<false>;
+        auto ki = fft_lds_batched_kernel<true>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        const unsigned grid = (unsigned)((nbatch + T - 1) / T);
+        if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, p, in, out, nbatch, in_stride, T, G);
+        else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, p, in, out, nbatch, in_stride, T, G);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)p.nfft * sizeof(float2) * (generic ? 2 : 1);
     if (lds <= 128 * 1024) {
         auto kf = fft_lds_kernel<false>;

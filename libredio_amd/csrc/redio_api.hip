@@ -231,7 +231,7 @@ struct redio_fft {
     int device;
     FftPlanDev dev;
     float2 *d_tw;
-    int *d_leaf;
+    int *d_leaf, *d_leaf_pos;
     float2 *d_tmp; // for in-place calls on the global-memory path
     size_t tmp_elems;
 };
@@ -247,7 +247,7 @@ extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
     redio_fft *p = new (std::nothrow) redio_fft();
     if (!p) return REDIO_ERR_NOMEM;
     memset(&p->dev, 0, sizeof(p->dev));
-    p->device = dev; p->d_tw = nullptr; p->d_leaf = nullptr; p->d_tmp = nullptr; p->tmp_elems = 0;
+    p->device = dev; p->d_tw = nullptr; p->d_leaf = p->d_leaf_pos = nullptr; p->d_tmp = nullptr; p->tmp_elems = 0;
     p->dev.nfft = nfft; p->dev.inverse = inverse ? 1 : 0;
     p->dev.nstages = fft_plan_stages(nfft, p->dev.st, FFT_MAX_STAGES);
     if (p->dev.nstages < 0) { delete p; return REDIO_ERR_UNSUPPORTED; }
@@ -261,18 +261,28 @@ extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
     }
     std::vector<int> leaf((size_t)nfft);
     for (int P = 0; P < nfft; ++P) leaf[P] = fft_leaf_source(P, p->dev.st, p->dev.nstages);
+    std::vector<int> pos((size_t)nfft);
+    for (int P = 0; P < nfft; ++P) pos[(size_t)leaf[P]] = P;
+    // ceil(2^32 / d); 0 stands for d == 1 (the quotient is the dividend)
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    for (int i = 0; i < p->dev.nstages; ++i) p->dev.magic_m[i] = magic(p->dev.st[i].m);
+    p->dev.magic_n = magic(nfft);
     hipError_t e = hipMalloc((void **)&p->d_tw, (size_t)nfft * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_leaf, (size_t)nfft * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_leaf_pos, (size_t)nfft * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(p->d_leaf_pos, pos.data(), (size_t)nfft * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), (size_t)nfft * sizeof(float2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_leaf, leaf.data(), (size_t)nfft * sizeof(int), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (p->d_tw) hipFree(p->d_tw);
         if (p->d_leaf) hipFree(p->d_leaf);
+        if (p->d_leaf_pos) hipFree(p->d_leaf_pos);
         delete p;
         return hip_rc(e);
     }
     p->dev.tw = p->d_tw;
     p->dev.leaf_src = p->d_leaf;
+    p->dev.leaf_pos = p->d_leaf_pos;
     *h = p;
     return REDIO_OK;
 }
@@ -281,6 +291,7 @@ extern "C" int redio_fft_destroy(redio_fft *h)
     if (!h) return REDIO_OK;
     hipFree(h->d_tw);
     hipFree(h->d_leaf);
+    hipFree(h->d_leaf_pos);
     if (h->d_tmp) hipFree(h->d_tmp);
     delete h;
     return REDIO_OK;

@@ -20,6 +20,9 @@ struct FftPlanDev {
     FftStage st[FFT_MAX_STAGES];
     const float2 *tw;     // device twiddle table, nfft entries
     const int *leaf_src;  // device table: leaf position -> input index (digit reversal), nfft entries
+    const int *leaf_pos;  // the inverse: input index -> leaf position
+    unsigned magic_m[FFT_MAX_STAGES]; // ceil(2^32 / m) per stage and ceil(2^32 / nfft): exact quotients by __umulhi for
+    unsigned magic_n;                 // dividends below 2^16 * ... (b * m < 2^32), which LDS-resident sizes satisfy
 };
 // in != out required unless work is given; work (nfft*nbatch float2) is used for in-place calls and
 // by the global-memory path
