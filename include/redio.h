@@ -47,6 +47,11 @@ int redio_free(void *dptr);
 int redio_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int redio_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int redio_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+/* pinned host memory that kernels can address directly (zero-copy over PCIe): *host is the CPU pointer, *dev the
+ * pointer to pass as a device buffer.  For small host-resident messages this saves the two staged copies of
+ * redio_upload / redio_download (the kiss_fft drop-in uses it up to 8192 points). */
+int redio_host_alloc(void **host, void **dev, size_t bytes);
+int redio_host_free(void *host);
 int redio_stream_create(void **stream);
 int redio_stream_destroy(void *stream);
 int redio_stream_sync(void *stream); /* NULL = default stream */

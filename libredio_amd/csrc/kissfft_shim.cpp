@@ -15,7 +15,10 @@ struct kiss_fft_state {
     void *d_buf;   // nfft complex on the device
     void *stream;
     kiss_fft_cpx *gather; // host scratch for strided input
+    // small transforms: pinned, device-addressable message buffers (zero-copy) instead of two staged copies
+    void *pin_in, *pin_in_dev, *pin_out, *pin_out_dev;
 };
+enum { KISS_ZERO_COPY_MAX = 8192 };
 
 extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, size_t *lenmem)
 {
@@ -30,10 +33,19 @@ extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, siz
     }
     if (!st) return NULL;
     st->nfft = nfft; st->inverse = inverse_fft; st->plan = NULL; st->d_buf = NULL; st->stream = NULL; st->gather = NULL;
+    st->pin_in = st->pin_in_dev = st->pin_out = st->pin_out_dev = NULL;
     if (nfft <= 0) { if (st->on_heap) free(st); return NULL; }
     int rc = redio_fft_create(&st->plan, nfft, inverse_fft);
     if (rc == REDIO_OK) rc = redio_malloc(&st->d_buf, (size_t)nfft * sizeof(kiss_fft_cpx));
     if (rc == REDIO_OK) rc = redio_stream_create(&st->stream);
+    if (rc == REDIO_OK && nfft <= KISS_ZERO_COPY_MAX) {
+        // best effort: without mapped pinned memory the copy path below serves every size
+        if (redio_host_alloc(&st->pin_in, &st->pin_in_dev, (size_t)nfft * sizeof(kiss_fft_cpx)) != REDIO_OK ||
+            redio_host_alloc(&st->pin_out, &st->pin_out_dev, (size_t)nfft * sizeof(kiss_fft_cpx)) != REDIO_OK) {
+            redio_host_free(st->pin_in); redio_host_free(st->pin_out);
+            st->pin_in = st->pin_in_dev = st->pin_out = st->pin_out_dev = NULL;
+        }
+    }
     if (rc != REDIO_OK) {
         fprintf(stderr, "kiss_fft_alloc(%d): %s\n", nfft, redio_strerror(rc));
         redio_fft_destroy(st->plan);
@@ -53,6 +65,15 @@ extern "C" void kiss_fft_stride(kiss_fft_cfg st, const kiss_fft_cpx *fin, kiss_f
         if (!st->gather) st->gather = (kiss_fft_cpx *)malloc(bytes);
         for (int i = 0; i < st->nfft; ++i) st->gather[i] = fin[(size_t)i * in_stride];
         src = st->gather;
+    }
+    if (st->pin_out) { // the kernel reads and writes the pinned message buffers across PCIe itself
+        memcpy(st->pin_in, src, bytes);
+        int rc0 = redio_fft_enqueue(st->plan, st->pin_in_dev, st->pin_out_dev, 1, st->stream);
+        if (rc0 == REDIO_OK) rc0 = redio_stream_sync(st->stream);
+        if (rc0 == REDIO_OK) { memcpy(fout, st->pin_out, bytes); return; }
+        fprintf(stderr, "kiss_fft: %s\n", redio_strerror(rc0));
+        for (int i = 0; i < st->nfft; ++i) fout[i].r = fout[i].i = NAN;
+        return;
     }
     int rc = redio_upload(st->d_buf, src, bytes, st->stream);
     if (rc == REDIO_OK) rc = redio_fft_enqueue(st->plan, st->d_buf, st->d_buf, 1, st->stream);
@@ -84,6 +105,8 @@ extern "C" void kiss_fft_free(kiss_fft_cfg st)
     if (!st) return;
     redio_fft_destroy(st->plan);
     redio_free(st->d_buf);
+    redio_host_free(st->pin_in);
+    redio_host_free(st->pin_out);
     redio_stream_destroy(st->stream);
     free(st->gather);
     if (st->on_heap) free(st);

@@ -72,6 +72,19 @@ extern "C" int redio_copy(void *dst, const void *src, size_t bytes, void *stream
     if (!dst || !src) return REDIO_ERR_ARG;
     return hip_rc(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
 }
+extern "C" int redio_host_alloc(void **host, void **dev, size_t bytes)
+{
+    if (!host || !dev) return REDIO_ERR_ARG;
+    *host = *dev = nullptr;
+    void *h = nullptr, *d = nullptr;
+    RD_TRY(hipHostMalloc(&h, bytes ? bytes : 1, hipHostMallocMapped));
+    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { hipHostFree(h); return hip_rc(e); }
+    *host = h; *dev = d;
+    return REDIO_OK;
+}
+extern "C" int redio_host_free(void *host) { return host ? hip_rc(hipHostFree(host)) : REDIO_OK; }
+
 extern "C" int redio_stream_create(void **stream)
 {
     if (!stream) return REDIO_ERR_ARG;
