@@ -88,6 +88,88 @@ __global__ __launch_bounds__(256) void fft4k_kernel(const float2 *in, float2 *ou
     }
 }
 
+// ---- overlap-save with 4096-point blocks in ONE kernel ---------------------------------------------
+// A 4096-point block fits LDS, so block load, forward transform, product with conj(H), inverse transform,
+// 1/N scale and the store of the hop valid outputs all happen in one workgroup: 8 B read and 8*hop/4096 B
+// written per block sample, nothing in between touches HBM.  The pieces are fft4k_kernel's (forward with the
+// plan's table, inverse with the inverse plan's); the spectrum goes from the forward outer stage's registers
+// straight into the inverse transform's de-interleaved regions.  Bit-identical to transform -> multiply ->
+// transform -> scaled copy.
+__global__ __launch_bounds__(256) void ovsave4k_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
+                                                       const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
+                                                       float2 *__restrict__ out, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *src = x + (long)blockIdx.x * hop;
+    float2 *dst = out + (long)blockIdx.x * hop;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int n = tid + 256 * it;
+        L[(n & 3) * FFT4K_REGION + (n >> 2)] = src[n];
+    }
+    __syncthreads();
+    float2 *mine = L + wave * FFT4K_REGION;
+    float2 v[16];
+    {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
+        const TwEvery4 tw1k = {tw_f};
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw1k);
+        fft1k_wave_regs<false>(v, mine, mine, tw1k, t, lane);
+    }
+    __syncthreads();
+    // forward outer stage into registers, times conj(H): v[4 i + j] = Y[k + 1024 j], k = tid + 256 i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        float2 a0 = L[k], a1 = L[FFT4K_REGION + k], a2 = L[2 * FFT4K_REGION + k], a3 = L[3 * FFT4K_REGION + k];
+        bfly4<false>(a0, a1, a2, a3, tw_f[k], tw_f[2 * k], tw_f[3 * k]);
+        v[4 * i] = cmul_rn(a0, Hc[k]);
+        v[4 * i + 1] = cmul_rn(a1, Hc[k + 1024]);
+        v[4 * i + 2] = cmul_rn(a2, Hc[k + 2048]);
+        v[4 * i + 3] = cmul_rn(a3, Hc[k + 3072]);
+    }
+    __syncthreads(); // every thread has read its columns
+    // the inverse transform's input, de-interleaved: sample n = k + 1024 j -> region n & 3, slot n >> 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L[(k & 3) * FFT4K_REGION + (k >> 2) + 256 * j] = v[4 * i + j];
+    }
+    __syncthreads();
+    {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
+        const TwEvery4 tw1k = {tw_i};
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw1k);
+        fft1k_wave_regs<true>(v, mine, mine, tw1k, t, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        float2 a[4] = {L[k], L[FFT4K_REGION + k], L[2 * FFT4K_REGION + k], L[3 * FFT4K_REGION + k]};
+        bfly4<true>(a[0], a[1], a[2], a[3], tw_i[k], tw_i[2 * k], tw_i[3 * k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + 1024 * j < hop) dst[k + 1024 * j] = make_float2(mul_rn(a[j].x, scale), mul_rn(a[j].y, scale));
+    }
+}
+
+hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s)
+{
+    const size_t lds = 4 * FFT4K_REGION * sizeof(float2);
+    hipLaunchKernelGGL(ovsave4k_kernel, dim3((unsigned)nblk), dim3(256), lds, s, x, hop, tw_f, tw_i, Hc, out, scale);
+    return hipGetLastError();
+}
+
 // ---- N = 16384 = 16 x 1024: one 1024-thread workgroup per transform --------------------------------
 // Two outer kissfft stages (m = 1024 with fstride 4, m = 4096 with fstride 1) over sixteen 1024-point
 // transforms of x[r + 16 i]; leaf block g = 4 j0 + j1 holds the stream r = j0 + 4 j1.  Sixteen waves,
@@ -141,6 +223,90 @@ __global__ __launch_bounds__(1024) void fft16k_kernel(const float2 *in, float2 *
     }
 #pragma unroll
     for (int g = 0; g < 16; ++g) dst[k + 1024 * g] = v[g];
+}
+
+// ---- overlap-save with 16384-point blocks in one kernel (the 4096-point scheme on fft16k_kernel's pieces) ----
+template <bool INV>
+__device__ __forceinline__ void fft16k_outer(float2 (&v)[16], const float2 *__restrict__ tw, int k)
+{
+    {
+        const float2 w1 = tw[4 * k], w2 = tw[8 * k], w3 = tw[12 * k];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) bfly4<INV>(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w1, w2, w3); // m = 1024
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { // m = 4096
+        const int kk = k + 1024 * b;
+        bfly4<INV>(v[b], v[b + 4], v[b + 8], v[b + 12], tw[kk], tw[2 * kk], tw[3 * kk]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void ovsave16k_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
+                                                         const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
+                                                         float2 *__restrict__ out, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *src = x + (long)blockIdx.x * hop;
+    float2 *dst = out + (long)blockIdx.x * hop;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int n = tid + 1024 * it, r = n & 15;
+        L[((r & 3) * 4 + (r >> 2)) * FFT16K_REGION + (n >> 4)] = src[n];
+    }
+    __syncthreads();
+    float2 *mine = L + wave * FFT16K_REGION;
+    float2 v[16];
+    {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
+        const TwEvery16 tw1k = {tw_f};
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw1k);
+        fft1k_wave_regs<false>(v, mine, mine, tw1k, t, lane);
+    }
+    __syncthreads();
+    const int k = tid;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = L[g * FFT16K_REGION + k];
+    fft16k_outer<false>(v, tw_f, k);                 // v[g] = Y[k + 1024 g]
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = cmul_rn(v[g], Hc[k + 1024 * g]);
+    __syncthreads(); // every thread has read its column
+    {   // the inverse transform's input n = k + 1024 g: stream r = k & 15, slot (k >> 4) + 64 g
+        const int r = k & 15;
+        float2 *reg = L + ((r & 3) * 4 + (r >> 2)) * FFT16K_REGION + (k >> 4);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) reg[64 * g] = v[g];
+    }
+    __syncthreads();
+    {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
+        const TwEvery16 tw1k = {tw_i};
+        Fft1kTw t;
+        fft1k_load_tw(t, lane, tw1k);
+        fft1k_wave_regs<true>(v, mine, mine, tw1k, t, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = L[g * FFT16K_REGION + k];
+    fft16k_outer<true>(v, tw_i, k);
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+        if (k + 1024 * g < hop) dst[k + 1024 * g] = make_float2(mul_rn(v[g].x, scale), mul_rn(v[g].y, scale));
+}
+
+hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                            float scale, hipStream_t s)
+{
+    const size_t lds = 16 * FFT16K_REGION * sizeof(float2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ovsave16k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ovsave16k_kernel, dim3((unsigned)nblk), dim3(1024), lds, s, x, hop, tw_f, tw_i, Hc, out, scale);
+    return hipGetLastError();
 }
 
 // ---- N = 256: four transforms per wavefront -------------------------------------------------------

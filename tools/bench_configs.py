@@ -67,6 +67,14 @@ if "c5" in which:
         hop = 65536 - k + 1
         b = 8 * 65536 / hop + 8
         print(f"C5 overlap-save N=65536 K={k}: {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  {b*out.numel()/ms/1e6:.0f} GB/s algorithmic ({b*out.numel()/ms/1e6/8000:.1%})")
+    for nfft, k in ((4096, 127), (4096, 1025), (16384, 127), (16384, 4097)):
+        taps = R.dsputils.lpf_corrected(k, 0.08)
+        x = R.synth_iq(0x5EED0005, 0, n)
+        plan = R.OverlapSave(taps, nfft)
+        out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan(x, out=out), n=10, warm=3)
+        b = 8 * nfft / (nfft - k + 1) + 8
+        print(f"overlap-save N={nfft} K={k}: {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  {b*out.numel()/ms/1e6:.0f} GB/s algorithmic ({b*out.numel()/ms/1e6/8000:.1%})")
 if "hipfft" in which:
     # same-hardware yardstick: the vendor FFT through torch.fft, same sizes, same batch
     for nfft in (1024, 64, 4096, 65536):
