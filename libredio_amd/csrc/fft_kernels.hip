@@ -88,6 +88,58 @@ __global__ __launch_bounds__(256) void fft4k_kernel(const float2 *in, float2 *ou
     }
 }
 
+// ---- overlap-save with 1024-point blocks: one wavefront per block, nothing but registers in between -------
+// The forward transform leaves X[lane + 64 q + 256 j] in v[4 q + j]; the inverse transform wants
+// v'[t] = Y[lane + 64 t], t = q + 4 j -- a register renaming.  Load, transform, product with conj(H), inverse
+// transform, scale and the store of the hop valid outputs, eight blocks per wave with the 54 lane-dependent
+// twiddles of both directions held in registers.
+__global__ __launch_bounds__(256) void ovsave1k_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
+                                                       const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
+                                                       float2 *__restrict__ out, long nblk, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
+    const long b0 = ((long)blockIdx.x * 4 + wave) * FFT1K_PER_WAVE;
+    if (b0 >= nblk) return; // wave-uniform
+    const long b1 = (b0 + FFT1K_PER_WAVE < nblk) ? b0 + FFT1K_PER_WAVE : nblk;
+    Fft1kTw tf, ti;
+    fft1k_load_tw(tf, lane, tw_f);
+    fft1k_load_tw(ti, lane, tw_i);
+    for (long b = b0; b < b1; ++b) {
+        float2 v[16], w[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = x[b * hop + lane + 64 * t];
+        fft1k_wave_stages0to3<false>(v, ex, tw_f, tf, lane);
+        fft1k_passC<false>(v, tf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[q + 4 * j] = cmul_rn(v[4 * q + j], Hc[lane + 64 * (q + 4 * j)]); // 8 KiB table: L1-resident
+        wave_lds_fence();
+        fft1k_wave_stages0to3<true>(w, ex, tw_i, ti, lane);
+        fft1k_passC<true>(w, ti);
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pos = lane + 64 * q + 256 * j;
+                if (pos < hop) out[b * hop + pos] = make_float2(mul_rn(w[4 * q + j].x, scale), mul_rn(w[4 * q + j].y, scale));
+            }
+    }
+}
+
+hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s)
+{
+    const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
+    const unsigned grid = (unsigned)((nblk + 4 * FFT1K_PER_WAVE - 1) / (4 * FFT1K_PER_WAVE));
+    hipLaunchKernelGGL(ovsave1k_kernel, dim3(grid), dim3(256), lds, s, x, hop, tw_f, tw_i, Hc, out, nblk, scale);
+    return hipGetLastError();
+}
+
 // ---- overlap-save with 4096-point blocks in ONE kernel ---------------------------------------------
 // A 4096-point block fits LDS, so block load, forward transform, product with conj(H), inverse transform,
 // 1/N scale and the store of the hop valid outputs all happen in one workgroup: 8 B read and 8*hop/4096 B

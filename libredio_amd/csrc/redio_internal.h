@@ -28,7 +28,9 @@ struct FftPlanDev {
 // by the global-memory path
 hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0);
 
-// overlap-save at nfft 4096: one kernel, no work buffers
+// overlap-save at nfft 1024 (one wave per block) and 4096: one kernel, no work buffers
+hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s);
 hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s);
 hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
