@@ -188,8 +188,9 @@ int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_in, void *d
  * Prototype of nchan*taps_per_branch taps; branch m filters rows x_t[m] = x[nchan*t + m] with
  * g_m[p] = proto[nchan*p + m] using the fold of dsputils::convolve (dsputils.rs:31), then every row
  * goes through kissfft's nchan-point forward transform (kissfft.rs:26).  Output rows: T-P+1 with
- * T = floor(n_in / nchan).  Built for nchan = 64, taps_per_branch in {4, 8, 16}; anything else is
- * REDIO_ERR_UNSUPPORTED.  flags: REDIO_FIR_FUSED as for redio_fir_create.
+ * T = floor(n_in / nchan).  nchan = 64 with taps_per_branch in {4, 8, 16} runs one fused kernel; any other
+ * shape runs the branch filters and the nchan-point transform as two passes (same results).
+ * flags: REDIO_FIR_FUSED as for redio_fir_create.
  * Output layout: ngroups = 1 -> [row][nchan]; ngroups = G -> [group][row][nchan/G], the send layout
  * of the multi-GPU regrouping (one contiguous chunk per destination rank). */
 typedef struct redio_pfb redio_pfb;

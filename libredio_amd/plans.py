@@ -226,9 +226,10 @@ def synth_f32(seed, first, n, device="cuda"):
 
 
 class Channelizer:
-    """redio_pfb_*: 64-channel polyphase channelizer (BASELINE.json configs[3]): branch FIRs with the
-    dsputils fold + kissfft across branches.  out[row][channel], or [group][row][64/ngroups] for the
-    multi-GPU regrouping (see channelizer_all_to_all)."""
+    """redio_pfb_*: polyphase channelizer (BASELINE.json configs[3]): branch FIRs with the dsputils fold + kissfft
+    across branches.  64 channels with 4 / 8 / 16 taps per branch run one fused kernel; any other shape runs the
+    branch filters and the plan's transform as two passes.  out[row][channel], or [group][row][nchan/ngroups] for
+    the multi-GPU regrouping (see channelizer_all_to_all)."""
 
     def __init__(self, proto, nchan=64, taps_per_branch=16, fused=True):
         t, p = _taps(proto)

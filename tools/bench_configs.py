@@ -150,3 +150,11 @@ if "srcgen" in which:
         out, used = plan.process(x, ratio)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"resample ratio {ratio:.5f} x{nch} ch, {frames} frames: {dt*1e3:.2f} ms  {nch*used/dt/1e9:.3f} GS/s in, {out.shape[1]} out per channel")
+if "c4gen" in which:
+    for M, P in ((64, 16), (32, 16), (128, 16), (256, 8), (1024, 4), (64, 12)):
+        h = R.dsputils.lpf_corrected(M * P, 0.45 / M)
+        x = R.synth_iq(0x5EED0004, 0, n)
+        plan = R.Channelizer(h, M, P)
+        out = torch.empty((plan.nrows(n), M), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan(x, out=out), n=10, warm=3)
+        print(f"channelizer M={M} P={P}: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  ({16*n/ms/1e6/8000:.1%} of 8 TB/s)")
