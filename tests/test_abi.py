@@ -81,3 +81,22 @@ def test_host_tap_generators_match_oracle(redio, oracle):
         redio.dsputils.sinc(8, 0.5)
     with pytest.raises(redio.RedioError):
         redio.dsputils.hpf(1, 0.1)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """The product has no fallback: with libredio.so absent the loader raises instead of computing on the CPU
+    (run in a fresh interpreter so that the library this suite already loaded does not mask the check)."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import libredio_amd as R\n"
+        f"R.LIBREDIO = {str(tmp_path / 'nope' / 'libredio.so')!r}\n"
+        "try:\n"
+        "    R.dsputils.convolve([1.0, 2.0, 3.0], [1.0])\n"
+        "except ImportError as e:\n"
+        "    print('LOUD', e); sys.exit(0)\n"
+        "sys.exit(7)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "LOUD" in out.stdout, (out.returncode, out.stdout, out.stderr)
