@@ -72,6 +72,41 @@ __global__ __launch_bounds__(256) void ingest_mag_kernel(const uint8_t *__restri
     }
 }
 
+// The same through a table: |x| of a byte pair depends only on the unordered pair (the double-precision sum of
+// the two squares commutes), so 32896 floats cover the whole input domain.  A persistent 1024-thread workgroup
+// per CU builds the table in LDS with the expression above (exact by construction), then every sample is one
+// LDS lookup; the f64 square root leaves the streaming loop.
+constexpr int MAG_LUT = 256 * 257 / 2;
+__global__ __launch_bounds__(1024) void ingest_mag_lut_kernel(const uint8_t *__restrict__ d, float *__restrict__ mag, long nsamp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lut = reinterpret_cast<float *>(smem);
+    for (int p = threadIdx.x; p < 65536; p += 1024) {
+        const int a = p >> 8, b = p & 255;
+        if (b <= a) lut[a * (a + 1) / 2 + b] = norm_f32(i2f((unsigned)a), i2f((unsigned)b));
+    }
+    __syncthreads();
+    auto look = [&](unsigned re, unsigned im) {
+        const unsigned hi = re > im ? re : im, lo = re > im ? im : re;
+        return lut[hi * (hi + 1) / 2 + lo];
+    };
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = nsamp / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const uint2 w = reinterpret_cast<const uint2 *>(d)[q];
+        float4 m;
+        m.x = look(w.x & 255u, (w.x >> 8) & 255u);
+        m.y = look((w.x >> 16) & 255u, w.x >> 24);
+        m.z = look(w.y & 255u, (w.y >> 8) & 255u);
+        m.w = look((w.y >> 16) & 255u, w.y >> 24);
+        reinterpret_cast<float4 *>(mag)[q] = m;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (nsamp & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        mag[i] = look(d[2 * i], d[2 * i + 1]);
+    }
+}
+
 // per-block sums in sample order (bitfount.rs:48): one lane per block; a wave stages 64 blocks'
 // chunks through LDS so that global reads stay coalesced (row padded by one float: lane stride 65).
 // Any block length and alignment.
@@ -237,6 +272,20 @@ extern "C" int redio_ingest_u8_mag(const void *d_bytes, size_t nbytes, void *d_m
     if (!d_bytes || !d_mag) return REDIO_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_bytes) & 7) || (reinterpret_cast<uintptr_t>(d_mag) & 15)) return REDIO_ERR_ARG;
     const long ns = (long)(nbytes / 2);
+    if (ns >= (1L << 22)) { // long streams: the table pays for itself (one persistent workgroup per CU)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const size_t lds = MAG_LUT * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ingest_mag_lut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_rc(e);
+        hipLaunchKernelGGL(ingest_mag_lut_kernel, dim3((unsigned)cus), dim3(1024), lds, (hipStream_t)stream, (const uint8_t *)d_bytes, (float *)d_mag, ns);
+        return hip_rc(hipGetLastError());
+    }
     hipLaunchKernelGGL(ingest_mag_kernel, dim3(grid_for(ns / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float *)d_mag, ns);
     return hip_rc(hipGetLastError());
 }

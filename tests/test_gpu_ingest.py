@@ -26,6 +26,10 @@ def test_norm_is_hypotf_on_the_whole_u8_domain(gpu, redio, oracle):
     want = oracle.norm(x)
     assert np.array_equal(bits(redio.bitfount.norm(gpu.from_numpy(x).cuda()).cpu().numpy()), bits(want))
     assert np.array_equal(bits(redio.bitfount.ingest_mag(gpu.from_numpy(d).cuda()).cpu().numpy()), bits(want))
+    # long streams switch to the LDS-table kernel: the whole domain again, 65 times over plus a ragged tail
+    big = np.concatenate([np.tile(d, 65), d[: 2 * 4099]])
+    got = redio.bitfount.ingest_mag(gpu.from_numpy(big).cuda()).cpu().numpy()
+    assert np.array_equal(bits(got), bits(np.concatenate([np.tile(want, 65), want[:4099]])))
     y = oracle.synth_iq(5, 0, 100003) * np.float32(1000.0)                              # and on random data
     assert np.array_equal(bits(redio.bitfount.norm(gpu.from_numpy(y).cuda()).cpu().numpy()), bits(oracle.norm(y)))
 
