@@ -113,8 +113,9 @@ int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, size_t nbatch
 int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, long in_stride, void *stream);
 
 /* ---- C2 chain: FIR (ntaps, decimate decim) -> nfft-point forward FFT of consecutive blocks ----
- * Fused single kernel for (ntaps, decim, nfft) = (127, 5, 1024); other shapes run the FIR and FFT
- * kernels back to back through a plan-owned intermediate buffer (same results).  Trailing decimated
+ * Fused single kernel for nfft = 1024 with (ntaps, decim) in {(127, 5), (127, 3), (127, 1), (63, 5), (63, 1)} on a
+ * 16-byte aligned stream; other shapes run the FIR and FFT kernels back to back through a plan-owned
+ * intermediate buffer (same results).  Trailing decimated
  * samples that do not fill a block are dropped, as kpn::shaper would (src/kpn/src/kpn.rs:278-282). */
 typedef struct redio_chain redio_chain;
 int redio_chain_create(redio_chain **h, const float *taps_host, size_t ntaps, size_t decim, int nfft, unsigned flags);

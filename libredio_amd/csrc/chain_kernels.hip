@@ -310,7 +310,14 @@ hipError_t launch_chain_v5(const float2 *x, const float *taps, const float2 *tw,
 static unsigned long long *g_chain_dbg = nullptr; // diagnostic stamps (tools/clock_probe.py), never set in production
 void chain_set_debug_buffer(unsigned long long *p) { g_chain_dbg = p; }
 
-bool chain_supported(int K, long D, int nfft) { return nfft == 1024 && K == 127 && D == 5; }
+hipError_t launch_chain_v4_shape(int K, int D, const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
+                                 hipStream_t s); // chain_v4.hip
+
+bool chain_supported(int K, long D, int nfft)
+{
+    if (nfft != 1024) return false;
+    return (K == 127 && (D == 5 || D == 1 || D == 3)) || (K == 63 && (D == 5 || D == 1));
+}
 
 static int num_cus()
 {
@@ -411,7 +418,9 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
         if (variant == 2 && aligned) return launch_chain_v2<127, 5>(p, x, taps, out, nblocks, fused, s);
         return launch_chain_t<127, 5>(p, x, n_in, taps, out, nblocks, fused, s);
     }
-    return hipErrorNotSupported;
+    if (p.nfft == 1024 && !p.inverse && (reinterpret_cast<uintptr_t>(x) & 15) == 0) // other fused shapes need the aligned stream
+        return launch_chain_v4_shape(K, (int)D, x, taps, p.tw, out, nblocks, fused, s);
+    return hipErrorNotSupported; // the C-ABI layer then runs the two-kernel path
 }
 
 } // namespace redio

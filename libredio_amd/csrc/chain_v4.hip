@@ -171,6 +171,17 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
     return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg); // last-stage twiddles resident
 }
 
+// the same kernel for the other tap / decimation pairs with a fused build (K - D even, image within the per-wave LDS budget)
+hipError_t launch_chain_v4_shape(int K, int D, const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
+                                 hipStream_t s)
+{
+    if (K == 63 && D == 5) return launch_v4_t<63, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    if (K == 127 && D == 1) return launch_v4_t<127, 1, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    if (K == 63 && D == 1) return launch_v4_t<63, 1, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    if (K == 127 && D == 3) return launch_v4_t<127, 3, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    return hipErrorNotSupported;
+}
+
 // stand-alone 127-tap decimate-by-5 FIR on whole 1024-output blocks (16-byte aligned cf32 in and out)
 hipError_t launch_fir_v4_127_5(const float2 *x, const float *taps, float2 *y, long nblocks, bool fused, hipStream_t s)
 {

@@ -417,8 +417,10 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     RD_TRY(hipSetDevice(h->fir->device));
     const bool fused_math = (h->fir->flags & REDIO_FIR_FUSED) != 0;
     if (redio_chain_is_fused(h)) {
-        return hip_rc(launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
-                                   (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, h->variant, (hipStream_t)stream, h->d_queue));
+        hipError_t e = launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
+                                    (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, h->variant, (hipStream_t)stream, h->d_queue);
+        if (e != hipErrorNotSupported) return hip_rc(e);
+        // e.g. an input pointer the fused kernel cannot take: same results through the two kernels below
     }
     // two kernels through a plan-owned intermediate (allocated on first use / growth)
     size_t ny = nblk * (size_t)h->nfft;

@@ -215,6 +215,24 @@ def test_chain_fused_rounding_vs_reference_rounding_tolerance(gpu, redio, oracle
     assert same_bits(exact, want)
 
 
+@pytest.mark.parametrize("k,d", [(63, 5), (127, 1), (63, 1), (127, 3)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_chain_other_fused_shapes(gpu, redio, oracle, k, d, fused):
+    # the single-kernel chain is built for these tap / decimation pairs too (1024-point blocks)
+    taps = oracle.lpf_corrected(k, 0.4 / max(d, 2))
+    for nblocks in (1, 5, 37):
+        n = nblocks * 1024 * d + (k - d) + 2
+        x = oracle.synth_iq(0x5EED0002, 0, n + 1)
+        dx = gpu.from_numpy(x).cuda()
+        chain = redio.Chain(taps, d, 1024, fused=fused)
+        assert chain.is_fused and chain.nblocks(n) == nblocks
+        want = oracle.chain_fir_fft(x[:n], taps, d, 1024, fused=fused)
+        assert same_bits(chain(dx[:n]).cpu().numpy(), want), (k, d, nblocks)
+        # a stream that starts on an odd sample (8-byte aligned only) takes the two-kernel path: same bits
+        want1 = oracle.chain_fir_fft(x[1:n + 1], taps, d, 1024, fused=fused)
+        assert same_bits(chain(dx[1:n + 1]).cpu().numpy(), want1), (k, d, nblocks, "unaligned")
+
+
 def test_chain_other_shape_runs_unfused(gpu, redio, oracle):
     taps = oracle.lpf_corrected(63, 0.1)
     x = oracle.synth_iq(3, 0, 64 * 2 * 10 + 62)

@@ -158,3 +158,13 @@ if "c4gen" in which:
         out = torch.empty((plan.nrows(n), M), dtype=torch.complex64, device="cuda")
         ms = timeit(lambda: plan(x, out=out), n=10, warm=3)
         print(f"channelizer M={M} P={P}: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  ({16*n/ms/1e6/8000:.1%} of 8 TB/s)")
+if "chains" in which:
+    for (k, d) in ((127, 5), (63, 5), (127, 3), (127, 1), (63, 1), (64, 4)):
+        taps = R.dsputils.lpf_corrected(k, 0.4 / max(d, 2))
+        m = 1 << 27
+        x = R.synth_iq(2, 0, m)
+        plan = R.Chain(taps, d, 1024, fused=True)
+        out = torch.empty((plan.nblocks(m), 1024), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan(x, out), n=10, warm=3)
+        b = 8 + 8 / d
+        print(f"chain K={k} D={d} -> FFT 1024 ({'one kernel' if plan.is_fused else 'two kernels'}): {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  ({b*m/ms/1e6/8000:.1%} of 8 TB/s)")
