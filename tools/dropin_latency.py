@@ -27,3 +27,14 @@ t0 = time.perf_counter()
 for _ in range(20): dsputils.convolve(u, v)
 dt = (time.perf_counter() - t0) / 20
 print(f"redio_convolve_f32 2^20 x 63 taps (host buffers): {dt*1e3:.2f} ms per call ({len(u)/dt/1e6:.0f} MS/s)")
+from libredio_amd import samplerate
+for ratio, frames in ((0.02, 4096), (0.02, 65536), (0.5, 4096), (2.0, 4096), (48000 / 44100, 4096)):
+    st = samplerate.State(1, 1)
+    x = np.random.rand(frames).astype(np.float32)
+    for _ in range(5): st.block(x, ratio)
+    t0 = time.perf_counter()
+    reps = 100
+    for _ in range(reps): st.block(x, ratio)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"src_process drop-in ratio {ratio:.4f}, {frames} frames per message: {dt*1e6:.1f} us per call ({frames/dt/1e6:.1f} MS/s in)")
+    st.close()
