@@ -226,8 +226,11 @@ class Resampler:
             raise ValueError(f"src_new failed with error {err.value}")
 
     def __del__(self):
-        if getattr(self, "_s", None):
-            lib().orc_src_delete(self._s); self._s = None
+        try:   # module globals may already be gone at interpreter shutdown
+            if getattr(self, "_s", None):
+                lib().orc_src_delete(self._s); self._s = None
+        except Exception:
+            pass
 
     def block(self, vin, ratio):
         vin = _f32(vin)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the device kernels against the CPU oracle (bit-exact), beyond the fixed cases
+of tests/: python tools/fuzz_parity.py [seconds] [seed].  Prints one line per failure and a summary."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import libredio_amd as R
+import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+fails, runs = 0, {}
+
+
+def check(name, ok, detail):
+    global fails
+    runs[name] = runs.get(name, 0) + 1
+    if not ok:
+        fails += 1
+        print("FAIL", name, detail, flush=True)
+
+
+t_end = time.time() + budget
+while time.time() < t_end:
+    which = rng.integers(0, 6)
+    if which == 0:      # FIR, any K / D / length / alignment
+        k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000))]))
+        d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
+        cplx, fused = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        n = k - 1 + int(rng.integers(0, 30000)); off = int(rng.integers(0, 4))
+        taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
+        x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, n + off)
+        got = R.Fir(taps, d, complex_input=cplx, fused=fused)(torch.from_numpy(x).cuda()[off:]).cpu().numpy()
+        want = O.fir(x[off:], taps, d, fused)
+        check("fir", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, cplx, fused, n, off))
+    elif which == 1:    # FFT, any size
+        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 15)), 3 * 2 ** int(rng.integers(0, 10)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 6))]))
+        inv = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 70))
+        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n * nb)
+        d = torch.from_numpy(x).cuda()
+        plan = R.Fft(n, inv)
+        got = plan(d).cpu().numpy(); want = O.fft(x, n, inv)
+        ok = np.array_equal(bits(got), bits(want))
+        plan(d, out=d)
+        ok = ok and np.array_equal(bits(d.cpu().numpy()), bits(want))
+        check("fft", ok, (n, inv, nb))
+    elif which == 2:    # chain shapes
+        k, dd = [(127, 5), (63, 5), (127, 3), (127, 1), (63, 1), (100, 2), (31, 4)][int(rng.integers(0, 7))]
+        fused = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 40)); extra = int(rng.integers(0, 1024 * dd))
+        taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
+        n = nb * 1024 * dd + (k - dd) + extra
+        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n)
+        got = R.Chain(taps, dd, 1024, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.chain_fir_fft(x, taps, dd, 1024, fused=fused)
+        check("chain", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, fused, nb, extra))
+    elif which == 3:    # overlap-save
+        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 1000]))
+        k = int(rng.integers(1, nfft + 1)); hop = nfft - k + 1
+        n = nfft + int(rng.integers(0, 6)) * hop + int(rng.integers(0, hop))
+        taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
+        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n)
+        got = R.OverlapSave(taps, nfft)(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.overlap_save(x, taps, nfft)
+        check("ovsave", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nfft, k, n))
+    elif which == 4:    # channelizer, any M / P
+        M = int(rng.choice([64, 32, 16, 128, 100, 7, int(rng.integers(1, 300))])); P = int(rng.choice([4, 8, 16, int(rng.integers(1, 20))]))
+        fused = bool(rng.integers(0, 2)); rows = int(rng.integers(0, 200))
+        h = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, M * P)
+        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, M * (P - 1 + rows) + int(rng.integers(0, M)))
+        got = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.pfb_channelizer(x, h, M, P, fused)
+        check("pfb", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows))
+    else:               # resampler, batched, random ratio and message cuts
+        nch = int(rng.choice([1, 3, 40])); conv = int(rng.integers(0, 3))
+        ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 1 / 7, float(rng.uniform(0.01, 3.0))]))
+        n = int(rng.integers(1, 40000))
+        x = np.stack([O.synth_f32(int(rng.integers(1, 1 << 30)), 0, n) for _ in range(nch)])
+        plan = R.Src(nch, conv, mode=int(rng.choice([0, 2])))
+        refs = [O.Resampler(conv) for _ in range(nch)]
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 3)]))
+        ok = True
+        dx = torch.from_numpy(x).cuda()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            cap = int(ratio * (hi - lo) + 1.0)
+            a, used = plan.process(dx[:, lo:hi].contiguous(), ratio)
+            a = a.cpu().numpy()
+            for c in range(nch):
+                err, want, wused = refs[c].process(x[c, lo:hi], ratio, cap)
+                ok = ok and err == 0 and wused == used and a.shape[1] == len(want) and np.array_equal(bits(a[c]), bits(want))
+        check("src", ok, (nch, conv, ratio, n, cuts))
+print("runs", runs, "failures", fails)
+sys.exit(1 if fails else 0)
