@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run of the device kernels against the CPU oracle (bit-exact), beyond the fixed cases
-of tests/: python tools/fuzz_parity.py [seconds] [seed].  Prints one line per failure and a summary."""
+of tests/: python tests/fuzz_parity.py [seconds] [seed].  Prints one line per failure and a summary."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
