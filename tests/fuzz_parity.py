@@ -23,7 +23,7 @@ def check(name, ok, detail):
 
 t_end = time.time() + budget
 while time.time() < t_end:
-    which = rng.integers(0, 6)
+    which = rng.integers(0, 8)
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
@@ -71,6 +71,44 @@ while time.time() < t_end:
         got = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.pfb_channelizer(x, h, M, P, fused)
         check("pfb", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows))
+    elif which == 6:    # ingest: bytes -> samples -> |x| -> block sums -> slicer, any length / offset
+        from libredio_amd import bitfount as B
+        n = int(rng.integers(1, 60000)); off = 8 * int(rng.integers(0, 3))
+        raw = rng.integers(0, 256, 2 * n + off, dtype=np.uint8)
+        d = torch.from_numpy(raw).cuda()[off:]
+        xs = O.data_to_samples(raw[off:])
+        ok = np.array_equal(bits(B.data_to_samples(d).cpu().numpy()), bits(xs))
+        mag = O.norm(xs)
+        ok = ok and np.array_equal(bits(B.norm(torch.from_numpy(xs).cuda()).cpu().numpy()), bits(mag))
+        blk = int(rng.choice([512, 64, 100, 7]))
+        nb = n // blk
+        if nb:
+            got = B.block_sums(torch.from_numpy(mag[: nb * blk].copy()).cuda(), blk).cpu().numpy()
+            want = np.array([O.block_sum(mag[b * blk:(b + 1) * blk]) for b in range(nb)], np.float32)
+            ok = ok and np.array_equal(bits(got), bits(want))
+        o2 = int(rng.integers(0, 4))
+        dm = torch.from_numpy(mag).cuda()[o2:]
+        if dm.numel():
+            ok = ok and np.array_equal(B.discretize(dm).cpu().numpy(), O.discretize(mag[o2:]).astype(np.uint8))
+        check("ingest", ok, (n, off, blk, o2))
+    elif which == 7:    # runs and vector maps
+        from libredio_amd import kpn_dev as K
+        n = int(rng.integers(1, 50000)); off = int(rng.integers(0, 9))
+        v = np.repeat(rng.integers(0, 4, n), rng.integers(1, 6, n)).astype(np.uint8)[: n + off]
+        dev, ref = K.Rle(), O.Rle()
+        ok = True
+        cuts = sorted(set([off, len(v)] + [int(c) for c in rng.integers(off, len(v) + 1, 2)]))
+        dv = torch.from_numpy(v).cuda()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a, c = dev.feed(dv[lo:hi])
+            ok = ok and list(zip(a.cpu().tolist(), c.cpu().tolist())) == ref.feed(v[lo:hi])
+        cplx = bool(rng.integers(0, 2)); m = int(rng.integers(1, 5000)); o3 = int(rng.integers(0, 3))
+        gen = O.synth_iq if cplx else O.synth_f32
+        x, c = gen(int(rng.integers(1, 1 << 30)), 0, m + o3), gen(int(rng.integers(1, 1 << 30)), 0, m + 3)
+        dx, dc = torch.from_numpy(x).cuda()[o3:], torch.from_numpy(c).cuda()
+        ok = ok and np.array_equal(bits(K.mul_vecs(dx, dc).cpu().numpy()), bits(O.zip_vecs(x[o3:], c, add=False)))
+        ok = ok and np.array_equal(bits(K.sum_vecs(dx, dc).cpu().numpy()), bits(O.zip_vecs(x[o3:], c, add=True)))
+        check("runs", ok, (n, off, cplx, m, o3))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40])); conv = int(rng.integers(0, 3))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 1 / 7, float(rng.uniform(0.01, 3.0))]))
