@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void chain_v2_kernel(const float2 *__restri
 //     double buffering as in v2.
 // ---------------------------------------------------------------------------------------------
 // ABLATE (timing-only builds, wrong results): 1 = skip the FIR multiply-adds, 2 = skip the transform,
-// 4 = fetch only the very first sub-tile from HBM.  Reached through redio_chain_set_variant(10 + mask).
+// 4 = fetch only the very first sub-tile from HBM.  They produced the breakdown quoted in DESIGN.md 5.1; the
+// dispatch no longer instantiates them (a public call must never return wrong results).
 template <int K, int D, bool FUSED, int WPS, int CH, int ABLATE = 0>
 __global__ __launch_bounds__(64, WPS) void chain_v3_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
                                                          const float2 *__restrict__ tw, float2 *__restrict__ out,
@@ -402,19 +403,6 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
         if (variant == 6 && aligned) return launch_chain_v3<127, 5, 2, 8>(p, x, taps, out, nblocks, fused, s);
         if (variant == 3 && aligned) return launch_chain_v3<127, 5, 3, 6>(p, x, taps, out, nblocks, fused, s);
         if (variant == 4 && aligned) return launch_chain_v3<127, 5, 3, 8>(p, x, taps, out, nblocks, fused, s);
-        if (variant >= 10 && aligned && fused) { // timing-only ablations of v3 (results are wrong)
-            switch (variant - 10) {
-            case 1: return launch_chain_v3<127, 5, 3, 6, 1>(p, x, taps, out, nblocks, true, s);
-            case 2: return launch_chain_v3<127, 5, 3, 6, 2>(p, x, taps, out, nblocks, true, s);
-            case 3: return launch_chain_v3<127, 5, 3, 6, 3>(p, x, taps, out, nblocks, true, s);
-            case 4: return launch_chain_v3<127, 5, 3, 6, 4>(p, x, taps, out, nblocks, true, s);
-            case 6: return launch_chain_v3<127, 5, 3, 6, 6>(p, x, taps, out, nblocks, true, s);
-            case 7: return launch_chain_v3<127, 5, 3, 6, 7>(p, x, taps, out, nblocks, true, s);
-            case 11: return launch_chain_v3<127, 5, 2, 8, 11>(p, x, taps, out, nblocks, true, s);
-            case 13: return launch_chain_v3<127, 5, 2, 8, 3>(p, x, taps, out, nblocks, true, s);
-            default: break;
-            }
-        }
         if (variant == 2 && aligned) return launch_chain_v2<127, 5>(p, x, taps, out, nblocks, fused, s);
         return launch_chain_t<127, 5>(p, x, n_in, taps, out, nblocks, fused, s);
     }

@@ -404,7 +404,7 @@ namespace redio { void chain_set_debug_buffer(unsigned long long *p); }
 extern "C" int redio_debug_chain_stamps(void *d_buf) { chain_set_debug_buffer((unsigned long long *)d_buf); return REDIO_OK; }
 extern "C" int redio_chain_set_variant(redio_chain *h, int variant)
 {
-    if (!h || variant < 0 || variant > 31) return REDIO_ERR_ARG;
+    if (!h || variant < 0 || (variant > 10 && variant != 31)) return REDIO_ERR_ARG; // every selectable build is bit-identical
     h->variant = variant;
     return REDIO_OK;
 }
