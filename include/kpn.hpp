@@ -49,6 +49,7 @@ struct Chan {
     std::deque<T> q;
     int senders = 0;
     bool receiver_alive = true;
+    size_t capacity = 0; // 0: unbounded (std::sync::mpsc::channel); > 0: send blocks while the queue is full
 };
 } // namespace detail
 
@@ -77,15 +78,17 @@ public:
     Sender(Sender &&o) noexcept : c_(std::move(o.c_)) {}
     Sender &operator=(Sender o) { std::swap(c_, o.c_); return *this; }
     ~Sender() { detach(); }
-    // mpsc send: never blocks; false when the receiver is gone (Err in Rust; blocks decide to unwrap)
+    // mpsc send: never blocks on an unbounded channel; false when the receiver is gone (Err in Rust; blocks
+    // decide to unwrap).  On a bounded channel (bounded_channel) it waits for a free slot: back-pressure.
     bool send(T v) const
     {
         {
-            std::lock_guard<std::mutex> l(c_->m);
+            std::unique_lock<std::mutex> l(c_->m);
+            if (c_->capacity) c_->cv.wait(l, [&] { return !c_->receiver_alive || c_->q.size() < c_->capacity; });
             if (!c_->receiver_alive) return false;
             c_->q.push_back(std::move(v));
         }
-        c_->cv.notify_one();
+        c_->cv.notify_all();
         return true;
     }
     void send_unwrap(T v) const
@@ -118,6 +121,7 @@ public:
             c_->receiver_alive = false;
             c_->q.clear();
         }
+        c_->cv.notify_all(); // senders blocked on a full bounded channel see the hang-up
         c_.reset();
     }
     // blocking receive; nullopt once every sender is gone and the queue is drained (Err(RecvError))
@@ -128,6 +132,7 @@ public:
         if (c_->q.empty()) return std::nullopt;
         T v = std::move(c_->q.front());
         c_->q.pop_front();
+        if (c_->capacity) { l.unlock(); c_->cv.notify_all(); } // a slot is free
         return v;
     }
     T recv() const // recv().unwrap()
@@ -139,10 +144,11 @@ public:
     // try_recv(): nullopt when empty (the reference's grapes() unwraps this and panics, kpn.rs:245)
     std::optional<T> try_recv() const
     {
-        std::lock_guard<std::mutex> l(c_->m);
+        std::unique_lock<std::mutex> l(c_->m);
         if (c_->q.empty()) return std::nullopt;
         T v = std::move(c_->q.front());
         c_->q.pop_front();
+        if (c_->capacity) { l.unlock(); c_->cv.notify_all(); }
         return v;
     }
 };
@@ -151,6 +157,17 @@ template <typename T>
 std::pair<Sender<T>, Receiver<T>> channel()
 {
     auto c = std::make_shared<detail::Chan<T>>();
+    return {Sender<T>(c), Receiver<T>(c)};
+}
+
+// A deliberate deviation for device-resident graphs: the reference's channels are unbounded, which
+// is harmless for small host Vecs but lets a fast producer pin an unbounded amount of HBM.  A bounded channel holds
+// at most `capacity` messages; send waits for a slot (credit), everything else behaves like channel().
+template <typename T>
+std::pair<Sender<T>, Receiver<T>> bounded_channel(size_t capacity)
+{
+    auto c = std::make_shared<detail::Chan<T>>();
+    c->capacity = capacity ? capacity : 1;
     return {Sender<T>(c), Receiver<T>(c)};
 }
 

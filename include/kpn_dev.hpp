@@ -6,8 +6,9 @@
 //   shaper (kpn.rs:278-282)          dev::shaper: re-chunks a stream of Views into Views of length l,
 //                                    zero-copy when a chunk lies inside one allocation
 //   unpacketizer / shaper_vecs       the inverse is the identity on a View stream
-// and the hot blocks consume and produce Views through the device plans of include/redio.h.  Channels stay
-// the same unbounded FIFOs; back-pressure is the caller's business exactly as in the reference.
+// and the hot blocks consume and produce Views through the device plans of include/redio.h.  Channels are the
+// same FIFOs; use kpn::bounded_channel<View<T>>(n) between device blocks to cap the HBM a fast producer can pin
+// (the reference's unbounded mpsc has no back-pressure -- a documented deviation).
 #pragma once
 #include "kpn.hpp"
 #include <complex>

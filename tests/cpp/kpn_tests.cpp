@@ -6,6 +6,8 @@
 #include "../../include/kpn.hpp"
 #include "../../include/wavio.hpp"
 #include "../../include/kpn_dev.hpp"
+#include <atomic>
+#include <chrono>
 #include <cassert>
 #include <cmath>
 #include <fstream>
@@ -35,6 +37,27 @@ static int plumbing()
         bool threw = false;
         try { rx.recv(); } catch (const hangup &) { threw = true; }
         CHECK(threw);
+    }
+    { // bounded channel: send waits for a slot, a dropped receiver releases a blocked sender
+        auto [tx, rx] = bounded_channel<int>(2);
+        std::atomic<int> sent{0};
+        std::thread prod([t = tx, &sent]() mutable { for (int i = 0; i < 6; ++i) { if (!t.send(i)) break; ++sent; } });
+        for (int spin = 0; spin < 200 && sent.load() < 2; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        CHECK(sent.load() == 2);                       // the third send is parked: no credit
+        CHECK(rx.recv() == 0);
+        for (int spin = 0; spin < 200 && sent.load() < 3; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        CHECK(sent.load() == 3);
+        for (int i = 1; i < 6; ++i) CHECK(rx.recv() == i);
+        prod.join();
+        auto [tx2, rx2] = bounded_channel<int>(1);
+        tx2.send(7);
+        std::atomic<int> refused{-1};
+        std::thread blocked([t = tx2, &refused]() mutable { refused = t.send(8) ? 0 : 1; }); // parks, then sees the hang-up
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        rx2.close();
+        blocked.join();
+        CHECK(refused.load() == 1);
     }
     { // send to a dropped receiver fails (Err), does not throw
         auto [tx, rx] = channel<int>();
