@@ -43,9 +43,9 @@ if "fft" in which:
         out = torch.empty_like(x)
         ms = timeit(lambda: plan(x, out=out), n=20 if nfft < 16384 else 5, warm=3)
         print(f"FFT {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  {16*x.numel()/ms/1e6:.0f} GB/s algorithmic ({16*x.numel()/ms/1e6/8000:.1%})")
-if "c3" in which:
+if "c3" in which or "c3big" in which:
     import time
-    nch, frames = 256, 1 << 20
+    nch, frames = 256, (1 << 22) if "c3big" in which else (1 << 20)
     x = torch.stack([R.synth_f32(100 + c, 0, frames) for c in range(nch)])
     for name, mode in (("exact, one launch", R.Src.EXACT), ("fast f32 polyphase", R.Src.FAST), ("exact, per-refill launches", R.Src.EPOCHS)):
         plan = R.Src(nch, 1, mode=mode)
