@@ -47,26 +47,40 @@ inline void check(int rc)
     if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc));
 }
 
+// Every block owns a HIP stream for its life (one OS thread per block, src/ratpak.rs:60-185): blocks on
+// different threads then overlap on the device instead of serialising on the default stream.  A block
+// synchronises its stream before it sends a message, so ordering between blocks is the channel's.
+struct BlockStream {
+    void *s = nullptr;
+    BlockStream() { check(redio_stream_create(&s)); }
+    ~BlockStream() { redio_stream_destroy(s); }
+    BlockStream(const BlockStream &) = delete;
+    BlockStream &operator=(const BlockStream &) = delete;
+    operator void *() const { return s; }
+};
+
 // host Vec<T> -> device View<T> and back (the only PCIe crossings of a device-resident graph)
 template <typename T>
 void to_device(Receiver<std::vector<T>> u, Sender<View<T>> v)
 {
+    BlockStream st;
     for (;;) {
         auto x = u.recv();
         auto d = make<T>(x.size());
-        check(redio_upload(d.data(), x.data(), x.size() * sizeof(T), nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_upload(d.data(), x.data(), x.size() * sizeof(T), st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(d));
     }
 }
 template <typename T>
 void to_host(Receiver<View<T>> u, Sender<std::vector<T>> v)
 {
+    BlockStream st;
     for (;;) {
         auto d = u.recv();
         std::vector<T> x(d.len);
-        check(redio_download(x.data(), d.data(), d.len * sizeof(T), nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_download(x.data(), d.data(), d.len * sizeof(T), st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(x));
     }
 }
@@ -76,6 +90,7 @@ void to_host(Receiver<View<T>> u, Sender<std::vector<T>> v)
 template <typename T>
 void shaper(Receiver<View<T>> u, Sender<View<T>> v, size_t l)
 {
+    BlockStream st;
     View<T> pend;           // partially filled chunk (owned copy)
     size_t have = 0;
     for (;;) {
@@ -89,11 +104,11 @@ void shaper(Receiver<View<T>> u, Sender<View<T>> v, size_t l)
             }
             if (have == 0) pend = make<T>(l);
             const size_t take = std::min(l - have, d.len - pos);
-            check(redio_copy(pend.data() + have, d.data() + pos, take * sizeof(T), nullptr));
+            check(redio_copy(pend.data() + have, d.data() + pos, take * sizeof(T), st));
             have += take;
             pos += take;
             if (have == l) {
-                check(redio_stream_sync(nullptr));
+                check(redio_stream_sync(st));
                 v.send_unwrap(pend);
                 have = 0;
             }
@@ -104,14 +119,15 @@ void shaper(Receiver<View<T>> u, Sender<View<T>> v, size_t l)
 // dsputils::convolve semantics on device streams (complex samples x real taps, optional decimation)
 inline void fir(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, size_t decim, bool fused)
 {
+    BlockStream st;
     redio_fir *h = nullptr;
     check(redio_fir_create(&h, taps.data(), taps.size(), decim, REDIO_FIR_COMPLEX | (fused ? REDIO_FIR_FUSED : 0)));
     struct G { redio_fir *h; ~G() { redio_fir_destroy(h); } } g{h};
     for (;;) {
         auto d = u.recv();
         auto o = make<std::complex<float>>(redio_fir_nout(h, d.len));
-        check(redio_fir_enqueue(h, d.data(), d.len, o.data(), nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_fir_enqueue(h, d.data(), d.len, o.data(), st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(o));
     }
 }
@@ -119,6 +135,7 @@ inline void fir(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<
 // kissfft::fft semantics: every message must be a whole number of block_size-sample blocks
 inline void fft(Receiver<View<std::complex<float>>> pin, Sender<View<std::complex<float>>> cout, uint32_t block_size, uint32_t inv)
 {
+    BlockStream st;
     redio_fft *h = nullptr;
     check(redio_fft_create(&h, (int)block_size, (int)inv));
     struct G { redio_fft *h; ~G() { redio_fft_destroy(h); } } g{h};
@@ -126,8 +143,8 @@ inline void fft(Receiver<View<std::complex<float>>> pin, Sender<View<std::comple
         auto d = pin.recv();
         if (d.len % block_size) throw std::runtime_error("assert!(din.len() == block_size) (kissfft.rs:24)");
         auto o = make<std::complex<float>>(d.len);
-        check(redio_fft_enqueue(h, d.data(), o.data(), d.len / block_size, nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_fft_enqueue(h, d.data(), o.data(), d.len / block_size, st));
+        check(redio_stream_sync(st));
         cout.send_unwrap(std::move(o));
     }
 }
@@ -136,14 +153,15 @@ inline void fft(Receiver<View<std::complex<float>>> pin, Sender<View<std::comple
 inline void fir_fft_chain(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps,
                           size_t decim, int nfft, bool fused)
 {
+    BlockStream st;
     redio_chain *h = nullptr;
     check(redio_chain_create(&h, taps.data(), taps.size(), decim, nfft, fused ? REDIO_FIR_FUSED : 0));
     struct G { redio_chain *h; ~G() { redio_chain_destroy(h); } } g{h};
     for (;;) {
         auto d = u.recv();
         auto o = make<std::complex<float>>(redio_chain_nblocks(h, d.len) * (size_t)nfft);
-        check(redio_chain_enqueue(h, d.data(), d.len, o.data(), nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_chain_enqueue(h, d.data(), d.len, o.data(), st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(o));
     }
 }
@@ -151,34 +169,36 @@ inline void fir_fft_chain(Receiver<View<std::complex<float>>> u, Sender<View<std
 // the front end of the shipped graph: u8 IQ bytes -> |x| (rtlsdr.rs:159-162 + ratpak.rs:64-68)
 inline void ingest_mag(Receiver<View<uint8_t>> u, Sender<View<float>> v)
 {
+    BlockStream st;
     for (;;) {
         auto d = u.recv();
         auto o = make<float>(d.len / 2);
-        check(redio_ingest_u8_mag(d.data(), d.len, o.data(), nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_ingest_u8_mag(d.data(), d.len, o.data(), st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(o));
     }
 }
 
 // kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231) with the constant vector resident on the device
 namespace detail {
-inline int zip_call(bool add, const float *a, const float *b, float *o, size_t n) { return add ? redio_add_f32(a, b, o, n, nullptr) : redio_mul_f32(a, b, o, n, nullptr); }
-inline int zip_call(bool add, const std::complex<float> *a, const std::complex<float> *b, std::complex<float> *o, size_t n)
+inline int zip_call(bool add, const float *a, const float *b, float *o, size_t n, void *st) { return add ? redio_add_f32(a, b, o, n, st) : redio_mul_f32(a, b, o, n, st); }
+inline int zip_call(bool add, const std::complex<float> *a, const std::complex<float> *b, std::complex<float> *o, size_t n, void *st)
 {
-    return add ? redio_add_c32(a, b, o, n, nullptr) : redio_mul_c32(a, b, o, n, nullptr);
+    return add ? redio_add_c32(a, b, o, n, st) : redio_mul_c32(a, b, o, n, st);
 }
 template <typename T>
 void zip_vecs(Receiver<View<T>> u, Sender<View<T>> v, const std::vector<T> &c, bool add)
 {
+    BlockStream st;
     auto dc = make<T>(c.size());
-    check(redio_upload(dc.data(), c.data(), c.size() * sizeof(T), nullptr));
-    check(redio_stream_sync(nullptr));
+    check(redio_upload(dc.data(), c.data(), c.size() * sizeof(T), st));
+    check(redio_stream_sync(st));
     for (;;) {
         auto x = u.recv();
         const size_t n = x.len < c.size() ? x.len : c.size();
         auto o = make<T>(n);
-        check(zip_call(add, x.data(), dc.data(), o.data(), n));
-        check(redio_stream_sync(nullptr));
+        check(zip_call(add, x.data(), dc.data(), o.data(), n, st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(o));
     }
 }
@@ -192,6 +212,7 @@ void sum_vecs(Receiver<View<T>> u, Sender<View<T>> v, std::vector<T> c) { detail
 // life of the block, output capacity floor(ratio*len + 1) per message, output_frames_gen samples sent
 inline void resample(Receiver<View<float>> din, Sender<View<float>> dout, double ratio)
 {
+    BlockStream st;
     redio_src *h = nullptr;
     int rc = redio_src_create(&h, 1 /* SRC_SINC_MEDIUM_QUALITY, samplerate.rs:27 */, 1);
     if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc));
@@ -201,7 +222,7 @@ inline void resample(Receiver<View<float>> din, Sender<View<float>> dout, double
         const long lout = (long)(ratio * (double)d.len + 1.0);
         auto o = make<float>((size_t)lout);
         long used = 0, gen = 0;
-        rc = redio_src_process(h, d.data(), (long)d.len, (long)d.len, o.data(), lout, lout, ratio, 0, &used, &gen, nullptr);
+        rc = redio_src_process(h, d.data(), (long)d.len, (long)d.len, o.data(), lout, lout, ratio, 0, &used, &gen, st);
         if (rc != REDIO_OK) throw std::runtime_error(redio_strerror(rc)); // the reference panics with src_strerror's text
         dout.send_unwrap(o.sub(0, (size_t)gen));
     }
@@ -211,14 +232,15 @@ inline void resample(Receiver<View<float>> din, Sender<View<float>> dout, double
 inline void channelizer(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> proto, int nchan,
                         int taps_per_branch, bool fused)
 {
+    BlockStream st;
     redio_pfb *h = nullptr;
     check(redio_pfb_create(&h, proto.data(), nchan, taps_per_branch, fused ? REDIO_FIR_FUSED : 0));
     struct G { redio_pfb *h; ~G() { redio_pfb_destroy(h); } } g{h};
     for (;;) {
         auto d = u.recv();
         auto o = make<std::complex<float>>(redio_pfb_nrows(h, d.len) * (size_t)nchan);
-        check(redio_pfb_enqueue(h, d.data(), d.len, o.data(), 1, nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_pfb_enqueue(h, d.data(), d.len, o.data(), 1, st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(o));
     }
 }
@@ -226,14 +248,15 @@ inline void channelizer(Receiver<View<std::complex<float>>> u, Sender<View<std::
 // overlap-save FFT convolution (BASELINE configs[4]) with dsputils::convolve's valid-mode semantics per message
 inline void overlap_save(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, int nfft)
 {
+    BlockStream st;
     redio_ovsave *h = nullptr;
     check(redio_ovsave_create(&h, taps.data(), taps.size(), nfft));
     struct G { redio_ovsave *h; ~G() { redio_ovsave_destroy(h); } } g{h};
     for (;;) {
         auto d = u.recv();
         auto o = make<std::complex<float>>(redio_ovsave_nout(h, d.len));
-        check(redio_ovsave_enqueue(h, d.data(), d.len, o.data(), nullptr));
-        check(redio_stream_sync(nullptr));
+        check(redio_ovsave_enqueue(h, d.data(), d.len, o.data(), st));
+        check(redio_stream_sync(st));
         v.send_unwrap(std::move(o));
     }
 }
