@@ -212,29 +212,83 @@ extern "C" int redio_fir_enqueue(redio_fir *h, const void *d_in, size_t n_in, vo
 }
 
 // ---------------------------------------------------------------- A1 host drop-in
+// Per-thread state of the host-buffer convolve: the reference calls convolve once per message from a block thread
+// (src/ratpak.rs:60-185: one OS thread per block), with the same taps every time, so the plan, a stream and the
+// message buffers are kept per calling thread instead of being created and freed on every call.  Small messages go
+// through pinned, device-addressable buffers (the kernel reads and writes them across PCIe itself); large ones
+// through device buffers with explicit copies.  The cache lives as long as the thread's process (never freed at
+// thread exit: the HIP runtime may already be shutting down there).
+namespace {
+struct ConvCache {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    redio_fir *plan = nullptr;
+    std::vector<float> taps;
+    float *pin_in = nullptr, *pin_in_dev = nullptr, *pin_out = nullptr, *pin_out_dev = nullptr; // zero-copy path
+    size_t pin_cap = 0;
+    float *d_in = nullptr, *d_out = nullptr; // copy path
+    size_t d_cap = 0;
+};
+constexpr size_t CONV_ZERO_COPY_MAX = 1 << 16; // floats
+} // namespace
+
 extern "C" int redio_convolve_f32(const float *u, size_t nu, const float *v, size_t nv, float *out, size_t *nout)
 {
     if (nout) *nout = 0;
     if (nv == 0) return REDIO_ERR_ASSERT;
     if (nu < nv) return REDIO_OK;
     if (!u || !v || !out) return REDIO_ERR_ARG;
-    redio_fir *h = nullptr;
-    int rc = redio_fir_create(&h, v, nv, 1, 0);
-    if (rc) return rc;
-    size_t n = nu - nv + 1;
-    float *d_in = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_in, nu * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(d_in, u, nu * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = redio_fir_enqueue(h, d_in, nu, d_out, nullptr);
-        if (rc == REDIO_OK) e = hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost); // syncs
+    static thread_local ConvCache *cache = nullptr;
+    int dev = current_device();
+    if (dev < 0) return REDIO_ERR_NO_DEVICE;
+    if (!cache) cache = new (std::nothrow) ConvCache();
+    if (!cache) return REDIO_ERR_NOMEM;
+    ConvCache &c = *cache;
+    if (c.device != dev) { // first call of this thread (or the thread moved to another device): start over
+        c = ConvCache();
+        c.device = dev;
+        RD_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     }
-    if (d_in) hipFree(d_in);
-    if (d_out) hipFree(d_out);
-    redio_fir_destroy(h);
-    if (rc) return rc;
-    if (e != hipSuccess) return hip_rc(e);
+    if (!c.plan || c.taps.size() != nv || memcmp(c.taps.data(), v, nv * sizeof(float)) != 0) {
+        if (c.plan) redio_fir_destroy(c.plan);
+        c.plan = nullptr;
+        int rc = redio_fir_create(&c.plan, v, nv, 1, 0);
+        if (rc) return rc;
+        c.taps.assign(v, v + nv);
+    }
+    const size_t n = nu - nv + 1;
+    if (nu <= CONV_ZERO_COPY_MAX) {
+        if (nu > c.pin_cap) {
+            if (c.pin_in) hipHostFree(c.pin_in);
+            if (c.pin_out) hipHostFree(c.pin_out);
+            c.pin_in = c.pin_out = nullptr; c.pin_cap = 0;
+            const size_t cap = nu < 4096 ? 4096 : nu;
+            RD_TRY(hipHostMalloc((void **)&c.pin_in, cap * sizeof(float), hipHostMallocMapped));
+            RD_TRY(hipHostMalloc((void **)&c.pin_out, cap * sizeof(float), hipHostMallocMapped));
+            RD_TRY(hipHostGetDevicePointer((void **)&c.pin_in_dev, c.pin_in, 0));
+            RD_TRY(hipHostGetDevicePointer((void **)&c.pin_out_dev, c.pin_out, 0));
+            c.pin_cap = cap;
+        }
+        memcpy(c.pin_in, u, nu * sizeof(float));
+        int rc = redio_fir_enqueue(c.plan, c.pin_in_dev, nu, c.pin_out_dev, c.stream);
+        if (rc) return rc;
+        RD_TRY(hipStreamSynchronize(c.stream));
+        memcpy(out, c.pin_out, n * sizeof(float));
+    } else {
+        if (nu > c.d_cap) {
+            if (c.d_in) hipFree(c.d_in);
+            if (c.d_out) hipFree(c.d_out);
+            c.d_in = c.d_out = nullptr; c.d_cap = 0;
+            RD_TRY(hipMalloc((void **)&c.d_in, nu * sizeof(float)));
+            RD_TRY(hipMalloc((void **)&c.d_out, nu * sizeof(float)));
+            c.d_cap = nu;
+        }
+        RD_TRY(hipMemcpyAsync(c.d_in, u, nu * sizeof(float), hipMemcpyHostToDevice, c.stream));
+        int rc = redio_fir_enqueue(c.plan, c.d_in, nu, c.d_out, c.stream);
+        if (rc) return rc;
+        RD_TRY(hipMemcpyAsync(out, c.d_out, n * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+        RD_TRY(hipStreamSynchronize(c.stream));
+    }
     if (nout) *nout = n;
     return REDIO_OK;
 }

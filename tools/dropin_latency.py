@@ -27,6 +27,16 @@ t0 = time.perf_counter()
 for _ in range(20): dsputils.convolve(u, v)
 dt = (time.perf_counter() - t0) / 20
 print(f"redio_convolve_f32 2^20 x 63 taps (host buffers): {dt*1e3:.2f} ms per call ({len(u)/dt/1e6:.0f} MS/s)")
+for m in (1024, 16384):
+    um = u[:m].copy()
+    dsputils.convolve(um, v)
+    t0 = time.perf_counter()
+    for _ in range(300): dsputils.convolve(um, v)
+    dt = (time.perf_counter() - t0) / 300
+    t0 = time.perf_counter()
+    for _ in range(50): np.correlate(um, v, "valid")
+    cpu = (time.perf_counter() - t0) / 50
+    print(f"redio_convolve_f32 {m} x 63 taps per message: {dt*1e6:.1f} us per call; numpy.correlate on this host: {cpu*1e6:.1f} us")
 from libredio_amd import samplerate
 for ratio, frames in ((0.02, 4096), (0.02, 65536), (0.5, 4096), (2.0, 4096), (48000 / 44100, 4096)):
     st = samplerate.State(1, 1)
