@@ -98,6 +98,7 @@ struct redio_src {
     int mode;                                // REDIO_SRC_EXACT / REDIO_SRC_FAST
     int window_ok;                           // single-launch path enabled (off: one launch per buffer refill)
     size_t stage_in_cap, stage_out_cap;
+    hipStream_t host_stream; // the host-buffer entry point's own stream: states on different threads do not serialise
 };
 
 static double fmod_one(double x)
@@ -119,6 +120,7 @@ extern "C" int redio_src_reset(redio_src *s)
     s->cur = 0;
     SRC_TRY(hipMemset(s->d_buf[0], 0, (size_t)s->nchan * s->buf_stride * sizeof(float)));
     SRC_TRY(hipMemset(s->d_buf[1], 0, (size_t)s->nchan * s->buf_stride * sizeof(float)));
+    SRC_TRY(hipStreamSynchronize(nullptr)); // later work runs on non-blocking streams, which do not wait for the default stream
     return REDIO_OK;
 }
 
@@ -138,7 +140,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->coeff_half_len = half; s->index_inc = inc;
     s->d_coeffs = nullptr; s->d_buf[0] = s->d_buf[1] = nullptr;
     s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
-    s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0;
+    s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0; s->host_stream = nullptr;
     s->fast_inc = 0; s->d_cl = s->d_cr = nullptr; s->ncl = s->ncr = 0;
     s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
     s->h_coeffs = coeffs;
@@ -163,6 +165,7 @@ extern "C" int redio_src_destroy(redio_src *s)
     hipFree(s->d_coeffs); hipFree(s->d_buf[0]); hipFree(s->d_buf[1]);
     hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
     hipFree(s->d_stage_in); hipFree(s->d_stage_out);
+    if (s->host_stream) hipStreamDestroy(s->host_stream);
     hipFree(s->d_cl); hipFree(s->d_cr); hipFree(s->d_T2);
     delete s;
     return REDIO_OK;
@@ -551,6 +554,8 @@ extern "C" int redio_src_process_host(redio_src *s, const float *data_in, long i
         return REDIO_SRC_ERR_DATA_OVERLAP;
     }
     SRC_TRY(hipSetDevice(s->device));
+    if (!s->host_stream) SRC_TRY(hipStreamCreateWithFlags(&s->host_stream, hipStreamNonBlocking));
+    hipStream_t st = s->host_stream;
     if ((size_t)output_frames > s->stage_out_cap) {
         hipFree(s->d_stage_out);
         s->d_stage_out = nullptr; s->stage_out_cap = 0;
@@ -565,15 +570,15 @@ extern "C" int redio_src_process_host(redio_src *s, const float *data_in, long i
             SRC_TRY(hipMalloc((void **)&s->d_stage_in, ((size_t)input_frames + 1024) * sizeof(float)));
             s->stage_in_cap = (size_t)input_frames + 1024;
         }
-        SRC_TRY(hipMemcpyAsync(s->d_stage_in, data_in, (size_t)input_frames * sizeof(float), hipMemcpyHostToDevice, nullptr));
+        SRC_TRY(hipMemcpyAsync(s->d_stage_in, data_in, (size_t)input_frames * sizeof(float), hipMemcpyHostToDevice, st));
         in = {nullptr, s->d_stage_in, (long)s->stage_in_cap};
     }
     long used = 0, gen = 0;
     int rc = src_process_impl(s, in, input_frames, s->d_stage_out, (long)s->stage_out_cap, output_frames, src_ratio, end_of_input,
-                              &used, &gen, nullptr);
+                              &used, &gen, st);
     hipError_t e = hipSuccess;
-    if (rc == REDIO_OK && gen > 0) e = hipMemcpy(data_out, s->d_stage_out, (size_t)gen * sizeof(float), hipMemcpyDeviceToHost);
-    else e = hipStreamSynchronize(nullptr);
+    if (rc == REDIO_OK && gen > 0) e = hipMemcpyAsync(data_out, s->d_stage_out, (size_t)gen * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (rc) return rc;
     if (e != hipSuccess) return hip_rc(e);
     if (input_frames_used) *input_frames_used = used;
