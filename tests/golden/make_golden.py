@@ -105,7 +105,50 @@ def pfb_cases():
     return {"x": x, "proto": h, "y": O.pfb_channelizer(x, h, 64, 16, False), "y_fused": O.pfb_channelizer(x, h, 64, 16, True)}
 
 
-CASES = {"fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
+def ovsave_cases():
+    out = {}
+    for nfft, k in ((256, 33), (1024, 127), (4096, 63)):
+        taps = O.lpf_corrected(k, 0.1)
+        x = O.synth_iq(0x5EED0005 + nfft, 0, nfft + 2 * (nfft - k + 1) + 5)
+        y = O.overlap_save(x, taps, nfft)
+        direct = O.fir(x, taps, 1, fused=False)[: len(y)]
+        assert np.abs(y - direct).max() <= 2e-6 * np.abs(taps).sum() * np.sqrt(np.log2(nfft)) + 1e-7
+        out.update({f"n{nfft}_x": x, f"n{nfft}_taps": taps, f"n{nfft}_y": y})
+    return out
+
+
+def front_end_cases():
+    """The shipped graph's front end on one burst: bytes -> samples -> |x| -> 512-sample block sums -> slicer -> runs."""
+    out = {}
+    rng = np.random.default_rng(0x5EED0A)
+    n = 512 * 9
+    env = np.where((np.arange(n) // 300) % 2 == 0, 100.0, 8.0)                 # on/off keyed carrier
+    i = np.clip(127.5 + env * np.cos(0.3 * np.arange(n)) + rng.normal(0, 2, n), 0, 255)
+    q = np.clip(127.5 + env * np.sin(0.3 * np.arange(n)) + rng.normal(0, 2, n), 0, 255)
+    raw = np.stack([i, q], axis=1).astype(np.uint8).reshape(-1)
+    xs = O.data_to_samples(raw)
+    mag = O.norm(xs)
+    bitsv = O.discretize(mag).astype(np.uint8)
+    runs = O.Rle().feed(bitsv)
+    out["raw"] = raw
+    out["mag"] = mag
+    out["block_sums"] = np.array([O.block_sum(mag[b * 512:(b + 1) * 512]) for b in range(n // 512)], np.float32)
+    out["bits"] = bitsv
+    out["run_values"] = np.array([r[0] for r in runs], np.uint8)
+    out["run_counts"] = np.array([r[1] for r in runs], np.int64)
+    return out
+
+
+def pfb_generic_cases():
+    out = {}
+    for M, P in ((32, 4), (100, 3)):
+        h = O.synth_f32(0x5EED0B, 0, M * P)
+        x = O.synth_iq(0x5EED0004 + M, 0, M * (P + 6))
+        out.update({f"m{M}_x": x, f"m{M}_proto": h, f"m{M}_y": O.pfb_channelizer(x, h, M, P, False)})
+    return out
+
+
+CASES = {"ovsave": ovsave_cases, "front_end": front_end_cases, "pfb_generic": pfb_generic_cases, "fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
 
 
 def generate(outdir=HERE):
