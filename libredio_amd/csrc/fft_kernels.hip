@@ -589,6 +589,148 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
     return hipGetLastError();
 }
 
+// ---- selected mixed-radix sizes (3 * 2^k, 5 * 2^k, 100, 1000): the same scheme with a compile-time factor list ----
+// kissfft's factor order (4s, then 2, then 3, 5; fft_plan_stages) evaluated at compile time; radix-4 neighbours run
+// as register pairs, every other stage as one pass over padded LDS; 4096 / N (at least one) transforms per
+// workgroup.  Butterflies, twiddle indices and stage order are the table-driven kernel's, so results are the same bits.
+template <int N>
+struct FftCt {
+    static constexpr int isqrt() { int r = 0; while ((r + 1) * (r + 1) <= N) ++r; return r; }
+    static constexpr int MAXS = 16;
+    struct List { int n; int p[MAXS], m[MAXS], fs[MAXS]; };
+    static constexpr List make()
+    {
+        List l{};
+        int p = 4, n = N, fstride = 1;
+        const int fsq = isqrt();
+        do {
+            while (n % p) {
+                switch (p) {
+                case 4: p = 2; break;
+                case 2: p = 3; break;
+                default: p += 2; break;
+                }
+                if (p > fsq) p = n;
+            }
+            n /= p;
+            l.p[l.n] = p; l.m[l.n] = n; l.fs[l.n] = fstride;
+            fstride *= p;
+            ++l.n;
+        } while (n > 1);
+        return l;
+    }
+    static constexpr List L = make();
+    static constexpr int T = N >= 4096 ? 1 : 4096 / N;
+    static constexpr int E = T * N;
+    static constexpr int LDS_ELEMS = E + (E >> 3) + 8;
+    __device__ static __forceinline__ int phys(int e) { return e + (e >> 3); }
+    __device__ static __forceinline__ int leaf_pos(int n)
+    {
+        int P = 0;
+#pragma unroll
+        for (int s = 0; s < L.n; ++s) P += ((n / L.fs[s]) % L.p[s]) * L.m[s];
+        return P;
+    }
+    static constexpr bool supported()
+    {
+        for (int s = 0; s < L.n; ++s)
+            if (L.p[s] > 5) return false;
+        return true;
+    }
+};
+
+struct CtView { // one transform inside the padded batch image
+    float2 *p; int off;
+    __device__ __forceinline__ float2 &operator[](int i) const { const int e = off + i; return p[e + (e >> 3)]; }
+};
+
+template <int N, bool INV, int S>
+__device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restrict__ tw, int tid)
+{
+    using F = FftCt<N>;
+    if constexpr (S >= 0) {
+        constexpr int P = F::L.p[S], M = F::L.m[S], FS = F::L.fs[S];
+        if constexpr (P == 4 && S >= 1 && F::L.p[S >= 1 ? S - 1 : 0] == 4) {
+            constexpr int FS2 = F::L.fs[S - 1];
+#pragma unroll 1
+            for (int g = tid; g < F::E / 16; g += 256) {
+                const int xf = g / (N / 16), gl = g % (N / 16);
+                const int blk = gl / M, kk = gl % M;
+                const int base = xf * N + blk * 16 * M + kk;
+                float2 a[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[j] = Ls[F::phys(base + j * M)];
+                const float2 t1 = tw[kk * FS], t2 = tw[2 * kk * FS], t3 = tw[3 * kk * FS];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k2 = (kk + u * M) * FS2;
+                    bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k2], tw[2 * k2], tw[3 * k2]);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) Ls[F::phys(base + j * M)] = a[j];
+            }
+            __syncthreads();
+            fftct_stages<N, INV, S - 2>(Ls, tw, tid);
+        } else {
+            constexpr FftStage st = {P, M, FS};
+#pragma unroll 1
+            for (int bb = tid; bb < F::E / P; bb += 256) {
+                const int xf = bb / (N / P), b = bb % (N / P);
+                fft_stage_butterfly_gk<INV>(CtView{Ls, xf * N}, tw, st, b / M, b % M);
+            }
+            __syncthreads();
+            fftct_stages<N, INV, S - 1>(Ls, tw, tid);
+        }
+    }
+}
+
+template <int N, bool INV>
+__global__ __launch_bounds__(256) void fft_ct_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch, long in_stride)
+{
+    using F = FftCt<N>;
+    static_assert(F::supported(), "radices up to 5 only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *Ls = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const long b0 = (long)blockIdx.x * F::T;
+#pragma unroll 4
+    for (int e = tid; e < F::E; e += 256) {
+        const int xf = e / N, n = e % N;
+        const long b = (b0 + xf < nbatch) ? b0 + xf : nbatch - 1;
+        Ls[F::phys(xf * N + F::leaf_pos(n))] = in[b * in_stride + n];
+    }
+    __syncthreads();
+    fftct_stages<N, INV, F::L.n - 1>(Ls, tw, tid);
+#pragma unroll 4
+    for (int e = tid; e < F::E; e += 256) {
+        const int xf = e / N;
+        if (b0 + xf < nbatch) out[(b0 + xf) * N + (e % N)] = Ls[F::phys(e)];
+    }
+}
+
+template <int N>
+static hipError_t launch_fft_ct(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, long in_stride, bool inv, hipStream_t s)
+{
+    using F = FftCt<N>;
+    // the compile-time list must be the plan's (it is the same algorithm; a mismatch would mean a different build)
+    if (p.nstages != F::L.n) return hipErrorNotSupported;
+    for (int i = 0; i < F::L.n; ++i)
+        if (p.st[i].p != F::L.p[i] || p.st[i].m != F::L.m[i] || p.st[i].fstride != F::L.fs[i]) return hipErrorNotSupported;
+    const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
+    auto kf = fft_ct_kernel<N, false>;
+    auto ki = fft_ct_kernel<N, true>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned grid = (unsigned)((nbatch + F::T - 1) / F::T);
+    if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+    else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+    return hipGetLastError();
+}
+
 // ---- any N that fits LDS: one workgroup per transform ----------------------------------------
 template <bool INV>
 __global__ __launch_bounds__(256) void fft_lds_kernel(FftPlanDev p, const float2 *in,
@@ -885,6 +1027,17 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     if (p.nfft == F64K_N) {
         if (in == out) return hipErrorNotSupported; // pass 0 is a global transposition: the C-ABI layer stages in-place calls
         return inv ? launch_fft64k<true>(in, out, p.tw, nbatch, in_stride, s) : launch_fft64k<false>(in, out, p.tw, nbatch, in_stride, s);
+    }
+    {   // sizes with a compile-time pass list
+        hipError_t e = hipErrorNotSupported;
+        switch (p.nfft) {
+#define REDIO_CT(NN) case NN: e = launch_fft_ct<NN>(p, in, out, nbatch, in_stride, inv, s); break;
+            REDIO_CT(96) REDIO_CT(192) REDIO_CT(384) REDIO_CT(768) REDIO_CT(1536) REDIO_CT(3072) REDIO_CT(6144)
+            REDIO_CT(160) REDIO_CT(320) REDIO_CT(640) REDIO_CT(1280) REDIO_CT(2560) REDIO_CT(100) REDIO_CT(1000)
+#undef REDIO_CT
+        default: break;
+        }
+        if (e != hipErrorNotSupported) return e;
     }
     bool generic = false;
     for (int i = 0; i < p.nstages; ++i) generic |= p.st[i].p > 5;

@@ -100,7 +100,7 @@ def test_fir_decimate_is_stride_of_full(gpu, redio, oracle):
 
 
 # ---------------------------------------------------------------- FFT
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 30, 32, 64, 100, 128, 243, 256, 512, 1000, 1024, 2048, 4096, 8192, 11, 221])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 30, 32, 64, 96, 100, 128, 160, 192, 243, 256, 320, 384, 512, 640, 768, 1000, 1024, 1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192, 11, 221])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_bit_exact(gpu, redio, oracle, n, inverse):
     nb = 5
