@@ -824,6 +824,21 @@ __global__ __launch_bounds__(256) void fft_global_stage_kernel(FftPlanDev p, int
     fft_stage_butterfly<INV>(data + b * p.nfft, p.tw, st, bf);
 }
 
+// a generic-radix stage (prime factor above 5) in global memory, out of place: one output element per thread
+template <bool INV>
+__global__ __launch_bounds__(256) void fft_global_generic_stage_kernel(FftPlanDev p, int s, const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                                       long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const FftStage st = p.st[s];
+    const long b = i / p.nfft;
+    const int e = (int)(i - b * p.nfft);
+    const int pm = st.p * st.m;
+    const int g = e / pm, r = e - g * pm, q1 = r / st.m, u = r - q1 * st.m;
+    dst[i] = fft_generic_output(src + b * p.nfft, p.tw, st, p.nfft, g, u, q1);
+}
+
 // ---- N = 65536: two passes of four in-LDS radix-4 stages (fft_core.h, "65536-point transform") ----
 // One workgroup per 256 x 16 tile; rows are 128 contiguous bytes in memory.  PASS 0 gathers the
 // digit-reversed input (in -> out), PASS 1 works in place on out.  32 B of HBM traffic per sample
@@ -970,7 +985,7 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
     return hipGetLastError();
 }
 
-hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride)
+hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride, float2 *work)
 {
     if (in_stride <= 0) in_stride = p.nfft; // consecutive messages; smaller strides give overlapping blocks (overlap-save)
     if (nbatch <= 0) return hipSuccess;
@@ -1073,14 +1088,28 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         return hipGetLastError();
     }
-    if (generic || in == out) return hipErrorNotSupported; // the C-ABI layer routes in-place calls through a temporary
+    // global-memory stages.  The C-ABI layer routes in-place calls through a temporary and supplies `work`
+    // (nbatch * nfft elements) when a generic-radix stage needs an out-of-place step.
+    if (in == out || (generic && !work)) return hipErrorNotSupported;
     const long total = nbatch * p.nfft;
-    hipLaunchKernelGGL(fft_global_leaf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, in, out, total, in_stride);
+    const unsigned egrid = (unsigned)((total + 255) / 256);
+    float2 *cur = out, *other = work;
+    hipLaunchKernelGGL(fft_global_leaf_kernel, dim3(egrid), dim3(256), 0, s, p, in, cur, total, in_stride);
     for (int st = p.nstages - 1; st >= 0; --st) {
+        if (p.st[st].p > 5) {
+            if (inv) hipLaunchKernelGGL(fft_global_generic_stage_kernel<true>, dim3(egrid), dim3(256), 0, s, p, st, cur, other, total);
+            else hipLaunchKernelGGL(fft_global_generic_stage_kernel<false>, dim3(egrid), dim3(256), 0, s, p, st, cur, other, total);
+            float2 *t = cur; cur = other; other = t;
+            continue;
+        }
         const long nb = nbatch * (p.nfft / p.st[st].p);
         const unsigned grid = (unsigned)((nb + 255) / 256);
-        if (inv) hipLaunchKernelGGL(fft_global_stage_kernel<true>, dim3(grid), dim3(256), 0, s, p, st, out, nb);
-        else hipLaunchKernelGGL(fft_global_stage_kernel<false>, dim3(grid), dim3(256), 0, s, p, st, out, nb);
+        if (inv) hipLaunchKernelGGL(fft_global_stage_kernel<true>, dim3(grid), dim3(256), 0, s, p, st, cur, nb);
+        else hipLaunchKernelGGL(fft_global_stage_kernel<false>, dim3(grid), dim3(256), 0, s, p, st, cur, nb);
+    }
+    if (cur != out) {
+        hipError_t e = hipMemcpyAsync(out, cur, (size_t)total * sizeof(float2), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
     }
     return hipGetLastError();
 }

@@ -363,6 +363,26 @@ extern "C" int redio_fft_destroy(redio_fft *h)
     delete h;
     return REDIO_OK;
 }
+// the retry of a launch that asked for staging: tmp = [input copy | work], grown on first use / growth only
+static int fft_enqueue_staged(redio_fft *h, const float2 *d_in, float2 *d_out, size_t nbatch, long in_stride, hipStream_t st)
+{
+    const size_t need = nbatch * (size_t)h->dev.nfft;
+    if (2 * need > h->tmp_elems) {
+        if (h->d_tmp) hipFree(h->d_tmp);
+        h->d_tmp = nullptr; h->tmp_elems = 0;
+        RD_TRY(hipMalloc((void **)&h->d_tmp, 2 * need * sizeof(float2)));
+        h->tmp_elems = 2 * need;
+    }
+    const float2 *src = d_in;
+    if (d_in == d_out) { // only reachable with contiguous messages (in_stride == nfft)
+        RD_TRY(hipMemcpyAsync(h->d_tmp, d_in, need * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        src = h->d_tmp;
+    }
+    hipError_t e = launch_fft(h->dev, src, d_out, (long)nbatch, st, in_stride, h->d_tmp + need);
+    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
+    return hip_rc(e);
+}
+
 extern "C" int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, void *stream)
 {
     if (!h) return REDIO_ERR_ARG;
@@ -370,20 +390,9 @@ extern "C" int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, si
     if (!d_in || !d_out) return REDIO_ERR_ARG;
     RD_TRY(hipSetDevice(h->device));
     hipError_t e = launch_fft(h->dev, (const float2 *)d_in, (float2 *)d_out, (long)nbatch, (hipStream_t)stream);
-    if (e == hipErrorNotSupported && d_in == d_out) {
-        // global-memory path, in place: stage through a plan-owned temporary (grown outside of any
-        // capture; a caller that needs graph capture passes distinct buffers)
-        size_t need = nbatch * (size_t)h->dev.nfft;
-        if (need > h->tmp_elems) {
-            if (h->d_tmp) hipFree(h->d_tmp);
-            h->d_tmp = nullptr; h->tmp_elems = 0;
-            RD_TRY(hipMalloc((void **)&h->d_tmp, need * sizeof(float2)));
-            h->tmp_elems = need;
-        }
-        RD_TRY(hipMemcpyAsync(h->d_tmp, d_in, need * sizeof(float2), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        e = launch_fft(h->dev, h->d_tmp, (float2 *)d_out, (long)nbatch, (hipStream_t)stream);
-    }
-    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
+    // global-memory path in place, or a prime factor above 5 in a size that does not fit LDS: stage through the
+    // plan-owned temporary (a caller that needs graph capture runs the sequence once before capturing)
+    if (e == hipErrorNotSupported) return fft_enqueue_staged(h, (const float2 *)d_in, (float2 *)d_out, nbatch, 0, (hipStream_t)stream);
     return hip_rc(e);
 }
 
@@ -396,7 +405,7 @@ extern "C" int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d
     if (!d_in || !d_out || d_in == d_out || in_stride <= 0) return REDIO_ERR_ARG;
     RD_TRY(hipSetDevice(h->device));
     hipError_t e = launch_fft(h->dev, (const float2 *)d_in, (float2 *)d_out, (long)nbatch, (hipStream_t)stream, in_stride);
-    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
+    if (e == hipErrorNotSupported) return fft_enqueue_staged(h, (const float2 *)d_in, (float2 *)d_out, nbatch, in_stride, (hipStream_t)stream);
     return hip_rc(e);
 }
 
@@ -487,9 +496,7 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     size_t need_in = (ny - 1) * h->fir->decim + h->fir->ntaps; // inputs feeding the kept blocks
     RD_TRY(launch_fir(d_in, (long)need_in, h->fir->d_taps, (int)h->fir->ntaps, (long)h->fir->decim, h->d_mid, (long)ny,
                       true, fused_math, (hipStream_t)stream));
-    hipError_t e = launch_fft(h->fft->dev, h->d_mid, (float2 *)d_out, (long)nblk, (hipStream_t)stream);
-    if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
-    return hip_rc(e);
+    return redio_fft_enqueue(h->fft, h->d_mid, d_out, nblk, stream);
 }
 
 // ---------------------------------------------------------------- synthetic input

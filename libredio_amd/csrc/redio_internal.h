@@ -24,9 +24,10 @@ struct FftPlanDev {
     unsigned magic_m[FFT_MAX_STAGES]; // ceil(2^32 / m) per stage and ceil(2^32 / nfft): exact quotients by __umulhi for
     unsigned magic_n;                 // dividends below 2^16 * ... (b * m < 2^32), which LDS-resident sizes satisfy
 };
-// in != out required unless work is given; work (nfft*nbatch float2) is used for in-place calls and
-// by the global-memory path
-hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0);
+// in != out on the paths that say so (hipErrorNotSupported otherwise: the C-ABI layer stages the input); work
+// (nfft*nbatch float2) is needed by the global-memory path when the size has a prime factor above 5
+hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0,
+                      float2 *work = nullptr);
 
 // overlap-save at nfft 1024 (one wave per block) and 4096: one kernel, no work buffers
 hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,

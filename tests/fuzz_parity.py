@@ -23,7 +23,7 @@ def check(name, ok, detail):
 
 t_end = time.time() + budget
 while time.time() < t_end:
-    which = rng.integers(0, 8)
+    which = rng.integers(0, 10)
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
@@ -109,6 +109,33 @@ while time.time() < t_end:
         ok = ok and np.array_equal(bits(K.mul_vecs(dx, dc).cpu().numpy()), bits(O.zip_vecs(x[o3:], c, add=False)))
         ok = ok and np.array_equal(bits(K.sum_vecs(dx, dc).cpu().numpy()), bits(O.zip_vecs(x[o3:], c, add=True)))
         check("runs", ok, (n, off, cplx, m, o3))
+    elif which == 8:    # the host-buffer drop-ins: kiss_fft (zero-copy and copy paths) and convolve (per-thread cache)
+        from libredio_amd import kissfft, dsputils
+        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 15)), 8192, 8193, 16384]))
+        inv = int(rng.integers(0, 2))
+        cfg = kissfft.Cfg(n, inv)
+        ok = True
+        for _ in range(3):
+            x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n)
+            ok = ok and np.array_equal(bits(cfg(x)), bits(O.fft(x, n, bool(inv))))
+        cfg.close()
+        nu, nv = int(rng.integers(1, 100000)), int(rng.choice([1, 3, 63, 64, 127, int(rng.integers(1, 400))]))
+        u, v = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, nu), O.synth_f32(int(rng.integers(1, 1 << 30)), 0, nv)
+        got, want = dsputils.convolve(u, v), O.convolve(u, v)
+        ok = ok and got.shape == want.shape and np.array_equal(bits(got), bits(want))
+        check("dropin", ok, (n, inv, nu, nv))
+    elif which == 9:    # src_process drop-in (host buffers, one state, random messages)
+        from libredio_amd import samplerate
+        conv = int(rng.integers(0, 3))
+        ratio = float(rng.choice([0.02, 0.5, 1.0, 2.0, 0.25, 1.0884, float(rng.uniform(0.01, 3.0))]))
+        st, ref, ok = samplerate.State(conv, 1), O.Resampler(conv), True
+        for _ in range(int(rng.integers(1, 5))):
+            m = int(rng.integers(1, 20000))
+            x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m)
+            a, b = st.block(x, ratio), ref.block(x, ratio)
+            ok = ok and len(a) == len(b) and np.array_equal(bits(a), bits(b))
+        st.close()
+        check("srcdrop", ok, (conv, ratio))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40])); conv = int(rng.integers(0, 3))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 1 / 7, float(rng.uniform(0.01, 3.0))]))

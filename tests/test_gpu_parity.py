@@ -110,6 +110,19 @@ def test_fft_bit_exact(gpu, redio, oracle, n, inverse):
     assert same_bits(got, want), (n, inverse)
 
 
+@pytest.mark.parametrize("n", [8193, 8209, 9 * 1031, 2 * 8191, 20011])
+def test_fft_large_sizes_with_big_prime_factors(gpu, redio, oracle, n):
+    # too large for the out-of-place generic butterfly in LDS: global-memory stages, the generic radix out of place
+    x = oracle.synth_iq(n, 0, n * 2)
+    d = gpu.from_numpy(x).cuda()
+    want = oracle.fft(x, n, False)
+    assert same_bits(redio.Fft(n, False)(d).cpu().numpy(), want)
+    redio.Fft(n, False)(d, out=d)                      # in place
+    assert same_bits(d.cpu().numpy(), want)
+    xi = oracle.synth_iq(n + 1, 0, n)
+    assert same_bits(redio.Fft(n, True)(gpu.from_numpy(xi).cuda()).cpu().numpy(), oracle.fft(xi, n, True))
+
+
 @pytest.mark.parametrize("n", [16384, 65536])
 def test_fft_large_global_path(gpu, redio, oracle, n):
     x = oracle.synth_iq(n, 0, n * 2)
