@@ -25,18 +25,19 @@ t_end = time.time() + budget
 while time.time() < t_end:
     which = rng.integers(0, 10)
     if which == 0:      # FIR, any K / D / length / alignment
-        k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000))]))
+        k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000)), int(rng.integers(2000, 20000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
         cplx, fused = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-        n = k - 1 + int(rng.integers(0, 30000)); off = int(rng.integers(0, 4))
+        n = k - 1 + int(rng.integers(0, 30000 if k < 2000 else 3000)); off = int(rng.integers(0, 4))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
         x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, n + off)
         got = R.Fir(taps, d, complex_input=cplx, fused=fused)(torch.from_numpy(x).cuda()[off:]).cpu().numpy()
         want = O.fir(x[off:], taps, d, fused)
         check("fir", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, cplx, fused, n, off))
     elif which == 1:    # FFT, any size
-        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 15)), 3 * 2 ** int(rng.integers(0, 10)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 6))]))
-        inv = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 70))
+        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 17)), 3 * 2 ** int(rng.integers(0, 12)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 8)),
+                            int(rng.integers(3000, 70000))]))
+        inv = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 70 if n < 4000 else 4))
         x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n * nb)
         d = torch.from_numpy(x).cuda()
         plan = R.Fft(n, inv)
@@ -47,15 +48,16 @@ while time.time() < t_end:
         check("fft", ok, (n, inv, nb))
     elif which == 2:    # chain shapes
         k, dd = [(127, 5), (63, 5), (127, 3), (127, 1), (63, 1), (100, 2), (31, 4)][int(rng.integers(0, 7))]
-        fused = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 40)); extra = int(rng.integers(0, 1024 * dd))
+        nfc = int(rng.choice([1024, 1024, 256, 4096, 1000, 64, 2048]))
+        fused = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 40 if nfc <= 1024 else 6)); extra = int(rng.integers(0, nfc * dd))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
-        n = nb * 1024 * dd + (k - dd) + extra
+        n = nb * nfc * dd + (k - dd) + extra
         x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n)
-        got = R.Chain(taps, dd, 1024, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
-        want = O.chain_fir_fft(x, taps, dd, 1024, fused=fused)
-        check("chain", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, fused, nb, extra))
+        got = R.Chain(taps, dd, nfc, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.chain_fir_fft(x, taps, dd, nfc, fused=fused)
+        check("chain", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, nfc, fused, nb, extra))
     elif which == 3:    # overlap-save
-        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 1000]))
+        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 1000, int(rng.integers(2, 12000))]))
         k = int(rng.integers(1, nfft + 1)); hop = nfft - k + 1
         n = nfft + int(rng.integers(0, 6)) * hop + int(rng.integers(0, hop))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
@@ -64,8 +66,8 @@ while time.time() < t_end:
         want = O.overlap_save(x, taps, nfft)
         check("ovsave", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nfft, k, n))
     elif which == 4:    # channelizer, any M / P
-        M = int(rng.choice([64, 32, 16, 128, 100, 7, int(rng.integers(1, 300))])); P = int(rng.choice([4, 8, 16, int(rng.integers(1, 20))]))
-        fused = bool(rng.integers(0, 2)); rows = int(rng.integers(0, 200))
+        M = int(rng.choice([64, 32, 16, 128, 100, 7, int(rng.integers(1, 300)), int(rng.integers(300, 9000))])); P = int(rng.choice([4, 8, 16, int(rng.integers(1, 20))]))
+        fused = bool(rng.integers(0, 2)); rows = int(rng.integers(0, 200 if M < 300 else 12))
         h = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, M * P)
         x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, M * (P - 1 + rows) + int(rng.integers(0, M)))
         got = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
@@ -137,9 +139,9 @@ while time.time() < t_end:
         st.close()
         check("srcdrop", ok, (conv, ratio))
     else:               # resampler, batched, random ratio and message cuts
-        nch = int(rng.choice([1, 3, 40])); conv = int(rng.integers(0, 3))
-        ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 1 / 7, float(rng.uniform(0.01, 3.0))]))
-        n = int(rng.integers(1, 40000))
+        nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 3))
+        ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
+        n = int(rng.integers(1, 40000 if ratio < 10 else 400))
         x = np.stack([O.synth_f32(int(rng.integers(1, 1 << 30)), 0, n) for _ in range(nch)])
         plan = R.Src(nch, conv, mode=int(rng.choice([0, 2])))
         refs = [O.Resampler(conv) for _ in range(nch)]
