@@ -168,3 +168,19 @@ if "chains" in which:
         ms = timeit(lambda: plan(x, out), n=10, warm=3)
         b = 8 + 8 / d
         print(f"chain K={k} D={d} -> FFT 1024 ({'one kernel' if plan.is_fused else 'two kernels'}): {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  ({b*m/ms/1e6/8000:.1%} of 8 TB/s)")
+if "trigger" in which:
+    # bitfount::trigger on a long capture: bursts every ~2^20 samples on a noise floor (block sums on the device,
+    # the state machine on the host, triggered blocks gathered on the device)
+    import time
+    from libredio_amd import bitfount as B
+    ns = 1 << 27
+    mag = torch.rand(ns, device="cuda") * 0.05
+    idx = torch.arange(ns, device="cuda")
+    mag += ((idx % (1 << 20)) < 60000).float() * 0.8
+    blocks = mag.view(-1, 512)
+    trig = B.Trigger()
+    trig.feed(blocks[:4096])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    bufs = trig.feed(blocks)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"trigger over {ns} samples ({blocks.shape[0]} blocks): {dt*1e3:.2f} ms  {ns/dt/1e9:.1f} GS/s, {len(bufs)} buffers emitted, {sum(b.numel() for b in bufs)} samples kept")
