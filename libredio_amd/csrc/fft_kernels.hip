@@ -589,9 +589,10 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
     return hipGetLastError();
 }
 
-// ---- selected mixed-radix sizes (3 * 2^k, 5 * 2^k, 100, 1000): the same scheme with a compile-time factor list ----
+// ---- the common 2^a 3^b 5^c sizes up to 8000 (see the dispatch list): the same scheme with a compile-time factor list ----
 // kissfft's factor order (4s, then 2, then 3, 5; fft_plan_stages) evaluated at compile time; radix-4 neighbours run
-// as register pairs, every other stage as one pass over padded LDS; 4096 / N (at least one) transforms per
+// as register pairs -- as do any two neighbours of up to 25 points (3x2, 5x5, 5x2, 5x4 ...) -- and a stage left
+// over as one pass over padded LDS; 4096 / N (at least one) transforms per
 // workgroup.  Butterflies, twiddle indices and stage order are the table-driven kernel's, so results are the same bits.
 template <int N>
 struct FftCt {
@@ -644,32 +645,55 @@ struct CtView { // one transform inside the padded batch image
     __device__ __forceinline__ float2 &operator[](int i) const { const int e = off + i; return p[e + (e >> 3)]; }
 };
 
+// one radix-P butterfly on P contiguous register values: index k inside the sub-length m, twiddle stride fs
+// (the argument lists of fft_stage_butterfly_gk)
+template <int P, bool INV>
+__device__ __forceinline__ void fftct_bfly(float2 (&a)[P], const float2 *__restrict__ tw, int k, int fs, int m)
+{
+    if constexpr (P == 2) bfly2(a[0], a[1], tw[k * fs]);
+    else if constexpr (P == 3) bfly3(a[0], a[1], a[2], tw[k * fs], tw[2 * k * fs], tw[fs * m]);
+    else if constexpr (P == 4) bfly4<INV>(a[0], a[1], a[2], a[3], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs]);
+    else bfly5(a[0], a[1], a[2], a[3], a[4], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs], tw[4 * k * fs], tw[fs * m], tw[fs * 2 * m]);
+}
+
 template <int N, bool INV, int S>
 __device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restrict__ tw, int tid)
 {
     using F = FftCt<N>;
     if constexpr (S >= 0) {
         constexpr int P = F::L.p[S], M = F::L.m[S], FS = F::L.fs[S];
-        if constexpr (P == 4 && S >= 1 && F::L.p[S >= 1 ? S - 1 : 0] == 4) {
-            constexpr int FS2 = F::L.fs[S - 1];
+        constexpr int PO = S >= 1 ? F::L.p[S >= 1 ? S - 1 : 0] : 0; // the next stage out
+        if constexpr (S >= 1 && P * PO <= 25) {
+            // two stages in registers: P*PO points base + j*M; inner radix P (sub-length M), outer radix PO (sub-length P*M)
+            constexpr int FS2 = F::L.fs[S - 1], G = P * PO;
 #pragma unroll 1
-            for (int g = tid; g < F::E / 16; g += 256) {
-                const int xf = g / (N / 16), gl = g % (N / 16);
+            for (int g = tid; g < F::E / G; g += 256) {
+                const int xf = g / (N / G), gl = g % (N / G);
                 const int blk = gl / M, kk = gl % M;
-                const int base = xf * N + blk * 16 * M + kk;
-                float2 a[16];
+                const int base = xf * N + blk * G * M + kk;
+                float2 a[G];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) a[j] = Ls[F::phys(base + j * M)];
-                const float2 t1 = tw[kk * FS], t2 = tw[2 * kk * FS], t3 = tw[3 * kk * FS];
+                for (int j = 0; j < G; ++j) a[j] = Ls[F::phys(base + j * M)];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+                for (int q = 0; q < PO; ++q) {
+                    float2 b[P];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k2 = (kk + u * M) * FS2;
-                    bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k2], tw[2 * k2], tw[3 * k2]);
+                    for (int i = 0; i < P; ++i) b[i] = a[q * P + i];
+                    fftct_bfly<P, INV>(b, tw, kk, FS, M);
+#pragma unroll
+                    for (int i = 0; i < P; ++i) a[q * P + i] = b[i];
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) Ls[F::phys(base + j * M)] = a[j];
+                for (int u = 0; u < P; ++u) {
+                    float2 b[PO];
+#pragma unroll
+                    for (int i = 0; i < PO; ++i) b[i] = a[u + P * i];
+                    fftct_bfly<PO, INV>(b, tw, kk + u * M, FS2, P * M);
+#pragma unroll
+                    for (int i = 0; i < PO; ++i) a[u + P * i] = b[i];
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) Ls[F::phys(base + j * M)] = a[j];
             }
             __syncthreads();
             fftct_stages<N, INV, S - 2>(Ls, tw, tid);
@@ -1047,8 +1071,16 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         hipError_t e = hipErrorNotSupported;
         switch (p.nfft) {
 #define REDIO_CT(NN) case NN: e = launch_fft_ct<NN>(p, in, out, nbatch, in_stride, inv, s); break;
-            REDIO_CT(96) REDIO_CT(192) REDIO_CT(384) REDIO_CT(768) REDIO_CT(1536) REDIO_CT(3072) REDIO_CT(6144)
-            REDIO_CT(160) REDIO_CT(320) REDIO_CT(640) REDIO_CT(1280) REDIO_CT(2560) REDIO_CT(100) REDIO_CT(1000)
+            REDIO_CT(6) REDIO_CT(9) REDIO_CT(10) REDIO_CT(12) REDIO_CT(15) REDIO_CT(20) REDIO_CT(24) REDIO_CT(25)
+            REDIO_CT(27) REDIO_CT(30) REDIO_CT(40) REDIO_CT(45) REDIO_CT(48) REDIO_CT(60) REDIO_CT(75) REDIO_CT(80)
+            REDIO_CT(81) REDIO_CT(90) REDIO_CT(96) REDIO_CT(100) REDIO_CT(120) REDIO_CT(125) REDIO_CT(150) REDIO_CT(160)
+            REDIO_CT(180) REDIO_CT(192) REDIO_CT(200) REDIO_CT(225) REDIO_CT(240) REDIO_CT(243) REDIO_CT(250) REDIO_CT(300)
+            REDIO_CT(320) REDIO_CT(360) REDIO_CT(384) REDIO_CT(400) REDIO_CT(450) REDIO_CT(480) REDIO_CT(500) REDIO_CT(600)
+            REDIO_CT(625) REDIO_CT(640) REDIO_CT(720) REDIO_CT(729) REDIO_CT(768) REDIO_CT(800) REDIO_CT(900) REDIO_CT(960)
+            REDIO_CT(1000) REDIO_CT(1200) REDIO_CT(1280) REDIO_CT(1440) REDIO_CT(1536) REDIO_CT(1600) REDIO_CT(1800) REDIO_CT(1920)
+            REDIO_CT(2000) REDIO_CT(2187) REDIO_CT(2400) REDIO_CT(2560) REDIO_CT(3072) REDIO_CT(3125) REDIO_CT(3200) REDIO_CT(3600)
+            REDIO_CT(3840) REDIO_CT(4000) REDIO_CT(4800) REDIO_CT(5120) REDIO_CT(6144) REDIO_CT(6400) REDIO_CT(6561) REDIO_CT(7680)
+            REDIO_CT(8000)
 #undef REDIO_CT
         default: break;
         }

@@ -110,6 +110,24 @@ def test_fft_bit_exact(gpu, redio, oracle, n, inverse):
     assert same_bits(got, want), (n, inverse)
 
 
+CT_SIZES = [6, 9, 10, 12, 15, 20, 24, 25, 27, 30, 40, 45, 48, 60, 75, 80, 81, 90, 120, 125, 150, 180, 200, 225, 240, 250, 300, 360,
+            400, 450, 480, 500, 600, 625, 720, 729, 800, 900, 960, 1200, 1440, 1600, 1800, 1920, 2000, 2187, 2400, 3125, 3200,
+            3600, 3840, 4000, 4800, 5120, 6400, 6561, 7680, 8000]
+
+
+@pytest.mark.parametrize("n", CT_SIZES)
+def test_fft_compile_time_mixed_radix_sizes(gpu, redio, oracle, n):
+    # every 2^a 3^b 5^c size that has its own compile-time kernel (fft_kernels.hip, REDIO_CT list), ragged batch counts
+    nb = 7 if n < 2000 else 3
+    x = oracle.synth_iq(n + 17, 0, n * nb)
+    d = gpu.from_numpy(x).cuda()
+    for inverse in (False, True):
+        assert same_bits(redio.Fft(n, inverse)(d).cpu().numpy(), oracle.fft(x, n, inverse)), (n, inverse)
+    want = oracle.fft(x, n, False)
+    redio.Fft(n, False)(d, out=d)
+    assert same_bits(d.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("n", [8193, 8209, 9 * 1031, 2 * 8191, 20011])
 def test_fft_large_sizes_with_big_prime_factors(gpu, redio, oracle, n):
     # too large for the out-of-place generic butterfly in LDS: global-memory stages, the generic radix out of place

@@ -43,6 +43,13 @@ if "fft" in which:
         out = torch.empty_like(x)
         ms = timeit(lambda: plan(x, out=out), n=20 if nfft < 16384 else 5, warm=3)
         print(f"FFT {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  {16*x.numel()/ms/1e6:.0f} GB/s algorithmic ({16*x.numel()/ms/1e6/8000:.1%})")
+if "fftct" in which:
+    for nfft in (48, 60, 120, 200, 240, 360, 480, 500, 600, 720, 729, 800, 960, 1200, 1440, 1920, 2000, 2400, 3125, 3600, 3840, 4000, 4800, 5120, 6400, 7680, 8000):
+        x = R.synth_iq(2, 0, n)[: n // nfft * nfft]
+        plan = R.Fft(nfft)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: plan(x, out=out), n=10, warm=2)
+        print(f"FFT {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  ({16*x.numel()/ms/1e6/8000:.1%})")
 if "c3" in which or "c3big" in which:
     import time
     nch, frames = 256, (1 << 22) if "c3big" in which else (1 << 20)
