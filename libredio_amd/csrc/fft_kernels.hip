@@ -905,8 +905,12 @@ __global__ __launch_bounds__(256) void fft64k_pass_kernel(const float2 *in, floa
 }
 
 template <bool INV>
+static hipError_t launch_fft64k_wave(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s);
+static int f64k_use_wave_tiles();
+template <bool INV>
 static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
 {
+    if (f64k_use_wave_tiles()) return launch_fft64k_wave<INV>(in, out, tw, nbatch, in_stride, s);
     const size_t lds = 256 * F64K_LD * sizeof(float2);
     const unsigned grid = (unsigned)(nbatch * 16);
     hipLaunchKernelGGL((fft64k_pass_kernel<INV, 0>), dim3(grid), dim3(256), lds, s, in, out, tw, in_stride);
@@ -998,14 +1002,204 @@ __global__ __launch_bounds__(256) void ovsave64k_last_kernel(const float2 *__res
     }
 }
 
+static hipError_t launch_ovsave64k_wave(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
+                                        float2 *out, long nblk, float scale, hipStream_t s);
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
                             float2 *out, long nblk, float scale, hipStream_t s)
 {
+    if (f64k_use_wave_tiles()) return launch_ovsave64k_wave(x, hop, a, b, tw_f, tw_i, Hc, out, nblk, scale, s);
     const size_t lds = 256 * F64K_LD * sizeof(float2);
     const unsigned grid = (unsigned)(nblk * 16);
     hipLaunchKernelGGL((fft64k_pass_kernel<false, 0>), dim3(grid), dim3(256), lds, s, x, a, tw_f, hop);
     hipLaunchKernelGGL(ovsave64k_mid_kernel, dim3(grid), dim3(256), lds, s, a, b, tw_f, tw_i, Hc);
     hipLaunchKernelGGL(ovsave64k_last_kernel, dim3(grid), dim3(256), lds, s, b, out, tw_i, hop, scale);
+    return hipGetLastError();
+}
+
+// ---- N = 65536, one wavefront per 256 x 16 tile ---------------------------------------------------
+// The same two passes of four stages, but a tile belongs to ONE wave: lane (col = lane & 15, q = lane >> 4) loads
+// four 16-row groups of its column straight from memory into registers (64 points per lane), runs stages t = 0, 1,
+// trades rows with the other three lanes of its column through a wave-private LDS region (four rounds of 64 rows,
+// no workgroup barrier), runs stages t = 2, 3 and stores from registers.  One LDS round trip per pass instead of
+// three, index arithmetic per lane instead of per element.  Same butterflies in the same order: bit-identical.
+constexpr int F64W_LD = 17;
+constexpr int F64W_REGION = 64 * F64W_LD; // float2 per wave
+
+// workgroup b runs on XCD b % 8: give each XCD a contiguous range of tiles, so that the workgroups that share the 2 KiB
+// rows of one transform go through the same L2 at about the same time
+__device__ __forceinline__ long f64w_first_tile()
+{
+    const unsigned g = gridDim.x, b = blockIdx.x, per = g >> 3, rem = g & 7, x = b & 7, i = b >> 3;
+    const unsigned logical = x < rem ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+    return (long)logical * 4;
+}
+
+// a[i][j] = row 16 g + j of the lane's column, g = 4 i + q (BY_CLASS: g = 4 q + i)   ->
+// b[x][j] = row s + 16 j of column cc: (s, cc) = (q + 4 x, col), or with TRANSPOSE (lane & 15, 4 (lane >> 4) + x)
+template <bool BY_CLASS, bool TRANSPOSE>
+__device__ __forceinline__ void f64w_exchange(float2 (&a)[4][16], float2 (&b)[4][16], float2 *Lw, int lane)
+{
+    const int col = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { // round r moves the 64 rows of the four groups {slot r of every q}
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Lw[(16 * q + j) * F64W_LD + col] = a[r][j];
+        wave_lds_fence();
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int jabs = BY_CLASS ? r + 4 * jj : 4 * r + jj; // the group written by lane-quarter jj
+                const int s = TRANSPOSE ? col : q + 4 * x;
+                const int cc = TRANSPOSE ? 4 * q + x : col;
+                b[x][jabs] = Lw[(s + 16 * jj) * F64W_LD + cc];
+            }
+        wave_lds_fence();
+    }
+}
+
+template <bool INV, int PASS>
+__global__ __launch_bounds__(256, 2) void fft64k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
+                                                          long ntiles)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return; // wave-uniform; no workgroup barrier below
+    float2 *Lw = Ls + w * F64W_REGION;
+    const long xf = tile >> 4;
+    const int c = (int)(tile & 15), col = lane & 15, q = lane >> 4;
+    // addresses = wave-uniform pointer + compile-time row + one 32-bit lane offset (scalar base + vector offset loads)
+    const float2 *src = (PASS == 0 ? in + xf * in_stride : out + xf * F64K_N) + F64K_COLS * c;
+    float2 *dst = out + xf * F64K_N;
+    const unsigned lo_q1 = col + 256u * q, lo_q4 = col + 1024u * q, lo_q16 = col + 4096u * q;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { // row 16 (4i + q) + j in transform order; pass 0 reads the digit-reversed one
+            if (PASS == 0) a[i][j] = (src + 256 * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_q4];
+            else a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f64k_macro_regs<INV>(a[i], tw, PASS, 0, 0, F64K_COLS * c + col);
+    f64w_exchange<false, PASS == 0>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) f64k_macro_regs<INV>(b[x], tw, PASS, 2, PASS == 0 ? col : q + 4 * x, F64K_COLS * c + col);
+    if (PASS == 0) { // lane = (row s = lane & 15, column 4q + x): 128-byte runs of the transposed layout, f64k_p0_dst
+        const int rc = ((c & 3) << 2) | (c >> 2);
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) (dst + 256 * (64 * x + rc) + 16 * j)[lo_q16] = b[x][j];
+    } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) (dst + F64K_COLS * c + 256 * (4 * x + 16 * j))[lo_q1] = b[x][j];
+    }
+}
+
+// overlap-save middle pass: forward pass 1, spectrum product, inverse pass 0 on the same tile.  After the forward
+// stages lane (col, q) holds rows s + 16 j, s = q + 4 x: in the inverse transform's digit-reversed order that IS
+// group 4 q + x with rows in rev2 order, so the inverse starts from registers without another exchange.
+__global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out,
+                                                                 const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
+                                                                 const float2 *__restrict__ Hc, long ntiles)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    float2 *Lw = Ls + w * F64W_REGION;
+    const long xf = tile >> 4;
+    const int c = (int)(tile & 15), col = lane & 15, q = lane >> 4;
+    const float2 *src = a_in + xf * F64K_N + F64K_COLS * c;
+    float2 *dst = b_out + xf * F64K_N;
+    const unsigned lo_q1 = col + 256u * q, lo_q16 = col + 4096u * q;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f64k_macro_regs<false>(a[i], tw_f, 1, 0, 0, F64K_COLS * c + col);
+    f64w_exchange<false, false>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) f64k_macro_regs<false>(b[x], tw_f, 1, 2, q + 4 * x, F64K_COLS * c + col);
+    const float2 *hc = Hc + F64K_COLS * c;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) // row q + 4x + 16j = digit reversal of 16 (4q + x) + rev2(j)
+            a[x][((j & 3) << 2) | (j >> 2)] = cmul_rn(b[x][j], (hc + 256 * (4 * x + 16 * j))[lo_q1]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) f64k_macro_regs<true>(a[x], tw_i, 0, 0, 0, 0);
+    f64w_exchange<true, true>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) f64k_macro_regs<true>(b[x], tw_i, 0, 2, col, 0);
+    const int rc = ((c & 3) << 2) | (c >> 2);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) (dst + 256 * (64 * x + rc) + 16 * j)[lo_q16] = b[x][j];
+}
+
+__global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
+                                                                  const float2 *__restrict__ tw_i, long hop, float scale, long ntiles)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    float2 *Lw = Ls + w * F64W_REGION;
+    const long xf = tile >> 4;
+    const int c = (int)(tile & 15), col = lane & 15, q = lane >> 4;
+    const float2 *src = b_in + xf * F64K_N + F64K_COLS * c;
+    float2 *dst = out + xf * hop + F64K_COLS * c;
+    const unsigned lo_q1 = col + 256u * q, lo_q16 = col + 4096u * q;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f64k_macro_regs<true>(a[i], tw_i, 1, 0, 0, F64K_COLS * c + col);
+    f64w_exchange<false, false>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) f64k_macro_regs<true>(b[x], tw_i, 1, 2, q + 4 * x, F64K_COLS * c + col);
+    const long lim = hop - F64K_COLS * c - (long)lo_q1; // pos < hop
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (256 * (4 * x + 16 * j) < lim) (dst + 256 * (4 * x + 16 * j))[lo_q1] = make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale));
+}
+
+static int f64k_use_wave_tiles()
+{
+    static const int v = [] { const char *e = getenv("REDIO_F64K_WG_TILES"); return (e && e[0] == '1') ? 0 : 1; }();
+    return v;
+}
+
+template <bool INV>
+static hipError_t launch_fft64k_wave(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
+{
+    const long ntiles = nbatch * 16;
+    const unsigned grid = (unsigned)((ntiles + 3) / 4);
+    hipLaunchKernelGGL((fft64k_wave_kernel<INV, 0>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles);
+    hipLaunchKernelGGL((fft64k_wave_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles);
+    return hipGetLastError();
+}
+
+static hipError_t launch_ovsave64k_wave(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
+                                        float2 *out, long nblk, float scale, hipStream_t s)
+{
+    const long ntiles = nblk * 16;
+    const unsigned grid = (unsigned)((ntiles + 3) / 4);
+    hipLaunchKernelGGL((fft64k_wave_kernel<false, 0>), dim3(grid), dim3(256), 0, s, x, a, tw_f, hop, ntiles);
+    hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3(grid), dim3(256), 0, s, a, b, tw_f, tw_i, Hc, ntiles);
+    hipLaunchKernelGGL(ovsave64k_last_wave_kernel, dim3(grid), dim3(256), 0, s, b, out, tw_i, hop, scale, ntiles);
     return hipGetLastError();
 }
 
