@@ -14,10 +14,65 @@
 
 namespace redio {
 
+// bfly4 with the packed-f32 instructions picked by hand: 3 per complex product, 1 per complex sum = 17 per butterfly and no
+// register shuffles (the compiler's own packing of bfly4 spends about 30).  Every product and sum is rounded on its own, in
+// the same association as bfly4, so the results are the same bits.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REDIO_NO_PK_BFLY)
+#define REDIO_PK_BFLY 1
+typedef float redio_pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ redio_pk2 pk_cmul(redio_pk2 a, redio_pk2 t)
+{
+    redio_pk2 p, r, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(t));               // (a.x t.x, a.y t.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));   // (a.y t.y, a.x t.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(o) : "v"(p), "v"(r));                   // (p.x - r.x, p.y + r.y)
+    return o;
+}
+__device__ __forceinline__ redio_pk2 pk_add_rot_a(redio_pk2 a, redio_pk2 b) // (a.x + b.y, a.y - b.x)
+{
+    redio_pk2 o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ redio_pk2 pk_add_rot_b(redio_pk2 a, redio_pk2 b) // (a.x - b.y, a.y + b.x)
+{
+    redio_pk2 o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ redio_pk2 pk_add2(redio_pk2 a, redio_pk2 b)
+{
+    redio_pk2 o;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ redio_pk2 pk_sub2(redio_pk2 a, redio_pk2 b)
+{
+    redio_pk2 o;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+#endif
+
 // ---- radix-4 butterfly (kf_bfly4 order) ------------------------------------------------------
-template <bool INV>
+template <bool INV, bool PK = true> // PK = false: leave the instruction selection to the compiler (same arithmetic)
 RD_HD void bfly4(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 t1, float2 t2, float2 t3)
 {
+#if defined(REDIO_PK_BFLY)
+    if constexpr (PK) {
+    const redio_pk2 x0 = {a0.x, a0.y};
+    const redio_pk2 s0 = pk_cmul(redio_pk2{a1.x, a1.y}, redio_pk2{t1.x, t1.y});
+    const redio_pk2 s1 = pk_cmul(redio_pk2{a2.x, a2.y}, redio_pk2{t2.x, t2.y});
+    const redio_pk2 s2 = pk_cmul(redio_pk2{a3.x, a3.y}, redio_pk2{t3.x, t3.y});
+    const redio_pk2 s5 = pk_sub2(x0, s1), y0 = pk_add2(x0, s1);
+    const redio_pk2 s3 = pk_add2(s0, s2), s4 = pk_sub2(s0, s2);
+    const redio_pk2 o2 = pk_sub2(y0, s3), o0 = pk_add2(y0, s3);
+    const redio_pk2 o1 = INV ? pk_add_rot_b(s5, s4) : pk_add_rot_a(s5, s4);
+    const redio_pk2 o3 = INV ? pk_add_rot_a(s5, s4) : pk_add_rot_b(s5, s4);
+    a0 = make_float2(o0.x, o0.y); a1 = make_float2(o1.x, o1.y); a2 = make_float2(o2.x, o2.y); a3 = make_float2(o3.x, o3.y);
+    return;
+    }
+#endif
     float2 s0 = cmul_rn(a1, t1);
     float2 s1 = cmul_rn(a2, t2);
     float2 s2 = cmul_rn(a3, t3);
@@ -390,62 +445,6 @@ RD_HD void f64k_tile_butterfly(Ptr L, TwPtr tw, int pass, int t, int col, int b,
     L[(base + 2 * m) * F64K_LD + col] = a2; L[(base + 3 * m) * F64K_LD + col] = a3;
 }
 
-// bfly4 with the packed-f32 instructions picked by hand: 3 per complex product, 1 per complex sum = 17 per butterfly and no
-// register shuffles (the compiler's own packing of bfly4 spends about 30).  Every product and sum is rounded on its own, in
-// the same association as bfly4, so the results are the same bits.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float redio_pk2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ redio_pk2 pk_cmul(redio_pk2 a, redio_pk2 t)
-{
-    redio_pk2 p, r, o;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(t));               // (a.x t.x, a.y t.x)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));   // (a.y t.y, a.x t.y)
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(o) : "v"(p), "v"(r));                   // (p.x - r.x, p.y + r.y)
-    return o;
-}
-__device__ __forceinline__ redio_pk2 pk_add_rot_a(redio_pk2 a, redio_pk2 b) // (a.x + b.y, a.y - b.x)
-{
-    redio_pk2 o;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-__device__ __forceinline__ redio_pk2 pk_add_rot_b(redio_pk2 a, redio_pk2 b) // (a.x - b.y, a.y + b.x)
-{
-    redio_pk2 o;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-__device__ __forceinline__ redio_pk2 pk_add2(redio_pk2 a, redio_pk2 b)
-{
-    redio_pk2 o;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-__device__ __forceinline__ redio_pk2 pk_sub2(redio_pk2 a, redio_pk2 b)
-{
-    redio_pk2 o;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-template <bool INV>
-__device__ __forceinline__ void bfly4_pk(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 t1, float2 t2, float2 t3)
-{
-    const redio_pk2 x0 = {a0.x, a0.y};
-    const redio_pk2 s0 = pk_cmul(redio_pk2{a1.x, a1.y}, redio_pk2{t1.x, t1.y});
-    const redio_pk2 s1 = pk_cmul(redio_pk2{a2.x, a2.y}, redio_pk2{t2.x, t2.y});
-    const redio_pk2 s2 = pk_cmul(redio_pk2{a3.x, a3.y}, redio_pk2{t3.x, t3.y});
-    const redio_pk2 s5 = pk_sub2(x0, s1), y0 = pk_add2(x0, s1);
-    const redio_pk2 s3 = pk_add2(s0, s2), s4 = pk_sub2(s0, s2);
-    const redio_pk2 o2 = pk_sub2(y0, s3), o0 = pk_add2(y0, s3);
-    const redio_pk2 o1 = INV ? pk_add_rot_b(s5, s4) : pk_add_rot_a(s5, s4);
-    const redio_pk2 o3 = INV ? pk_add_rot_a(s5, s4) : pk_add_rot_b(s5, s4);
-    a0 = make_float2(o0.x, o0.y); a1 = make_float2(o1.x, o1.y); a2 = make_float2(o2.x, o2.y); a3 = make_float2(o3.x, o3.y);
-}
-#else
-template <bool INV>
-inline void bfly4_pk(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 t1, float2 t2, float2 t3) { bfly4<INV>(a0, a1, a2, a3, t1, t2, t3); }
-#endif
-
 // two in-tile stages t and t+1 (t = 0 or 2) on the 16 rows base + j*m of one column held in registers
 // (grp = 0..15, blk = grp >> 2t, kk = grp & (m - 1), base = blk*16m + kk)
 template <bool INV, typename TwPtr>
@@ -456,14 +455,14 @@ RD_HD void f64k_macro_regs(float2 (&a)[16], TwPtr tw, int pass, int t, int kk, i
         const int k = pass == 0 ? kk : k0 + 256 * kk;
         const int fs = pass == 0 ? (16384 >> (2 * t)) : (64 >> (2 * t));
         const float2 t1 = tw[(unsigned)(k * fs)], t2 = tw[(unsigned)(2 * k * fs)], t3 = tw[(unsigned)(3 * k * fs)];
-        for (int q = 0; q < 4; ++q) bfly4_pk<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+        for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
     }
     {
         const int fs = pass == 0 ? (16384 >> (2 * t + 2)) : (64 >> (2 * t + 2));
         for (int u = 0; u < 4; ++u) {
             const int k1 = kk + u * m; // index inside the 4m-block
             const int k = pass == 0 ? k1 : k0 + 256 * k1;
-            bfly4_pk<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[(unsigned)(k * fs)], tw[(unsigned)(2 * k * fs)], tw[(unsigned)(3 * k * fs)]);
+            bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[(unsigned)(k * fs)], tw[(unsigned)(2 * k * fs)], tw[(unsigned)(3 * k * fs)]);
         }
     }
 }
