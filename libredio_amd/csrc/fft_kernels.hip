@@ -214,9 +214,13 @@ __global__ __launch_bounds__(256) void ovsave4k_kernel(const float2 *__restrict_
     }
 }
 
+static hipError_t launch_ovsave4k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                                       float scale, hipStream_t s);
+static int fft4k_use_wave();
 hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s)
 {
+    if (fft4k_use_wave()) return launch_ovsave4k_wave(x, hop, tw_f, tw_i, Hc, out, nblk, scale, s);
     const size_t lds = 4 * FFT4K_REGION * sizeof(float2);
     hipLaunchKernelGGL(ovsave4k_kernel, dim3((unsigned)nblk), dim3(256), lds, s, x, hop, tw_f, tw_i, Hc, out, scale);
     return hipGetLastError();
@@ -1016,6 +1020,45 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
     return hipGetLastError();
 }
 
+// ---- two radix-4 stages on 16 points in registers, twiddles fetched ahead ---------------------------------
+// Stage A multiplies by tw[n kA fsA] (n = 1, 2, 3; the same for its four butterflies), stage B butterfly u by
+// tw[n (kB + u step) fsB].  The 15 values are loaded as one batch (behind a scheduling barrier where the caller wants the
+// next group's batch in flight during the current group's arithmetic); the compiler otherwise sinks each load to its use.
+struct FftTw15 { float2 t[15]; };
+template <typename TwPtr>
+__device__ __forceinline__ void tw15_load(FftTw15 &T, TwPtr tw, unsigned kA, unsigned fsA, unsigned kB, unsigned step, unsigned fsB)
+{
+    T.t[0] = tw[kA * fsA]; T.t[1] = tw[2 * kA * fsA]; T.t[2] = tw[3 * kA * fsA];
+#pragma unroll
+    for (unsigned u = 0; u < 4; ++u) {
+        const unsigned k = kB + u * step;
+        T.t[3 + 3 * u] = tw[k * fsB]; T.t[4 + 3 * u] = tw[2 * k * fsB]; T.t[5 + 3 * u] = tw[3 * k * fsB];
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void macro16_apply(float2 (&a)[16], const FftTw15 &T)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], T.t[0], T.t[1], T.t[2]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], T.t[3 + 3 * u], T.t[4 + 3 * u], T.t[5 + 3 * u]);
+}
+// four groups with per-group twiddles: batch g + 1 is requested before group g is computed
+template <bool INV, bool AHEAD = true, typename LoadFn>
+__device__ __forceinline__ void macro16_x4(float2 (&a)[4][16], FftTw15 &T0, LoadFn load)
+{
+    FftTw15 Tn;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (AHEAD && g < 3) load(Tn, g + 1);
+        RD_SCHED_BARRIER();
+        macro16_apply<INV>(a[g], T0);
+        if (g < 3) {
+            if (AHEAD) T0 = Tn;
+            else { RD_SCHED_BARRIER(); load(T0, g + 1); } // fewer live registers, one exposed latency per group
+        }
+    }
+}
 // ---- N = 65536, one wavefront per 256 x 16 tile ---------------------------------------------------
 // The same two passes of four stages, but a tile belongs to ONE wave: lane (col = lane & 15, q = lane >> 4) loads
 // four 16-row groups of its column straight from memory into registers (64 points per lane), runs stages t = 0, 1,
@@ -1176,6 +1219,135 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float
             if (256 * (4 * x + 16 * j) < lim) (dst + 256 * (4 * x + 16 * j))[lo_q1] = make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale));
 }
 
+// ---- N = 4096, one wavefront per transform ---------------------------------------------------------
+// Position e of the in-place working array = six base-4 digits (d5 .. d0); stage t combines digit d_t with the twiddle
+// index e mod 4^t.  A lane keeps 64 points in registers and runs the stages two at a time on 16-point groups:
+//   A: stages 0, 1 on (d0, d1)   lane = (d3 d4 d5) = the low digits of the digit-reversed source index, slot = d2
+//   B: stages 2, 3 on (d2, d3)   lane = (d1 d4 d5), slot = d0
+//   C: stages 4, 5 on (d4, d5)   lane = (d2 d1 d0) = the low digits of the output index, slot = d3
+// so the loads and the stores are 512 contiguous bytes per instruction, and the two regroupings go through a wave-private
+// LDS region in four rounds of 1024 points (no workgroup barrier anywhere).  kissfft's butterflies in kissfft's order.
+constexpr int F4W_SA = 80, F4W_SB = 65;     // padded strides of the two exchange layouts
+constexpr int F4W_REGION = 16 * F4W_SA;     // float2 per wave
+
+template <bool INV, bool AHEAD = true>
+__device__ __forceinline__ void fft4k_wave_regs(float2 (&a)[4][16], float2 (&b)[4][16], const float2 *__restrict__ tw, float2 *Lw, int lane)
+{
+    const unsigned hi = lane >> 4, low = lane & 15;
+    FftTw15 T;
+    // A: stages 0, 1 (twiddle index 0, then d0): one batch for the four groups
+    tw15_load(T, tw, 0u, 1024u, 0u, 1u, 256u);
+    RD_SCHED_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) macro16_apply<INV>(a[i], T);
+    tw15_load(T, tw, 4u * hi, 64u, 4u * hi, 16u, 16u); // group d0 = 0 of B, in flight during the exchange
+    // A -> B: round r moves slot d2 = r; the four lanes that share (d4, d5) trade d3 against d1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Lw[((j & 3) * 4 + (j >> 2)) * F4W_SA + lane] = a[r][j]; // (d0, d1 | d3, d4, d5)
+        wave_lds_fence();
+#pragma unroll
+        for (int d0 = 0; d0 < 4; ++d0)
+#pragma unroll
+            for (int d3 = 0; d3 < 4; ++d3) b[d0][r + 4 * d3] = Lw[(d0 * 4 + hi) * F4W_SA + d3 * 16 + low];
+        wave_lds_fence();
+    }
+    // B: stages 2, 3 with k = d0 + 4 d1 (d1 = lane >> 4, d0 = slot)
+    macro16_x4<INV, AHEAD>(b, T, [&](FftTw15 &Tn, int d0) { tw15_load(Tn, tw, d0 + 4u * hi, 64u, d0 + 4u * hi, 16u, 16u); });
+    tw15_load(T, tw, (unsigned)lane, 4u, (unsigned)lane, 256u, 1u); // group d3 = 0 of C
+    // B -> C: round r moves d3 = r; all 64 lanes trade (d1, d4, d5) against (d2, d1, d0)
+    const unsigned c2 = lane >> 4, c1 = (lane >> 2) & 3, c0 = lane & 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int d0 = 0; d0 < 4; ++d0)
+#pragma unroll
+            for (int d2 = 0; d2 < 4; ++d2) Lw[(d0 * 4 + d2) * F4W_SB + lane] = b[d0][d2 + 4 * r]; // (d0, d2 | d1, d4, d5)
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[r][j] = Lw[(c0 * 4 + c2) * F4W_SB + c1 * 16 + (j & 3) * 4 + (j >> 2)]; // j = d4 + 4 d5
+        wave_lds_fence();
+    }
+    // C: stages 4, 5 with k = 64 d3 + lane
+    macro16_x4<INV, AHEAD>(a, T, [&](FftTw15 &Tn, int d3) { tw15_load(Tn, tw, 64u * d3 + lane, 4u, 64u * d3 + lane, 256u, 1u); });
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fft4k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch,
+                                                            long in_stride)
+{
+    __shared__ float2 Ls[4 * F4W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long xf = (long)blockIdx.x * 4 + w;
+    if (xf >= nbatch) return; // wave-uniform
+    const float2 *src = in + xf * in_stride;
+    float2 *dst = out + xf * 4096;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + 1024 * (j & 3) + 256 * (j >> 2) + 64 * i)[(unsigned)lane];
+    RD_SCHED_BARRIER(); // all 64 loads requested before the arithmetic starts
+    fft4k_wave_regs<INV>(a, b, tw, Ls + w * F4W_REGION, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) (dst + 1024 * (j >> 2) + 256 * (j & 3) + 64 * i)[(unsigned)lane] = a[i][j];
+}
+
+// overlap-save with 4096-point blocks, one wavefront per block: after the forward stages a lane holds output positions
+// e = 1024 d5 + 256 d4 + 64 d3 + lane (registers j = d4 + 4 d5, slot d3).  As input of the inverse transform that index is
+// digit-reversed, which lands every point in the same lane and slot with j' = d5 + 4 d4 -- the product with conj(H)
+// and the whole inverse start from registers.  One read of the block, one write of the hop valid outputs, four
+// wave-private exchanges, no workgroup barrier.  Same operations as transform -> multiply -> transform -> scaled copy.
+__global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
+                                                               const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
+                                                               float2 *__restrict__ out, long nblk, float scale)
+{
+    __shared__ float2 Ls[4 * F4W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long blk = (long)blockIdx.x * 4 + w;
+    if (blk >= nblk) return; // wave-uniform
+    const float2 *src = x + blk * hop;
+    float2 *dst = out + blk * hop;
+    float2 *Lw = Ls + w * F4W_REGION;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + 1024 * (j & 3) + 256 * (j >> 2) + 64 * i)[(unsigned)lane];
+    RD_SCHED_BARRIER();
+    fft4k_wave_regs<false>(a, b, tw_f, Lw, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[i][j] = (Hc + 1024 * (j >> 2) + 256 * (j & 3) + 64 * i)[(unsigned)lane];
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[i][j] = cmul_rn(a[i][j], b[i][j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][((j & 3) << 2) | (j >> 2)] = b[i][j];
+    }
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i)); // recompute the twiddle offsets: keeping the forward transform's sixty alive spills them
+    fft4k_wave_regs<true>(a, b, tw_i, Lw, lane_i);
+    const long lim = hop - lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = 1024 * (j >> 2) + 256 * (j & 3) + 64 * i;
+            if (e < lim) (dst + e)[(unsigned)lane] = make_float2(mul_rn(a[i][j].x, scale), mul_rn(a[i][j].y, scale));
+        }
+}
+
+static int fft4k_use_wave()
+{
+    static const int v = [] { const char *e = getenv("REDIO_FFT4K_WG"); return (e && e[0] == '1') ? 0 : 1; }();
+    return v;
+}
+
 static int f64k_use_wave_tiles()
 {
     static const int v = [] { const char *e = getenv("REDIO_F64K_WG_TILES"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -1200,6 +1372,13 @@ static hipError_t launch_ovsave64k_wave(const float2 *x, long hop, float2 *a, fl
     hipLaunchKernelGGL((fft64k_wave_kernel<false, 0>), dim3(grid), dim3(256), 0, s, x, a, tw_f, hop, ntiles);
     hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3(grid), dim3(256), 0, s, a, b, tw_f, tw_i, Hc, ntiles);
     hipLaunchKernelGGL(ovsave64k_last_wave_kernel, dim3(grid), dim3(256), 0, s, b, out, tw_i, hop, scale, ntiles);
+    return hipGetLastError();
+}
+
+static hipError_t launch_ovsave4k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                                       float scale, hipStream_t s)
+{
+    hipLaunchKernelGGL(ovsave4k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, nblk, scale);
     return hipGetLastError();
 }
 
@@ -1239,6 +1418,12 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         const unsigned grid = (unsigned)((nbatch + 15) / 16);
         if (inv) hipLaunchKernelGGL(fft256_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft256_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        return hipGetLastError();
+    }
+    if (p.nfft == 4096 && fft4k_use_wave()) {
+        const unsigned grid = (unsigned)((nbatch + 3) / 4);
+        if (inv) hipLaunchKernelGGL(fft4k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft4k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
     }
     if (p.nfft == 4096) {
