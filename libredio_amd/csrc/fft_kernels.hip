@@ -1172,10 +1172,15 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
     for (int x = 0; x < 4; ++x) f64k_macro_regs<false>(b[x], tw_f, 1, 2, q + 4 * x, F64K_COLS * c + col);
     const float2 *hc = Hc + F64K_COLS * c;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 4; ++x) { // sixteen spectrum taps as one batch of loads (the compiler would wait for them one by one)
+        float2 h[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h[j] = (hc + 256 * (4 * x + 16 * j))[lo_q1];
+        RD_SCHED_BARRIER();
 #pragma unroll
         for (int j = 0; j < 16; ++j) // row q + 4x + 16j = digit reversal of 16 (4q + x) + rev2(j)
-            a[x][((j & 3) << 2) | (j >> 2)] = cmul_rn(b[x][j], (hc + 256 * (4 * x + 16 * j))[lo_q1]);
+            a[x][((j & 3) << 2) | (j >> 2)] = cmul_rn(b[x][j], h[j]);
+    }
 #pragma unroll
     for (int x = 0; x < 4; ++x) f64k_macro_regs<true>(a[x], tw_i, 0, 0, 0, 0);
     f64w_exchange<true, true>(a, b, Lw, lane);
