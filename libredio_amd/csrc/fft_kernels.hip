@@ -1235,8 +1235,8 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float
 constexpr int F4W_SA = 80, F4W_SB = 65;     // padded strides of the two exchange layouts
 constexpr int F4W_REGION = 16 * F4W_SA;     // float2 per wave
 
-template <bool INV, bool AHEAD = true>
-__device__ __forceinline__ void fft4k_wave_regs(float2 (&a)[4][16], float2 (&b)[4][16], const float2 *__restrict__ tw, float2 *Lw, int lane)
+template <bool INV, bool AHEAD = true, typename TwPtr>
+__device__ __forceinline__ void fft4k_wave_regs(float2 (&a)[4][16], float2 (&b)[4][16], TwPtr tw, float2 *Lw, int lane)
 {
     const unsigned hi = lane >> 4, low = lane & 15;
     FftTw15 T;
@@ -1347,6 +1347,53 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
         }
 }
 
+// ---- N = 16384 = 4 x 4096: four wavefronts, one sub-transform each, last stage across them -------------------
+// Wave q runs the one-wave 4096-point program on x[4 n + q] (its twiddles are every fourth entry of the table), which
+// leaves F_q[k], k = 1024 d5 + 256 d4 + 64 d3 + lane, in its registers.  The last kissfft stage (m = 4096) needs the four
+// F_q[k] of one k in one thread: four rounds (d3 = r) through a 32 KiB LDS image, after which thread (wave w, lane) owns
+// k = 1024 w + 256 d4 + 64 r + lane and stores X[k + 4096 rr] (512-byte runs).
+struct TwEvery4W {
+    const float2 *p;
+    __device__ __forceinline__ float2 operator[](unsigned i) const { return p[4u * i]; }
+};
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+{
+    __shared__ float2 Ls[4 * F4W_REGION + 4096];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float2 *src = in + (long)blockIdx.x * in_stride + w;
+    float2 *dst = out + (long)blockIdx.x * 16384;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
+    RD_SCHED_BARRIER();
+    fft4k_wave_regs<INV>(a, b, TwEvery4W{tw}, Ls + w * F4W_REGION, lane);
+    float2 *X = Ls + 4 * F4W_REGION; // [q][1024]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r) __syncthreads(); // the previous round has been read
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[1024 * w + 64 * j + lane] = a[r][j]; // j = d4 + 4 d5
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const int jj = d4 + 4 * w;                 // d5 = w
+            const unsigned k = 1024u * w + 256u * d4 + 64u * r + lane;
+            float2 f0 = X[64 * jj + lane], f1 = X[1024 + 64 * jj + lane], f2 = X[2048 + 64 * jj + lane], f3 = X[3072 + 64 * jj + lane];
+            bfly4<INV>(f0, f1, f2, f3, tw[k], tw[2 * k], tw[3 * k]);
+            dst[k] = f0; dst[k + 4096] = f1; dst[k + 8192] = f2; dst[k + 12288] = f3;
+        }
+    }
+}
+
+static int fft16k_use_wave()
+{
+    static const int v = [] { const char *e = getenv("REDIO_FFT16K_WG"); return (e && e[0] == '1') ? 0 : 1; }();
+    return v;
+}
+
 static int fft4k_use_wave()
 {
     static const int v = [] { const char *e = getenv("REDIO_FFT4K_WG"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -1435,6 +1482,11 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         const size_t lds = 4 * FFT4K_REGION * sizeof(float2);
         if (inv) hipLaunchKernelGGL(fft4k_kernel<true>, dim3((unsigned)nbatch), dim3(256), lds, s, in, out, p.tw, in_stride);
         else hipLaunchKernelGGL(fft4k_kernel<false>, dim3((unsigned)nbatch), dim3(256), lds, s, in, out, p.tw, in_stride);
+        return hipGetLastError();
+    }
+    if (p.nfft == 16384 && fft16k_use_wave()) {
+        if (inv) hipLaunchKernelGGL(fft16k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
+        else hipLaunchKernelGGL(fft16k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
         return hipGetLastError();
     }
     if (p.nfft == 16384) {

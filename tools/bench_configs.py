@@ -38,7 +38,7 @@ if "fir" in which:
         print(f"FIR 127 taps /{d}: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {b*n/ms/1e6:.0f} GB/s algorithmic ({b*n/ms/1e6/8000:.1%})")
 if "fft" in which:
     for nfft in (1024, 64, 256, 4096, 16384, 65536, 2048, 512, 128, 32, 16, 8, 4, 8192, 1000, 100, 1536, 243, 30, 192, 768, 6144, 320, 2560):
-        x = R.synth_iq(2, 0, n if nfft < 16384 else 1 << 24)[: (n if nfft < 16384 else 1 << 24) // nfft * nfft]
+        x = R.synth_iq(2, 0, n)[: n // nfft * nfft]
         plan = R.Fft(nfft)
         out = torch.empty_like(x)
         ms = timeit(lambda: plan(x, out=out), n=20 if nfft < 16384 else 5, warm=3)
