@@ -355,9 +355,13 @@ __global__ __launch_bounds__(1024) void ovsave16k_kernel(const float2 *__restric
         if (k + 1024 * g < hop) dst[k + 1024 * g] = make_float2(mul_rn(v[g].x, scale), mul_rn(v[g].y, scale));
 }
 
+static hipError_t launch_ovsave16k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                                        float scale, hipStream_t s);
+static int fft16k_use_wave();
 hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                             float scale, hipStream_t s)
 {
+    if (fft16k_use_wave()) return launch_ovsave16k_wave(x, hop, tw_f, tw_i, Hc, out, nblk, scale, s);
     const size_t lds = 16 * FFT16K_REGION * sizeof(float2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ovsave16k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1388,6 +1392,79 @@ __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, f
     }
 }
 
+// overlap-save with 16384-point blocks in one kernel of four wavefronts (two workgroups per CU).  Forward as in
+// fft16k_wave_kernel, but the last forward stage runs in rounds over d4 so that its products with conj(H), regrouped
+// through a second LDS image, fill one register slot of the inverse sub-transforms per round: sample n = k + 4096 rr
+// belongs to inverse wave n & 3 at position n >> 2 = 1024 rr + 256 d5 + 64 d4 + 16 d3 + (lane >> 2).  Then the inverse
+// sub-transforms from registers, the inverse last stage, 1/N and the store of the hop valid outputs.  One read of the
+// block, one write of the outputs; same operations as transform -> multiply -> transform -> scaled copy.
+constexpr int OV16W_YS = 1040; // stride of one inverse wave's image (bank spread for the lane & 3 scatter)
+__global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
+                                                                const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
+                                                                float2 *__restrict__ out, float scale)
+{
+    __shared__ float2 Ls[4096 + 4 * OV16W_YS];
+    static_assert(4 * F4W_REGION <= 4096 + 4 * OV16W_YS, "the wave-private exchange images live inside the two shared ones");
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float2 *src = x + (long)blockIdx.x * hop + w;
+    float2 *dst = out + (long)blockIdx.x * hop;
+    float2 *X = Ls, *Y = Ls + 4096, *Lw = Ls + w * F4W_REGION;
+    float2 a[4][16], b[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
+    RD_SCHED_BARRIER();
+    fft4k_wave_regs<false>(a, b, TwEvery4W{tw_f}, Lw, lane);
+    __syncthreads(); // every wave is done with its private image
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { // d4 = r
+#pragma unroll
+        for (int d3 = 0; d3 < 4; ++d3)
+#pragma unroll
+            for (int d5 = 0; d5 < 4; ++d5) X[1024 * w + 256 * d5 + 64 * d3 + lane] = a[d3][r + 4 * d5];
+        __syncthreads();
+#pragma unroll
+        for (int d3 = 0; d3 < 4; ++d3) { // this thread's k: d5 = w
+            const unsigned k = 1024u * w + 256u * r + 64u * d3 + lane;
+            float2 f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = X[1024 * q + 256 * w + 64 * d3 + lane];
+            bfly4<false>(f[0], f[1], f[2], f[3], tw_f[k], tw_f[2 * k], tw_f[3 * k]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                Y[OV16W_YS * (lane & 3) + 64 * (rr + 4 * w) + 16 * d3 + (lane >> 2)] = cmul_rn(f[rr], Hc[k + 4096u * rr]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[r][j] = Y[OV16W_YS * w + 64 * j + lane]; // slot r of inverse sub-transform w
+    }
+    __syncthreads(); // the images are free again
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i)); // fresh twiddle offsets for the inverse (keeping the forward ones alive spills)
+    fft4k_wave_regs<true>(b, a, TwEvery4W{tw_i}, Lw, lane_i);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { // d3 = r, as in fft16k_wave_kernel
+        if (r) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[1024 * w + 64 * j + lane_i] = b[r][j];
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const int jj = d4 + 4 * w;
+            const unsigned k = 1024u * w + 256u * d4 + 64u * r + lane_i;
+            float2 f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = X[1024 * q + 64 * jj + lane_i];
+            bfly4<true>(f[0], f[1], f[2], f[3], tw_i[k], tw_i[2 * k], tw_i[3 * k]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if ((long)(k + 4096u * rr) < hop) dst[k + 4096u * rr] = make_float2(mul_rn(f[rr].x, scale), mul_rn(f[rr].y, scale));
+        }
+    }
+}
+
 static int fft16k_use_wave()
 {
     static const int v = [] { const char *e = getenv("REDIO_FFT16K_WG"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -1431,6 +1508,13 @@ static hipError_t launch_ovsave4k_wave(const float2 *x, long hop, const float2 *
                                        float scale, hipStream_t s)
 {
     hipLaunchKernelGGL(ovsave4k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, nblk, scale);
+    return hipGetLastError();
+}
+
+static hipError_t launch_ovsave16k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                                        float scale, hipStream_t s)
+{
+    hipLaunchKernelGGL(ovsave16k_wave_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, scale);
     return hipGetLastError();
 }
 
