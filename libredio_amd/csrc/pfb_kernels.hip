@@ -11,7 +11,8 @@
 
 namespace redio {
 
-template <int P, bool FUSED>
+// ROWMAJOR: the plain [row][64] output (ngroups == 1) with 32-byte stores and no index division.
+template <int P, bool FUSED, bool ROWMAJOR>
 __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x, const float *__restrict__ h,
                                                     const float2 *__restrict__ tw, float2 *__restrict__ out, long rows,
                                                     long rows_per_wave, int ngroups)
@@ -28,25 +29,29 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     float g[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) g[p] = h[PFB_M * p + lane];
-    float2 win[P];
+    // row r of the input = (x + 64 r)[lane]: wave-uniform row pointer + one 32-bit lane offset per load; rows past the
+    // end of the stream (only the last tiles of the last wave ever ask for them) are clamped on a separate path
+    auto load_rows = [&](float2(&dst)[PFB_TILE], long first) {
+        if (first + PFB_TILE - 1 <= last_in_row) {
+            const float2 *xr = x + PFB_M * first;
 #pragma unroll
-    for (int p = 0; p < P - 1; ++p) win[p] = x[PFB_M * (t0 + p) + lane];
-    float2 cur[PFB_TILE], nx[PFB_TILE];
-#pragma unroll
-    for (int ti = 0; ti < PFB_TILE; ++ti) {
-        long r = t0 + ti + P - 1;
-        r = r < last_in_row ? r : last_in_row;
-        cur[ti] = x[PFB_M * r + lane];
-    }
-    for (long tb = t0; tb < t1; tb += PFB_TILE) {
-        if (tb + PFB_TILE < t1) {
+            for (int ti = 0; ti < PFB_TILE; ++ti) dst[ti] = (xr + PFB_M * ti)[(unsigned)lane];
+        } else {
 #pragma unroll
             for (int ti = 0; ti < PFB_TILE; ++ti) {
-                long r = tb + PFB_TILE + ti + P - 1;
+                long r = first + ti;
                 r = r < last_in_row ? r : last_in_row;
-                nx[ti] = x[PFB_M * r + lane];
+                dst[ti] = (x + PFB_M * r)[(unsigned)lane];
             }
         }
+    };
+    float2 win[P];
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p) win[p] = (x + PFB_M * (t0 + p))[(unsigned)lane];
+    float2 cur[PFB_TILE], nx[PFB_TILE];
+    load_rows(cur, t0 + P - 1);
+    for (long tb = t0; tb < t1; tb += PFB_TILE) {
+        if (tb + PFB_TILE < t1) load_rows(nx, tb + PFB_TILE + P - 1);
         // branch FIRs: lane = branch, strict fold over p (dsputils.rs:31)
 #pragma unroll
         for (int ti = 0; ti < PFB_TILE; ++ti) {
@@ -73,15 +78,24 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
         pfb_fft64_passC<false>(v, lane, tw);
         const long row = tb + (lane >> 2);
         if (row < t1) {
+            if (ROWMAJOR) { // channels 16 k0 + 4 (lane & 3) + k2 of row tb + (lane >> 2): 32 bytes per lane, 128 per row and k0
+                float4 *orow = reinterpret_cast<float4 *>(out + PFB_M * tb) + (unsigned)(32 * (lane >> 2) + 2 * (lane & 3));
 #pragma unroll
-            for (int k0 = 0; k0 < 4; ++k0) {
-                if (ngroups <= 16) { // the four k2 of one k0 are consecutive channels of one group: a 32-byte run
-                    float2 *dst = out + pfb_out_index(row, pfb_out_channel(lane, k0, 0), rows, ngroups);
+                for (int k0 = 0; k0 < 4; ++k0) {
+                    orow[8 * k0] = make_float4(v[k0].x, v[k0].y, v[k0 + 4].x, v[k0 + 4].y);
+                    orow[8 * k0 + 1] = make_float4(v[k0 + 8].x, v[k0 + 8].y, v[k0 + 12].x, v[k0 + 12].y);
+                }
+            } else {
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; ++k2) dst[k2] = v[k0 + 4 * k2];
-                } else {
+                for (int k0 = 0; k0 < 4; ++k0) {
+                    if (ngroups <= 16) { // the four k2 of one k0 are consecutive channels of one group: a 32-byte run
+                        float2 *dst = out + pfb_out_index(row, pfb_out_channel(lane, k0, 0), rows, ngroups);
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; ++k2) out[pfb_out_index(row, pfb_out_channel(lane, k0, k2), rows, ngroups)] = v[k0 + 4 * k2];
+                        for (int k2 = 0; k2 < 4; ++k2) dst[k2] = v[k0 + 4 * k2];
+                    } else {
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) out[pfb_out_index(row, pfb_out_channel(lane, k0, k2), rows, ngroups)] = v[k0 + 4 * k2];
+                    }
                 }
             }
         }
@@ -107,8 +121,13 @@ static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw
     const long nwaves = (rows + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((nwaves + 3) / 4);
     const size_t lds = 4 * PFB_LDS * sizeof(float2);
-    if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
-    else hipLaunchKernelGGL((pfb64_kernel<P, false>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+    if (ngroups == 1) {
+        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, true>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        else hipLaunchKernelGGL((pfb64_kernel<P, false, true>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+    } else {
+        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, false>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        else hipLaunchKernelGGL((pfb64_kernel<P, false, false>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+    }
     return hipGetLastError();
 }
 
