@@ -40,54 +40,6 @@ __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float
     }
 }
 
-// ---- N = 4096 = 4 x 1024: one workgroup per transform -------------------------------------------
-// The outermost kissfft stage (radix 4, m = 1024, fstride 1) combines four 1024-point transforms of
-// the decimated inputs x[4 i + j]; their twiddles are every fourth entry of the 4096 table, which the
-// library computes to the same doubles ((-2 pi * 4 i) / 4096 == (-2 pi * i) / 1024: exact scalings),
-// so each wavefront runs the one-wave 1024-point transform of fft_wave.h on its own block and the
-// workgroup finishes with the 1024 outer butterflies.  Coalesced load -> de-interleaved LDS regions
-// (region stride 1096 float2 = 8 mod 32 bank pairs: the four interleaved streams land on disjoint
-// banks) -> per-wave transform in place in its region -> barrier -> outer stage -> coalesced store.
-constexpr int FFT4K_REGION = 1096; // float2; >= FFT1K_LDS
-struct TwEvery4 {
-    const float2 *p;
-    __device__ __forceinline__ float2 operator[](int i) const { return p[4 * i]; }
-};
-
-template <bool INV>
-__global__ __launch_bounds__(256) void fft4k_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
-{
-    static_assert(FFT4K_REGION >= FFT1K_LDS, "a region doubles as the wave's exchange image");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float2 *src = in + (long)blockIdx.x * in_stride;
-    float2 *dst = out + (long)blockIdx.x * 4096;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int n = tid + 256 * it;
-        L[(n & 3) * FFT4K_REGION + (n >> 2)] = src[n];
-    }
-    __syncthreads();
-    float2 *mine = L + wave * FFT4K_REGION;
-    float2 v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
-    const TwEvery4 tw1k = {tw};
-    Fft1kTw t;
-    fft1k_load_tw(t, lane, tw1k);
-    fft1k_wave_regs<INV>(v, mine, mine, tw1k, t, lane);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-        float2 a0 = L[k], a1 = L[FFT4K_REGION + k], a2 = L[2 * FFT4K_REGION + k], a3 = L[3 * FFT4K_REGION + k];
-        bfly4<INV>(a0, a1, a2, a3, tw[k], tw[2 * k], tw[3 * k]);
-        dst[k] = a0; dst[k + 1024] = a1; dst[k + 2048] = a2; dst[k + 3072] = a3;
-    }
-}
-
 // ---- overlap-save with 1024-point blocks: one wavefront per block, nothing but registers in between -------
 // The forward transform leaves X[lane + 64 q + 256 j] in v[4 q + j]; the inverse transform wants
 // v'[t] = Y[lane + 64 t], t = q + 4 j -- a register renaming.  Load, transform, product with conj(H), inverse
@@ -137,235 +89,6 @@ hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const 
     const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
     const unsigned grid = (unsigned)((nblk + 4 * FFT1K_PER_WAVE - 1) / (4 * FFT1K_PER_WAVE));
     hipLaunchKernelGGL(ovsave1k_kernel, dim3(grid), dim3(256), lds, s, x, hop, tw_f, tw_i, Hc, out, nblk, scale);
-    return hipGetLastError();
-}
-
-// ---- overlap-save with 4096-point blocks in ONE kernel ---------------------------------------------
-// A 4096-point block fits LDS, so block load, forward transform, product with conj(H), inverse transform,
-// 1/N scale and the store of the hop valid outputs all happen in one workgroup: 8 B read and 8*hop/4096 B
-// written per block sample, nothing in between touches HBM.  The pieces are fft4k_kernel's (forward with the
-// plan's table, inverse with the inverse plan's); the spectrum goes from the forward outer stage's registers
-// straight into the inverse transform's de-interleaved regions.  Bit-identical to transform -> multiply ->
-// transform -> scaled copy.
-__global__ __launch_bounds__(256) void ovsave4k_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
-                                                       const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
-                                                       float2 *__restrict__ out, float scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float2 *src = x + (long)blockIdx.x * hop;
-    float2 *dst = out + (long)blockIdx.x * hop;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int n = tid + 256 * it;
-        L[(n & 3) * FFT4K_REGION + (n >> 2)] = src[n];
-    }
-    __syncthreads();
-    float2 *mine = L + wave * FFT4K_REGION;
-    float2 v[16];
-    {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
-        const TwEvery4 tw1k = {tw_f};
-        Fft1kTw t;
-        fft1k_load_tw(t, lane, tw1k);
-        fft1k_wave_regs<false>(v, mine, mine, tw1k, t, lane);
-    }
-    __syncthreads();
-    // forward outer stage into registers, times conj(H): v[4 i + j] = Y[k + 1024 j], k = tid + 256 i
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-        float2 a0 = L[k], a1 = L[FFT4K_REGION + k], a2 = L[2 * FFT4K_REGION + k], a3 = L[3 * FFT4K_REGION + k];
-        bfly4<false>(a0, a1, a2, a3, tw_f[k], tw_f[2 * k], tw_f[3 * k]);
-        v[4 * i] = cmul_rn(a0, Hc[k]);
-        v[4 * i + 1] = cmul_rn(a1, Hc[k + 1024]);
-        v[4 * i + 2] = cmul_rn(a2, Hc[k + 2048]);
-        v[4 * i + 3] = cmul_rn(a3, Hc[k + 3072]);
-    }
-    __syncthreads(); // every thread has read its columns
-    // the inverse transform's input, de-interleaved: sample n = k + 1024 j -> region n & 3, slot n >> 2
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) L[(k & 3) * FFT4K_REGION + (k >> 2) + 256 * j] = v[4 * i + j];
-    }
-    __syncthreads();
-    {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
-        const TwEvery4 tw1k = {tw_i};
-        Fft1kTw t;
-        fft1k_load_tw(t, lane, tw1k);
-        fft1k_wave_regs<true>(v, mine, mine, tw1k, t, lane);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-        float2 a[4] = {L[k], L[FFT4K_REGION + k], L[2 * FFT4K_REGION + k], L[3 * FFT4K_REGION + k]};
-        bfly4<true>(a[0], a[1], a[2], a[3], tw_i[k], tw_i[2 * k], tw_i[3 * k]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k + 1024 * j < hop) dst[k + 1024 * j] = make_float2(mul_rn(a[j].x, scale), mul_rn(a[j].y, scale));
-    }
-}
-
-static hipError_t launch_ovsave4k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                                       float scale, hipStream_t s);
-static int fft4k_use_wave();
-hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                           float scale, hipStream_t s)
-{
-    if (fft4k_use_wave()) return launch_ovsave4k_wave(x, hop, tw_f, tw_i, Hc, out, nblk, scale, s);
-    const size_t lds = 4 * FFT4K_REGION * sizeof(float2);
-    hipLaunchKernelGGL(ovsave4k_kernel, dim3((unsigned)nblk), dim3(256), lds, s, x, hop, tw_f, tw_i, Hc, out, scale);
-    return hipGetLastError();
-}
-
-// ---- N = 16384 = 16 x 1024: one 1024-thread workgroup per transform --------------------------------
-// Two outer kissfft stages (m = 1024 with fstride 4, m = 4096 with fstride 1) over sixteen 1024-point
-// transforms of x[r + 16 i]; leaf block g = 4 j0 + j1 holds the stream r = j0 + 4 j1.  Sixteen waves,
-// one block each (region stride 1090 float2 = 2 mod 32 bank pairs for the de-interleaving store), then
-// every thread finishes one column k of the 16 x 1024 array in registers.
-constexpr int FFT16K_REGION = 1090;
-struct TwEvery16 {
-    const float2 *p;
-    __device__ __forceinline__ float2 operator[](int i) const { return p[16 * i]; }
-};
-
-template <bool INV>
-__global__ __launch_bounds__(1024) void fft16k_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
-{
-    static_assert(FFT16K_REGION >= FFT1K_LDS, "a region doubles as the wave's exchange image");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float2 *src = in + (long)blockIdx.x * in_stride;
-    float2 *dst = out + (long)blockIdx.x * 16384;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int n = tid + 1024 * it, r = n & 15;
-        L[((r & 3) * 4 + (r >> 2)) * FFT16K_REGION + (n >> 4)] = src[n];
-    }
-    __syncthreads();
-    float2 *mine = L + wave * FFT16K_REGION;
-    float2 v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
-    const TwEvery16 tw1k = {tw};
-    {
-        Fft1kTw t;
-        fft1k_load_tw(t, lane, tw1k);
-        fft1k_wave_regs<INV>(v, mine, mine, tw1k, t, lane);
-    }
-    __syncthreads();
-    const int k = tid;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = L[g * FFT16K_REGION + k];
-    {
-        const float2 w1 = tw[4 * k], w2 = tw[8 * k], w3 = tw[12 * k];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) bfly4<INV>(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w1, w2, w3); // m = 1024
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { // m = 4096: index k + 1024 b inside the 4096-block
-        const int kk = k + 1024 * b;
-        bfly4<INV>(v[b], v[b + 4], v[b + 8], v[b + 12], tw[kk], tw[2 * kk], tw[3 * kk]);
-    }
-#pragma unroll
-    for (int g = 0; g < 16; ++g) dst[k + 1024 * g] = v[g];
-}
-
-// ---- overlap-save with 16384-point blocks in one kernel (the 4096-point scheme on fft16k_kernel's pieces) ----
-template <bool INV>
-__device__ __forceinline__ void fft16k_outer(float2 (&v)[16], const float2 *__restrict__ tw, int k)
-{
-    {
-        const float2 w1 = tw[4 * k], w2 = tw[8 * k], w3 = tw[12 * k];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) bfly4<INV>(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w1, w2, w3); // m = 1024
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { // m = 4096
-        const int kk = k + 1024 * b;
-        bfly4<INV>(v[b], v[b + 4], v[b + 8], v[b + 12], tw[kk], tw[2 * kk], tw[3 * kk]);
-    }
-}
-
-__global__ __launch_bounds__(1024) void ovsave16k_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
-                                                         const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
-                                                         float2 *__restrict__ out, float scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float2 *src = x + (long)blockIdx.x * hop;
-    float2 *dst = out + (long)blockIdx.x * hop;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int n = tid + 1024 * it, r = n & 15;
-        L[((r & 3) * 4 + (r >> 2)) * FFT16K_REGION + (n >> 4)] = src[n];
-    }
-    __syncthreads();
-    float2 *mine = L + wave * FFT16K_REGION;
-    float2 v[16];
-    {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
-        const TwEvery16 tw1k = {tw_f};
-        Fft1kTw t;
-        fft1k_load_tw(t, lane, tw1k);
-        fft1k_wave_regs<false>(v, mine, mine, tw1k, t, lane);
-    }
-    __syncthreads();
-    const int k = tid;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = L[g * FFT16K_REGION + k];
-    fft16k_outer<false>(v, tw_f, k);                 // v[g] = Y[k + 1024 g]
-#pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = cmul_rn(v[g], Hc[k + 1024 * g]);
-    __syncthreads(); // every thread has read its column
-    {   // the inverse transform's input n = k + 1024 g: stream r = k & 15, slot (k >> 4) + 64 g
-        const int r = k & 15;
-        float2 *reg = L + ((r & 3) * 4 + (r >> 2)) * FFT16K_REGION + (k >> 4);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) reg[64 * g] = v[g];
-    }
-    __syncthreads();
-    {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = mine[lane + 64 * t];
-        const TwEvery16 tw1k = {tw_i};
-        Fft1kTw t;
-        fft1k_load_tw(t, lane, tw1k);
-        fft1k_wave_regs<true>(v, mine, mine, tw1k, t, lane);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = L[g * FFT16K_REGION + k];
-    fft16k_outer<true>(v, tw_i, k);
-#pragma unroll
-    for (int g = 0; g < 16; ++g)
-        if (k + 1024 * g < hop) dst[k + 1024 * g] = make_float2(mul_rn(v[g].x, scale), mul_rn(v[g].y, scale));
-}
-
-static hipError_t launch_ovsave16k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                                        float scale, hipStream_t s);
-static int fft16k_use_wave();
-hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                            float scale, hipStream_t s)
-{
-    if (fft16k_use_wave()) return launch_ovsave16k_wave(x, hop, tw_f, tw_i, Hc, out, nblk, scale, s);
-    const size_t lds = 16 * FFT16K_REGION * sizeof(float2);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ovsave16k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ovsave16k_kernel, dim3((unsigned)nblk), dim3(1024), lds, s, x, hop, tw_f, tw_i, Hc, out, scale);
     return hipGetLastError();
 }
 
@@ -871,159 +594,6 @@ __global__ __launch_bounds__(256) void fft_global_generic_stage_kernel(FftPlanDe
     dst[i] = fft_generic_output(src + b * p.nfft, p.tw, st, p.nfft, g, u, q1);
 }
 
-// ---- N = 65536: two passes of four in-LDS radix-4 stages (fft_core.h, "65536-point transform") ----
-// One workgroup per 256 x 16 tile; rows are 128 contiguous bytes in memory.  PASS 0 gathers the
-// digit-reversed input (in -> out), PASS 1 works in place on out.  32 B of HBM traffic per sample
-// (twice the one-pass minimum; a 512 KiB transform does not fit LDS).
-template <bool INV, int PASS>
-__global__ __launch_bounds__(256) void fft64k_pass_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw,
-                                                          long in_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x;
-    const long xf = blockIdx.x >> 4; // transform
-    const int c = blockIdx.x & 15;   // tile
-    const float2 *src = PASS == 0 ? in + xf * in_stride : out + xf * F64K_N;
-    float2 *dst = out + xf * F64K_N;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, row = e >> 4, col = e & 15;
-        if (PASS == 0) L[rev4_of_8bit(row) * F64K_LD + col] = src[f64k_p0_src(c, row, col)];
-        else L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
-    }
-    __syncthreads();
-    const int col = tid & 15;
-    // four stages as two register passes of two stages each (16 rows per thread)
-#pragma unroll 1
-    for (int t = 0; t < 4; t += 2) {
-        f64k_tile_macro<INV>(L, tw, PASS, t, col, tid >> 4, F64K_COLS * c + col);
-        __syncthreads();
-    }
-    if (PASS == 0) {
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) dst[f64k_p0_dst(c, tid, it)] = L[tid * F64K_LD + it]; // 2 KiB runs per column
-    } else {
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
-            dst[f64k_p1_pos(c, row, cc)] = L[row * F64K_LD + cc];
-        }
-    }
-}
-
-template <bool INV>
-static hipError_t launch_fft64k_wave(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s);
-static int f64k_use_wave_tiles();
-template <bool INV>
-static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
-{
-    if (f64k_use_wave_tiles()) return launch_fft64k_wave<INV>(in, out, tw, nbatch, in_stride, s);
-    const size_t lds = 256 * F64K_LD * sizeof(float2);
-    const unsigned grid = (unsigned)(nbatch * 16);
-    hipLaunchKernelGGL((fft64k_pass_kernel<INV, 0>), dim3(grid), dim3(256), lds, s, in, out, tw, in_stride);
-    hipLaunchKernelGGL((fft64k_pass_kernel<INV, 1>), dim3(grid), dim3(256), lds, s, in, out, tw, in_stride);
-    return hipGetLastError();
-}
-
-// ---- overlap-save at N = 65536 in three passes instead of six ------------------------------------
-// forward pass 1, the spectrum product and inverse pass 0 touch the same 256 x 16 tile (column k0 of the
-// forward output IS the stride-256 leaf set of the inverse transform: f64k_p1_pos == f64k_p0_src), so
-// they run back to back in LDS; inverse pass 1 scales and writes only the `hop` valid outputs.  Same
-// butterflies, same C_MUL, same scale as transform -> multiply -> transform -> copy: bit-identical.
-__global__ __launch_bounds__(256) void ovsave64k_mid_kernel(const float2 *__restrict__ a, float2 *__restrict__ b,
-                                                            const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
-                                                            const float2 *__restrict__ Hc)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x;
-    const long xf = blockIdx.x >> 4;
-    const int c = blockIdx.x & 15;
-    const float2 *src = a + xf * F64K_N;
-    float2 *dst = b + xf * F64K_N;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, row = e >> 4, col = e & 15;
-        L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
-    }
-    __syncthreads();
-    const int col = tid & 15;
-    // four stages as two register passes of two stages each (16 rows per thread)
-#pragma unroll 1
-    for (int t = 0; t < 4; t += 2) {
-        f64k_tile_macro<false>(L, tw_f, 1, t, col, tid >> 4, F64K_COLS * c + col);
-        __syncthreads();
-    }
-    float2 v[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
-        v[it] = cmul_rn(L[row * F64K_LD + cc], Hc[f64k_p1_pos(c, row, cc)]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 16; ++it) { // the inverse transform's leaf order along the row index
-        const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
-        L[rev4_of_8bit(row) * F64K_LD + cc] = v[it];
-    }
-    __syncthreads();
-    // four stages as two register passes of two stages each (16 rows per thread)
-#pragma unroll 1
-    for (int t = 0; t < 4; t += 2) {
-        f64k_tile_macro<true>(L, tw_i, 0, t, col, tid >> 4, F64K_COLS * c + col);
-        __syncthreads();
-    }
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) dst[f64k_p0_dst(c, tid, it)] = L[tid * F64K_LD + it];
-}
-
-__global__ __launch_bounds__(256) void ovsave64k_last_kernel(const float2 *__restrict__ b, float2 *__restrict__ out,
-                                                             const float2 *__restrict__ tw_i, long hop, float scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *L = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x;
-    const long xf = blockIdx.x >> 4;
-    const int c = blockIdx.x & 15;
-    const float2 *src = b + xf * F64K_N;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, row = e >> 4, col = e & 15;
-        L[row * F64K_LD + col] = src[f64k_p1_pos(c, row, col)];
-    }
-    __syncthreads();
-    const int col = tid & 15;
-    // four stages as two register passes of two stages each (16 rows per thread)
-#pragma unroll 1
-    for (int t = 0; t < 4; t += 2) {
-        f64k_tile_macro<true>(L, tw_i, 1, t, col, tid >> 4, F64K_COLS * c + col);
-        __syncthreads();
-    }
-    float2 *dst = out + xf * hop;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, row = e >> 4, cc = e & 15;
-        const int pos = f64k_p1_pos(c, row, cc);
-        const float2 y = L[row * F64K_LD + cc];
-        if (pos < hop) dst[pos] = make_float2(mul_rn(y.x, scale), mul_rn(y.y, scale));
-    }
-}
-
-static hipError_t launch_ovsave64k_wave(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
-                                        float2 *out, long nblk, float scale, hipStream_t s);
-hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
-                            float2 *out, long nblk, float scale, hipStream_t s)
-{
-    if (f64k_use_wave_tiles()) return launch_ovsave64k_wave(x, hop, a, b, tw_f, tw_i, Hc, out, nblk, scale, s);
-    const size_t lds = 256 * F64K_LD * sizeof(float2);
-    const unsigned grid = (unsigned)(nblk * 16);
-    hipLaunchKernelGGL((fft64k_pass_kernel<false, 0>), dim3(grid), dim3(256), lds, s, x, a, tw_f, hop);
-    hipLaunchKernelGGL(ovsave64k_mid_kernel, dim3(grid), dim3(256), lds, s, a, b, tw_f, tw_i, Hc);
-    hipLaunchKernelGGL(ovsave64k_last_kernel, dim3(grid), dim3(256), lds, s, b, out, tw_i, hop, scale);
-    return hipGetLastError();
-}
-
 // ---- two radix-4 stages on 16 points in registers, twiddles fetched ahead ---------------------------------
 // Stage A multiplies by tw[n kA fsA] (n = 1, 2, 3; the same for its four butterflies), stage B butterfly u by
 // tw[n (kB + u step) fsB].  The 15 values are loaded as one batch (behind a scheduling barrier where the caller wants the
@@ -1465,26 +1035,8 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
     }
 }
 
-static int fft16k_use_wave()
-{
-    static const int v = [] { const char *e = getenv("REDIO_FFT16K_WG"); return (e && e[0] == '1') ? 0 : 1; }();
-    return v;
-}
-
-static int fft4k_use_wave()
-{
-    static const int v = [] { const char *e = getenv("REDIO_FFT4K_WG"); return (e && e[0] == '1') ? 0 : 1; }();
-    return v;
-}
-
-static int f64k_use_wave_tiles()
-{
-    static const int v = [] { const char *e = getenv("REDIO_F64K_WG_TILES"); return (e && e[0] == '1') ? 0 : 1; }();
-    return v;
-}
-
 template <bool INV>
-static hipError_t launch_fft64k_wave(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
+static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
 {
     const long ntiles = nbatch * 16;
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
@@ -1493,8 +1045,8 @@ static hipError_t launch_fft64k_wave(const float2 *in, float2 *out, const float2
     return hipGetLastError();
 }
 
-static hipError_t launch_ovsave64k_wave(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
-                                        float2 *out, long nblk, float scale, hipStream_t s)
+hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
+                            float2 *out, long nblk, float scale, hipStream_t s)
 {
     const long ntiles = nblk * 16;
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
@@ -1504,15 +1056,15 @@ static hipError_t launch_ovsave64k_wave(const float2 *x, long hop, float2 *a, fl
     return hipGetLastError();
 }
 
-static hipError_t launch_ovsave4k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                                       float scale, hipStream_t s)
+hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s)
 {
     hipLaunchKernelGGL(ovsave4k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, nblk, scale);
     return hipGetLastError();
 }
 
-static hipError_t launch_ovsave16k_wave(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                                        float scale, hipStream_t s)
+hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+                            float scale, hipStream_t s)
 {
     hipLaunchKernelGGL(ovsave16k_wave_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, scale);
     return hipGetLastError();
@@ -1556,31 +1108,15 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         else hipLaunchKernelGGL(fft256_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
     }
-    if (p.nfft == 4096 && fft4k_use_wave()) {
+    if (p.nfft == 4096) {
         const unsigned grid = (unsigned)((nbatch + 3) / 4);
         if (inv) hipLaunchKernelGGL(fft4k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft4k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
     }
-    if (p.nfft == 4096) {
-        const size_t lds = 4 * FFT4K_REGION * sizeof(float2);
-        if (inv) hipLaunchKernelGGL(fft4k_kernel<true>, dim3((unsigned)nbatch), dim3(256), lds, s, in, out, p.tw, in_stride);
-        else hipLaunchKernelGGL(fft4k_kernel<false>, dim3((unsigned)nbatch), dim3(256), lds, s, in, out, p.tw, in_stride);
-        return hipGetLastError();
-    }
-    if (p.nfft == 16384 && fft16k_use_wave()) {
+    if (p.nfft == 16384) {
         if (inv) hipLaunchKernelGGL(fft16k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
         else hipLaunchKernelGGL(fft16k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
-        return hipGetLastError();
-    }
-    if (p.nfft == 16384) {
-        const size_t lds = 16 * FFT16K_REGION * sizeof(float2);
-        auto kf = fft16k_kernel<false>;
-        auto ki = fft16k_kernel<true>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)nbatch), dim3(1024), lds, s, in, out, p.tw, in_stride);
-        else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(1024), lds, s, in, out, p.tw, in_stride);
         return hipGetLastError();
     }
     if (p.nfft == F64K_N) {

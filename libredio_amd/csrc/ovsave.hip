@@ -8,7 +8,6 @@
 #include "../../include/redio.h"
 #include "redio_internal.h"
 #include <new>
-#include <stdlib.h>
 #include <vector>
 
 namespace redio {
@@ -66,9 +65,7 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     p->device = dev; p->nfft = nfft; p->ntaps = ntaps; p->hop = (size_t)nfft - ntaps + 1;
     p->fw = p->bw = nullptr; p->d_Hc = p->d_a = p->d_b = nullptr;
     // work buffers: about 64 MiB each, at least one block
-    size_t chunk_mb = 64;
-    if (const char *e = getenv("REDIO_OVSAVE_CHUNK_MB")) { const long v = atol(e); if (v >= 1 && v <= 4096) chunk_mb = (size_t)v; } // tuning aid
-    p->chunk_blocks = (chunk_mb << 20) / ((size_t)nfft * sizeof(float2));
+    p->chunk_blocks = (size_t)(64u << 20) / ((size_t)nfft * sizeof(float2)); // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
     if (p->chunk_blocks < 1) p->chunk_blocks = 1;
     int rc = redio_fft_create(&p->fw, nfft, 0);
     if (rc == REDIO_OK) rc = redio_fft_create(&p->bw, nfft, 1);
