@@ -80,6 +80,16 @@ class Fft:
         check(lib().redio_fft_enqueue(self._h, _dev_ptr(x), _dev_ptr(out), x.numel() // self.nfft, current_stream()), "fft_enqueue")
         return out
 
+    def strided(self, x, nbatch, in_stride, out=None):
+        """redio_fft_enqueue_strided: block b is x[b*in_stride : b*in_stride + nfft] (overlapping when in_stride < nfft,
+        the overlap-save framing); the outputs are packed."""
+        import torch
+        assert x.dtype == torch.complex64 and in_stride > 0 and (nbatch == 0 or (nbatch - 1) * in_stride + self.nfft <= x.numel())
+        if out is None:
+            out = torch.empty(nbatch * self.nfft, dtype=torch.complex64, device=x.device)
+        check(lib().redio_fft_enqueue_strided(self._h, _dev_ptr(x), _dev_ptr(out), nbatch, in_stride, current_stream()), "fft_enqueue_strided")
+        return out
+
     def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_fft_destroy", self._h)

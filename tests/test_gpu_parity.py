@@ -128,6 +128,18 @@ def test_fft_compile_time_mixed_radix_sizes(gpu, redio, oracle, n):
     assert same_bits(d.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n", [16, 64, 100, 243, 256, 1000, 1024, 1080, 2048, 4096, 6144, 8192, 8193, 16384, 65536])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_strided_blocks(gpu, redio, oracle, n, inverse):
+    # redio_fft_enqueue_strided through every kernel family: overlapping blocks (the overlap-save framing) and blocks with gaps
+    nb = 6 if n < 8192 else 3
+    for stride in (n - n // 3 if n > 3 else n, n + 5):
+        x = oracle.synth_iq(n + stride, 0, (nb - 1) * stride + n)
+        got = redio.Fft(n, inverse).strided(gpu.from_numpy(x).cuda(), nb, stride).cpu().numpy()
+        want = np.concatenate([oracle.fft(x[b * stride: b * stride + n], n, inverse) for b in range(nb)])
+        assert same_bits(got, want), (n, inverse, stride)
+
+
 @pytest.mark.parametrize("n", [8193, 8209, 9 * 1031, 2 * 8191, 20011])
 def test_fft_large_sizes_with_big_prime_factors(gpu, redio, oracle, n):
     # too large for the out-of-place generic butterfly in LDS: global-memory stages, the generic radix out of place
