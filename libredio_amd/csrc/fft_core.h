@@ -28,6 +28,27 @@ __device__ __forceinline__ redio_pk2 pk_cmul(redio_pk2 a, redio_pk2 t)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(o) : "v"(p), "v"(r));                   // (p.x - r.x, p.y + r.y)
     return o;
 }
+// the three instructions of pk_cmul on their own, so that a butterfly can keep dependent packed operations two issue slots
+// apart (gfx950 needs a wait state between a packed-f32 result and its use; the assembler-level order below avoids the
+// s_nop the compiler would otherwise insert after nearly every pair)
+__device__ __forceinline__ redio_pk2 pk_cmul_p(redio_pk2 a, redio_pk2 t)
+{
+    redio_pk2 p;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(t));
+    return p;
+}
+__device__ __forceinline__ redio_pk2 pk_cmul_r(redio_pk2 a, redio_pk2 t)
+{
+    redio_pk2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
+__device__ __forceinline__ redio_pk2 pk_cmul_o(redio_pk2 p, redio_pk2 r)
+{
+    redio_pk2 o;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(o) : "v"(p), "v"(r));
+    return o;
+}
 __device__ __forceinline__ redio_pk2 pk_add_rot_a(redio_pk2 a, redio_pk2 b) // (a.x + b.y, a.y - b.x)
 {
     redio_pk2 o;
@@ -60,10 +81,12 @@ RD_HD void bfly4(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 t1, floa
 {
 #if defined(REDIO_PK_BFLY)
     if constexpr (PK) {
-    const redio_pk2 x0 = {a0.x, a0.y};
-    const redio_pk2 s0 = pk_cmul(redio_pk2{a1.x, a1.y}, redio_pk2{t1.x, t1.y});
-    const redio_pk2 s1 = pk_cmul(redio_pk2{a2.x, a2.y}, redio_pk2{t2.x, t2.y});
-    const redio_pk2 s2 = pk_cmul(redio_pk2{a3.x, a3.y}, redio_pk2{t3.x, t3.y});
+    const redio_pk2 x0 = {a0.x, a0.y}, x1 = {a1.x, a1.y}, x2 = {a2.x, a2.y}, x3 = {a3.x, a3.y};
+    const redio_pk2 w1 = {t1.x, t1.y}, w2 = {t2.x, t2.y}, w3 = {t3.x, t3.y};
+    const redio_pk2 p1 = pk_cmul_p(x2, w2), r1 = pk_cmul_r(x2, w2);
+    const redio_pk2 p0 = pk_cmul_p(x1, w1), r0 = pk_cmul_r(x1, w1);
+    const redio_pk2 p2 = pk_cmul_p(x3, w3), r2 = pk_cmul_r(x3, w3);
+    const redio_pk2 s1 = pk_cmul_o(p1, r1), s0 = pk_cmul_o(p0, r0), s2 = pk_cmul_o(p2, r2);
     const redio_pk2 s5 = pk_sub2(x0, s1), y0 = pk_add2(x0, s1);
     const redio_pk2 s3 = pk_add2(s0, s2), s4 = pk_sub2(s0, s2);
     const redio_pk2 o2 = pk_sub2(y0, s3), o0 = pk_add2(y0, s3);
@@ -89,6 +112,39 @@ RD_HD void bfly4(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 t1, floa
         a1 = make_float2(add_rn(s5.x, s4.y), sub_rn(s5.y, s4.x));
         a3 = make_float2(sub_rn(s5.x, s4.y), add_rn(s5.y, s4.x));
     }
+}
+
+// two independent radix-4 butterflies with their packed operations interleaved (A, B, A, B ...): every result is used at
+// least three issue slots after it is produced, so no wait states are needed between the dependent packed operations
+template <bool INV>
+RD_HD void bfly4x2(float2 &a0, float2 &a1, float2 &a2, float2 &a3, float2 ta1, float2 ta2, float2 ta3,
+                   float2 &b0, float2 &b1, float2 &b2, float2 &b3, float2 tb1, float2 tb2, float2 tb3)
+{
+#if defined(REDIO_PK_BFLY)
+    const redio_pk2 xa0 = {a0.x, a0.y}, xa1 = {a1.x, a1.y}, xa2 = {a2.x, a2.y}, xa3 = {a3.x, a3.y};
+    const redio_pk2 xb0 = {b0.x, b0.y}, xb1 = {b1.x, b1.y}, xb2 = {b2.x, b2.y}, xb3 = {b3.x, b3.y};
+    const redio_pk2 wa1 = {ta1.x, ta1.y}, wa2 = {ta2.x, ta2.y}, wa3 = {ta3.x, ta3.y};
+    const redio_pk2 wb1 = {tb1.x, tb1.y}, wb2 = {tb2.x, tb2.y}, wb3 = {tb3.x, tb3.y};
+    const redio_pk2 pa1 = pk_cmul_p(xa2, wa2), pb1 = pk_cmul_p(xb2, wb2), ra1 = pk_cmul_r(xa2, wa2), rb1 = pk_cmul_r(xb2, wb2);
+    const redio_pk2 pa0 = pk_cmul_p(xa1, wa1), pb0 = pk_cmul_p(xb1, wb1), ra0 = pk_cmul_r(xa1, wa1), rb0 = pk_cmul_r(xb1, wb1);
+    const redio_pk2 pa2 = pk_cmul_p(xa3, wa3), pb2 = pk_cmul_p(xb3, wb3), ra2 = pk_cmul_r(xa3, wa3), rb2 = pk_cmul_r(xb3, wb3);
+    const redio_pk2 sa1 = pk_cmul_o(pa1, ra1), sb1 = pk_cmul_o(pb1, rb1);
+    const redio_pk2 sa0 = pk_cmul_o(pa0, ra0), sb0 = pk_cmul_o(pb0, rb0);
+    const redio_pk2 sa2 = pk_cmul_o(pa2, ra2), sb2 = pk_cmul_o(pb2, rb2);
+    const redio_pk2 sa5 = pk_sub2(xa0, sa1), sb5 = pk_sub2(xb0, sb1);
+    const redio_pk2 ya0 = pk_add2(xa0, sa1), yb0 = pk_add2(xb0, sb1);
+    const redio_pk2 sa3 = pk_add2(sa0, sa2), sb3 = pk_add2(sb0, sb2);
+    const redio_pk2 sa4 = pk_sub2(sa0, sa2), sb4 = pk_sub2(sb0, sb2);
+    const redio_pk2 oa2 = pk_sub2(ya0, sa3), ob2 = pk_sub2(yb0, sb3);
+    const redio_pk2 oa0 = pk_add2(ya0, sa3), ob0 = pk_add2(yb0, sb3);
+    const redio_pk2 oa1 = INV ? pk_add_rot_b(sa5, sa4) : pk_add_rot_a(sa5, sa4), ob1 = INV ? pk_add_rot_b(sb5, sb4) : pk_add_rot_a(sb5, sb4);
+    const redio_pk2 oa3 = INV ? pk_add_rot_a(sa5, sa4) : pk_add_rot_b(sa5, sa4), ob3 = INV ? pk_add_rot_a(sb5, sb4) : pk_add_rot_b(sb5, sb4);
+    a0 = make_float2(oa0.x, oa0.y); a1 = make_float2(oa1.x, oa1.y); a2 = make_float2(oa2.x, oa2.y); a3 = make_float2(oa3.x, oa3.y);
+    b0 = make_float2(ob0.x, ob0.y); b1 = make_float2(ob1.x, ob1.y); b2 = make_float2(ob2.x, ob2.y); b3 = make_float2(ob3.x, ob3.y);
+#else
+    bfly4<INV>(a0, a1, a2, a3, ta1, ta2, ta3);
+    bfly4<INV>(b0, b1, b2, b3, tb1, tb2, tb3);
+#endif
 }
 
 // ---- radix-2 butterfly (kf_bfly2 order) ------------------------------------------------------
@@ -455,14 +511,16 @@ RD_HD void f64k_macro_regs(float2 (&a)[16], TwPtr tw, int pass, int t, int kk, i
         const int k = pass == 0 ? kk : k0 + 256 * kk;
         const int fs = pass == 0 ? (16384 >> (2 * t)) : (64 >> (2 * t));
         const float2 t1 = tw[(unsigned)(k * fs)], t2 = tw[(unsigned)(2 * k * fs)], t3 = tw[(unsigned)(3 * k * fs)];
-        for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+        for (int q = 0; q < 4; q += 2)
+            bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
     }
     {
         const int fs = pass == 0 ? (16384 >> (2 * t + 2)) : (64 >> (2 * t + 2));
-        for (int u = 0; u < 4; ++u) {
-            const int k1 = kk + u * m; // index inside the 4m-block
-            const int k = pass == 0 ? k1 : k0 + 256 * k1;
-            bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[(unsigned)(k * fs)], tw[(unsigned)(2 * k * fs)], tw[(unsigned)(3 * k * fs)]);
+        for (int u = 0; u < 4; u += 2) {
+            const int k1 = kk + u * m, k1b = k1 + m; // index inside the 4m-block
+            const int k = pass == 0 ? k1 : k0 + 256 * k1, kb = pass == 0 ? k1b : k0 + 256 * k1b;
+            bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[(unsigned)(k * fs)], tw[(unsigned)(2 * k * fs)], tw[(unsigned)(3 * k * fs)],
+                         a[u + 1], a[u + 5], a[u + 9], a[u + 13], tw[(unsigned)(kb * fs)], tw[(unsigned)(2 * kb * fs)], tw[(unsigned)(3 * kb * fs)]);
         }
     }
 }

@@ -613,9 +613,13 @@ template <bool INV>
 __device__ __forceinline__ void macro16_apply(float2 (&a)[16], const FftTw15 &T)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], T.t[0], T.t[1], T.t[2]);
+    for (int q = 0; q < 4; q += 2)
+        bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], T.t[0], T.t[1], T.t[2], a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7],
+                     T.t[0], T.t[1], T.t[2]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], T.t[3 + 3 * u], T.t[4 + 3 * u], T.t[5 + 3 * u]);
+    for (int u = 0; u < 4; u += 2)
+        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], T.t[3 + 3 * u], T.t[4 + 3 * u], T.t[5 + 3 * u], a[u + 1], a[u + 5], a[u + 9], a[u + 13],
+                     T.t[6 + 3 * u], T.t[7 + 3 * u], T.t[8 + 3 * u]);
 }
 // four groups with per-group twiddles: batch g + 1 is requested before group g is computed
 template <bool INV, bool AHEAD = true, typename LoadFn>
