@@ -1039,6 +1039,136 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
     }
 }
 
+// ---- N = 2048 = 2 x 4^5, one wavefront per transform; N = 8192 = 4 x 2048, four wavefronts -------------------
+// Position e = b0 + 2 d1 + 8 d2 + 32 d3 + 128 d4 + 512 d5 (kissfft runs the radix-2 stage first, on b0).  32 points per lane:
+//   A: radix-2 + radix-4 on (b0, d1), four 8-point groups (slot d2)   lane = (d3 d4 d5) = source index mod 64
+//   B: stages on (d2, d3), two 16-point groups (slot b0)               lane = (d1 d4 d5)
+//   C: stages on (d4, d5), two 16-point groups (slot d3 >> 1)          lane = e mod 64
+// with the two regroupings through a wave-private LDS image in two rounds of 1024 points (fft4k_wave_regs' layouts).
+template <bool INV, typename TwPtr>
+__device__ __forceinline__ void fft2k_wave_regs(float2 (&a)[4][8], float2 (&b)[2][16], TwPtr tw, float2 *Lw, int lane)
+{
+    const unsigned hi = lane >> 4, low = lane & 15;
+    {
+        const float2 w0 = tw[0u], w1 = tw[256u], w2 = tw[512u], w3 = tw[768u];
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) {
+#pragma unroll
+            for (int d1 = 0; d1 < 4; ++d1) bfly2(a[d2][2 * d1], a[d2][2 * d1 + 1], w0);
+            bfly4x2<INV>(a[d2][0], a[d2][2], a[d2][4], a[d2][6], w0, w0, w0, a[d2][1], a[d2][3], a[d2][5], a[d2][7], w1, w2, w3);
+        }
+    }
+    FftTw15 T;
+    tw15_load(T, tw, 2u * hi, 64u, 2u * hi, 8u, 16u); // group b0 = 0 of B: k = b0 + 2 d1
+    // A -> B: round r moves b0 = r; the four lanes that share (d4, d5) trade d3 against d1
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+            for (int d1 = 0; d1 < 4; ++d1) Lw[(d2 * 4 + d1) * F4W_SA + lane] = a[d2][r + 2 * d1]; // (d2, d1 | d3, d4, d5)
+        wave_lds_fence();
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+            for (int d3 = 0; d3 < 4; ++d3) b[r][d2 + 4 * d3] = Lw[(d2 * 4 + hi) * F4W_SA + d3 * 16 + low];
+        wave_lds_fence();
+    }
+    {
+        FftTw15 Tn;
+        tw15_load(Tn, tw, 1u + 2u * hi, 64u, 1u + 2u * hi, 8u, 16u);
+        RD_SCHED_BARRIER();
+        macro16_apply<INV>(b[0], T);
+        macro16_apply<INV>(b[1], Tn);
+    }
+    tw15_load(T, tw, (unsigned)lane, 4u, (unsigned)lane, 128u, 1u); // slot 0 of C: k = e mod 128
+    // B -> C: round r moves d3 >> 1 = r; (d1 d4 d5) against (b0 d1 d2 d3&1)
+    const unsigned c0 = lane & 1, c1 = (lane >> 1) & 3, c2 = (lane >> 3) & 3, c3 = lane >> 5;
+    float2 (&c)[2][16] = b; // phase C reuses the registers round by round
+    float2 t[2][16];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int b0 = 0; b0 < 2; ++b0)
+#pragma unroll
+            for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+                for (int d3l = 0; d3l < 2; ++d3l) Lw[(b0 * 8 + d2 * 2 + d3l) * F4W_SB + lane] = c[b0][d2 + 4 * (2 * r + d3l)];
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[r][j] = Lw[(c0 * 8 + c2 * 2 + c3) * F4W_SB + c1 * 16 + (j & 3) * 4 + (j >> 2)]; // j = d4 + 4 d5
+        wave_lds_fence();
+    }
+    {
+        FftTw15 Tn;
+        tw15_load(Tn, tw, 64u + lane, 4u, 64u + lane, 128u, 1u);
+        RD_SCHED_BARRIER();
+        macro16_apply<INV>(t[0], T);
+        macro16_apply<INV>(t[1], Tn);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[r][j] = t[r][j]; // result: b[slot][j = d4 + 4 d5] = position lane + 64 slot + 128 d4 + 512 d5
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256) void fft2k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch, long in_stride)
+{
+    __shared__ float2 Ls[4 * F4W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long xf = (long)blockIdx.x * 4 + w;
+    if (xf >= nbatch) return; // wave-uniform
+    const float2 *src = in + xf * in_stride;
+    float2 *dst = out + xf * 2048;
+    float2 a[4][8], b[2][16];
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[d2][j] = (src + 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[(unsigned)lane]; // j = b0 + 2 d1
+    RD_SCHED_BARRIER();
+    fft2k_wave_regs<INV>(a, b, tw, Ls + w * F4W_REGION, lane);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) (dst + 128 * (j & 3) + 512 * (j >> 2) + 64 * r)[(unsigned)lane] = b[r][j];
+}
+
+// 8192: wave q runs the 2048-point program on x[4 n + q]; the last stage (m = 2048) across the waves, as in fft16k_wave_kernel
+template <bool INV>
+__global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+{
+    __shared__ float2 Ls[4 * F4W_REGION]; // the wave-private images, then (after a barrier) the [q][1024] image of the last stage
+    static_assert(4 * F4W_REGION >= 4096, "the shared image fits where the private ones were");
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float2 *src = in + (long)blockIdx.x * in_stride + w;
+    float2 *dst = out + (long)blockIdx.x * 8192;
+    float2 a[4][8], b[2][16];
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
+    RD_SCHED_BARRIER();
+    fft2k_wave_regs<INV>(a, b, TwEvery4W{tw}, Ls + w * F4W_REGION, lane);
+    float2 *X = Ls;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { // slot = r
+        __syncthreads(); // private images / the previous round are no longer read
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[1024 * w + 64 * j + lane] = b[r][j];
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const int jj = d4 + 4 * w; // d5 = w
+            const unsigned k = 512u * w + 128u * d4 + 64u * r + lane;
+            float2 f0 = X[64 * jj + lane], f1 = X[1024 + 64 * jj + lane], f2 = X[2048 + 64 * jj + lane], f3 = X[3072 + 64 * jj + lane];
+            bfly4<INV>(f0, f1, f2, f3, tw[k], tw[2 * k], tw[3 * k]);
+            dst[k] = f0; dst[k + 2048] = f1; dst[k + 4096] = f2; dst[k + 6144] = f3;
+        }
+    }
+}
+
 template <bool INV>
 static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
 {
@@ -1094,8 +1224,16 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     case 32: return launch_fft_p2<5>(in, out, p.tw, nbatch, in_stride, inv, s);
     case 128: return launch_fft_p2<7>(in, out, p.tw, nbatch, in_stride, inv, s);
     case 512: return launch_fft_p2<9>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 2048: return launch_fft_p2<11>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 8192: return launch_fft_p2<13>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 2048: {
+        const unsigned grid = (unsigned)((nbatch + 3) / 4);
+        if (inv) hipLaunchKernelGGL(fft2k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft2k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
+        return hipGetLastError();
+    }
+    case 8192:
+        if (inv) hipLaunchKernelGGL(fft8k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
+        else hipLaunchKernelGGL(fft8k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
+        return hipGetLastError();
     default: break;
     }
     if (p.nfft == 64) {
