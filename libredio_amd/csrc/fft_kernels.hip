@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void fft64_kernel(const float2 *in, float2 *ou
     }
 }
 
-// ---- small powers of two and N = 2 * 4^L (2, 4, 8, 16, 32, 128, 512, 2048, 8192): compile-time stages in LDS
+// ---- small powers of two and N = 2 * 4^L up to 512 (2, 4, 8, 16, 32, 128, 512; 2048 and 8192 have their own kernels below): compile-time stages in LDS
 // kissfft factors 2 * 4^L as 4, 4, ..., 4, 2 with the radix-2 stage innermost.  One 256-thread workgroup
 // handles 4096 points (8192 for the largest size): max(1, 4096 / N) transforms.  Coalesced load with the
 // digit reversal applied on the LDS side, then register passes over LDS (one pad float2 per 8 keeps the
@@ -226,11 +226,11 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict_
             for (int j = 0; j < 16; ++j) a[j] = Ls[F::phys(base + j * M)];
             const float2 t1 = tw[kk * FS], t2 = tw[2 * kk * FS], t3 = tw[3 * kk * FS];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bfly4<INV, LOG2N != 13>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
+            for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k2 = kk + u * M;
-                bfly4<INV, LOG2N != 13>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k2 * FS2], tw[2 * k2 * FS2], tw[3 * k2 * FS2]);
+                bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k2 * FS2], tw[2 * k2 * FS2], tw[3 * k2 * FS2]);
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) Ls[F::phys(base + j * M)] = a[j];
@@ -245,7 +245,7 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict_
             const int blk = gl / M, kk = gl % M;
             const int base = xf * N + blk * 4 * M + kk;
             float2 a0 = Ls[F::phys(base)], a1 = Ls[F::phys(base + M)], a2 = Ls[F::phys(base + 2 * M)], a3 = Ls[F::phys(base + 3 * M)];
-            bfly4<INV, LOG2N != 13>(a0, a1, a2, a3, tw[kk * FS], tw[2 * kk * FS], tw[3 * kk * FS]);
+            bfly4<INV>(a0, a1, a2, a3, tw[kk * FS], tw[2 * kk * FS], tw[3 * kk * FS]);
             Ls[F::phys(base)] = a0; Ls[F::phys(base + M)] = a1; Ls[F::phys(base + 2 * M)] = a2; Ls[F::phys(base + 3 * M)] = a3;
         }
         __syncthreads();
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *o
             for (int j = 0; j < 8; ++j) a[j] = Ls[F::phys(8 * g + j)];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bfly2(a[2 * q], a[2 * q + 1], one);
-            bfly4<INV, LOG2N != 13>(a[0], a[2], a[4], a[6], one, one, one);
-            bfly4<INV, LOG2N != 13>(a[1], a[3], a[5], a[7], w1, w2, w3);
+            bfly4<INV>(a[0], a[2], a[4], a[6], one, one, one);
+            bfly4<INV>(a[1], a[3], a[5], a[7], w1, w2, w3);
 #pragma unroll
             for (int j = 0; j < 8; ++j) Ls[F::phys(8 * g + j)] = a[j];
         }
