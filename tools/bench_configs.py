@@ -44,7 +44,7 @@ if "fft" in which:
         ms = timeit(lambda: plan(x, out=out), n=20 if nfft < 16384 else 5, warm=3)
         print(f"FFT {nfft}: {ms:.3f} ms  {x.numel()/ms/1e6:.1f} GS/s  {16*x.numel()/ms/1e6:.0f} GB/s algorithmic ({16*x.numel()/ms/1e6/8000:.1%})")
 if "fftall" in which:
-    for nfft in (6, 9, 10, 12, 15, 20, 24, 25, 27, 30, 40, 45, 48, 60, 75, 80, 81, 90, 96, 100, 120, 125, 150, 160, 180, 192, 200, 225, 240, 243, 250, 300, 320, 360, 384, 400, 450, 480, 500, 600, 625, 640, 720, 729, 768, 800, 900, 960, 1000, 1200, 1280, 1440, 1536, 1600, 1800, 1920, 2000):
+    for nfft in (6, 9, 10, 12, 15, 20, 24, 25, 27, 30, 40, 45, 48, 60, 75, 80, 81, 90, 96, 100, 120, 125, 150, 160, 180, 192, 200, 225, 240, 243, 250, 300, 320, 360, 384, 400, 450, 480, 500, 600, 625, 640, 720, 729, 768, 800, 900, 960, 1000, 1200, 1280, 1440, 1536, 1600, 1800, 1920, 2000, 2187, 2400, 2560, 3072, 3125, 3200, 3600, 3840, 4000, 4800, 5120, 6144, 6400, 6561, 7680, 8000):
         x = R.synth_iq(2, 0, n)[: n // nfft * nfft]
         plan = R.Fft(nfft)
         out = torch.empty_like(x)
