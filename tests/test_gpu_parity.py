@@ -128,7 +128,7 @@ def test_fft_compile_time_mixed_radix_sizes(gpu, redio, oracle, n):
     assert same_bits(d.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("n", [16, 64, 100, 243, 256, 1000, 1024, 1080, 2048, 4096, 6144, 8192, 8193, 16384, 65536])
+@pytest.mark.parametrize("n", [16, 64, 100, 243, 256, 768, 1000, 1024, 1080, 1536, 2048, 4096, 6144, 8192, 8193, 16384, 65536])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_strided_blocks(gpu, redio, oracle, n, inverse):
     # redio_fft_enqueue_strided through every kernel family: overlapping blocks (the overlap-save framing) and blocks with gaps
