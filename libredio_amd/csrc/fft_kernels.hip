@@ -320,7 +320,8 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
     return hipGetLastError();
 }
 
-// ---- the common 2^a 3^b 5^c sizes up to 8000 (see the dispatch list): the same scheme with a compile-time factor list ----
+// ---- every 2^a 3^b 5^c size up to 8192 without a kernel of its own (the sizes kiss_fft_next_fast_size returns; see the
+// dispatch list): the same scheme with a compile-time factor list ----
 // kissfft's factor order (4s, then 2, then 3, 5; fft_plan_stages) evaluated at compile time; radix-4 neighbours run
 // as register pairs -- as do any two neighbours of up to 25 points (3x2, 5x5, 5x2, 5x4 ...) -- and a stage left
 // over as one pass over padded LDS; 4096 / N (at least one) transforms per
@@ -1362,16 +1363,25 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         hipError_t e = hipErrorNotSupported;
         switch (p.nfft) {
 #define REDIO_CT(NN) case NN: e = launch_fft_ct<NN>(p, in, out, nbatch, in_stride, inv, s); break;
-            REDIO_CT(6) REDIO_CT(9) REDIO_CT(10) REDIO_CT(12) REDIO_CT(15) REDIO_CT(20) REDIO_CT(24) REDIO_CT(25)
-            REDIO_CT(27) REDIO_CT(30) REDIO_CT(40) REDIO_CT(45) REDIO_CT(48) REDIO_CT(60) REDIO_CT(75) REDIO_CT(80)
-            REDIO_CT(81) REDIO_CT(90) REDIO_CT(96) REDIO_CT(100) REDIO_CT(120) REDIO_CT(125) REDIO_CT(150) REDIO_CT(160)
-            REDIO_CT(180) REDIO_CT(192) REDIO_CT(200) REDIO_CT(225) REDIO_CT(240) REDIO_CT(243) REDIO_CT(250) REDIO_CT(300)
-            REDIO_CT(320) REDIO_CT(360) REDIO_CT(384) REDIO_CT(400) REDIO_CT(450) REDIO_CT(480) REDIO_CT(500) REDIO_CT(600)
-            REDIO_CT(625) REDIO_CT(640) REDIO_CT(720) REDIO_CT(729) REDIO_CT(768) REDIO_CT(800) REDIO_CT(900) REDIO_CT(960)
-            REDIO_CT(1000) REDIO_CT(1200) REDIO_CT(1280) REDIO_CT(1440) REDIO_CT(1536) REDIO_CT(1600) REDIO_CT(1800) REDIO_CT(1920)
-            REDIO_CT(2000) REDIO_CT(2187) REDIO_CT(2400) REDIO_CT(2560) REDIO_CT(3072) REDIO_CT(3125) REDIO_CT(3200) REDIO_CT(3600)
-            REDIO_CT(3840) REDIO_CT(4000) REDIO_CT(4800) REDIO_CT(5120) REDIO_CT(6144) REDIO_CT(6400) REDIO_CT(6561) REDIO_CT(7680)
-            REDIO_CT(8000)
+            REDIO_CT(6) REDIO_CT(9) REDIO_CT(10) REDIO_CT(12) REDIO_CT(15) REDIO_CT(18) REDIO_CT(20) REDIO_CT(24)
+            REDIO_CT(25) REDIO_CT(27) REDIO_CT(30) REDIO_CT(36) REDIO_CT(40) REDIO_CT(45) REDIO_CT(48) REDIO_CT(50)
+            REDIO_CT(54) REDIO_CT(60) REDIO_CT(72) REDIO_CT(75) REDIO_CT(80) REDIO_CT(81) REDIO_CT(90) REDIO_CT(96)
+            REDIO_CT(100) REDIO_CT(108) REDIO_CT(120) REDIO_CT(125) REDIO_CT(135) REDIO_CT(144) REDIO_CT(150) REDIO_CT(160)
+            REDIO_CT(162) REDIO_CT(180) REDIO_CT(192) REDIO_CT(200) REDIO_CT(216) REDIO_CT(225) REDIO_CT(240) REDIO_CT(243)
+            REDIO_CT(250) REDIO_CT(270) REDIO_CT(288) REDIO_CT(300) REDIO_CT(320) REDIO_CT(324) REDIO_CT(360) REDIO_CT(375)
+            REDIO_CT(384) REDIO_CT(400) REDIO_CT(405) REDIO_CT(432) REDIO_CT(450) REDIO_CT(480) REDIO_CT(486) REDIO_CT(500)
+            REDIO_CT(540) REDIO_CT(576) REDIO_CT(600) REDIO_CT(625) REDIO_CT(640) REDIO_CT(648) REDIO_CT(675) REDIO_CT(720)
+            REDIO_CT(729) REDIO_CT(750) REDIO_CT(768) REDIO_CT(800) REDIO_CT(810) REDIO_CT(864) REDIO_CT(900) REDIO_CT(960)
+            REDIO_CT(972) REDIO_CT(1000) REDIO_CT(1080) REDIO_CT(1125) REDIO_CT(1152) REDIO_CT(1200) REDIO_CT(1215) REDIO_CT(1250)
+            REDIO_CT(1280) REDIO_CT(1296) REDIO_CT(1350) REDIO_CT(1440) REDIO_CT(1458) REDIO_CT(1500) REDIO_CT(1536) REDIO_CT(1600)
+            REDIO_CT(1620) REDIO_CT(1728) REDIO_CT(1800) REDIO_CT(1875) REDIO_CT(1920) REDIO_CT(1944) REDIO_CT(2000) REDIO_CT(2025)
+            REDIO_CT(2160) REDIO_CT(2187) REDIO_CT(2250) REDIO_CT(2304) REDIO_CT(2400) REDIO_CT(2430) REDIO_CT(2500) REDIO_CT(2560)
+            REDIO_CT(2592) REDIO_CT(2700) REDIO_CT(2880) REDIO_CT(2916) REDIO_CT(3000) REDIO_CT(3072) REDIO_CT(3125) REDIO_CT(3200)
+            REDIO_CT(3240) REDIO_CT(3375) REDIO_CT(3456) REDIO_CT(3600) REDIO_CT(3645) REDIO_CT(3750) REDIO_CT(3840) REDIO_CT(3888)
+            REDIO_CT(4000) REDIO_CT(4050) REDIO_CT(4320) REDIO_CT(4374) REDIO_CT(4500) REDIO_CT(4608) REDIO_CT(4800) REDIO_CT(4860)
+            REDIO_CT(5000) REDIO_CT(5120) REDIO_CT(5184) REDIO_CT(5400) REDIO_CT(5625) REDIO_CT(5760) REDIO_CT(5832) REDIO_CT(6000)
+            REDIO_CT(6075) REDIO_CT(6144) REDIO_CT(6250) REDIO_CT(6400) REDIO_CT(6480) REDIO_CT(6561) REDIO_CT(6750) REDIO_CT(6912)
+            REDIO_CT(7200) REDIO_CT(7290) REDIO_CT(7500) REDIO_CT(7680) REDIO_CT(7776) REDIO_CT(8000) REDIO_CT(8100)
 #undef REDIO_CT
         default: break;
         }

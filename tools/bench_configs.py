@@ -50,6 +50,13 @@ if "fftall" in which:
         out = torch.empty_like(x)
         ms = timeit(lambda: plan(x, out=out), n=6, warm=2)
         print(f"FFT {nfft}: {x.numel()/ms/1e6:.1f}")
+if "fftnew" in which:
+    for nfft in (18, 36, 72, 144, 216, 288, 432, 576, 648, 864, 1080, 1152, 1296, 1500, 1728, 2160, 2304, 2500, 2880, 3000, 3456, 4050, 4320, 4500, 5000, 5400, 5760, 6000, 6250, 6480, 6750, 6912, 7200, 7290, 7500, 7776, 8100):
+        x = R.synth_iq(2, 0, n)[: n // nfft * nfft]
+        plan = R.Fft(nfft)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: plan(x, out=out), n=6, warm=2)
+        print(f"FFT {nfft}: {x.numel()/ms/1e6:.1f}")
 if "fftct" in which:
     for nfft in (48, 60, 120, 200, 240, 360, 480, 500, 600, 720, 729, 800, 960, 1200, 1440, 1920, 2000, 2400, 3125, 3600, 3840, 4000, 4800, 5120, 6400, 7680, 8000):
         x = R.synth_iq(2, 0, n)[: n // nfft * nfft]
