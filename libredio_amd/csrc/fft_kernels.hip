@@ -1263,6 +1263,163 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
     }
 }
 
+// ---- N = 4^L, L = 9 ... 12 (262144 ... 16777216): the 65536-point scheme with one or two more passes -------------
+// Position e of the working array has the base-4 digits d0 (first stage) ... d(L-1).  Pass A gathers the digit-reversed
+// input and runs stages 0-3 on tiles of 256 rows (d0..d3, 4^L / 256 apart in the source) x 16 source columns, writing the
+// working order (2 KiB runs); pass B runs four more stages in place on rows m_lo apart (m_lo = 4^4, then 4^8) x 16
+// neighbouring positions; the last one to three stages (rows 65536 apart) need no regrouping at all: a lane keeps whole
+// columns in registers and every load and store is 512 contiguous bytes.  16 B/sample per pass.  Twiddle index of the stage
+// with sub-length m: (e mod m) * N / (4 m), exactly kissfft's k * fstride.
+template <bool INV, typename TwPtr>
+__device__ __forceinline__ void big_macro16(float2 (&a)[16], TwPtr tw, unsigned l, unsigned m_lo, unsigned fs, unsigned kk, unsigned m)
+{
+    {
+        const unsigned k = l + m_lo * kk;
+        const float2 t1 = tw[k * fs], t2 = tw[2 * k * fs], t3 = tw[3 * k * fs];
+#pragma unroll
+        for (int q = 0; q < 4; q += 2)
+            bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
+    }
+    const unsigned fs2 = fs >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; u += 2) {
+        const unsigned k = l + m_lo * (kk + u * m), kb = k + m_lo * m;
+        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k * fs2], tw[2 * k * fs2], tw[3 * k * fs2],
+                     a[u + 1], a[u + 5], a[u + 9], a[u + 13], tw[kb * fs2], tw[2 * kb * fs2], tw[3 * kb * fs2]);
+    }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
+                                                           long ntiles, int L)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    float2 *Lw = Ls + w * F64W_REGION;
+    const unsigned N = 1u << (2 * L), S = N >> 8; // S: source row stride
+    const long xf = tile >> (2 * (L - 6));
+    const unsigned c = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)); // source columns 16c .. 16c + 15
+    const int col = lane & 15, q = lane >> 4;
+    const float2 *src = in + xf * in_stride + 16 * c;
+    float2 *dst = out + xf * (long)N;
+    float2 a[4][16], b[4][16];
+    const unsigned lo_src = col + 4u * S * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src]; // source row rev4(16 (4i + q) + j)
+    RD_SCHED_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw, 0u, 1u, N >> 2, 0u, 1u);
+    f64w_exchange<false, true>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw, 0u, 1u, N >> 6, (unsigned)col, 16u);
+    // column r = 16c + 4q + x of the source is column h = digit reversal of r (L - 4 digits) of the working array
+    unsigned rc = 0;
+    for (int d = 0, cc = c; d < L - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
+    const unsigned hq = 1u << (2 * (L - 6)), hx = hq << 2;
+    const unsigned lo_dst = col + 256u * hq * q;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) (dst + 256l * (hx * x + rc) + 16 * j)[lo_dst] = b[x][j];
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int L, int s)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    float2 *Lw = Ls + w * F64W_REGION;
+    const unsigned N = 1u << (2 * L), m_lo = 1u << (2 * s);
+    const long xf = tile >> (2 * (L - 6));
+    const unsigned tt = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1));
+    const unsigned c = tt & ((m_lo >> 4) - 1), h = tt >> (2 * s - 4); // positions l = 16c + col of block h
+    const int col = lane & 15, q = lane >> 4;
+    float2 *base = data + xf * (long)N + (long)h * 256 * m_lo + 16 * c;
+    const unsigned l = 16 * c + col, fsb = N >> (2 * s + 2);
+    float2 a[4][16], b[4][16];
+    const unsigned lo_ld = col + 16u * m_lo * q, lo_st = col + m_lo * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (base + (long)m_lo * (64 * i + j))[lo_ld]; // row 16 (4i + q) + j
+    RD_SCHED_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw, l, m_lo, fsb, 0u, 1u);
+    f64w_exchange<false, false>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw, l, m_lo, fsb >> 4, (unsigned)(q + 4 * x), 16u);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) (base + (long)m_lo * (4 * x + 16 * j))[lo_st] = b[x][j]; // row q + 4x + 16j
+}
+
+// the last LG = 1, 2 or 3 stages: G = 4^LG rows, m_lo = N / G apart; a wave takes 4096 / G neighbouring columns
+template <bool INV, int LG>
+__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int L)
+{
+    constexpr int G = 1 << (2 * LG), CPT = 4096 / G; // rows, columns per tile
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = (long)blockIdx.x * 4 + w;
+    if (tile >= ntiles) return;
+    const unsigned N = 1u << (2 * L), m_lo = N / G;
+    const long xf = tile >> (2 * (L - 6));
+    const unsigned l0 = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)) * CPT;
+    float2 *base = data + xf * (long)N + l0;
+    float2 a[CPT / 64][G];
+#pragma unroll
+    for (int i = 0; i < CPT / 64; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[i][g] = (base + (long)m_lo * g + 64 * i)[(unsigned)lane];
+    RD_SCHED_BARRIER();
+#pragma unroll
+    for (int i = 0; i < CPT / 64; ++i) {
+        const unsigned l = l0 + 64 * i + lane;
+        if constexpr (LG == 1) {
+            bfly4<INV>(a[i][0], a[i][1], a[i][2], a[i][3], tw[l], tw[2 * l], tw[3 * l]);
+        } else if constexpr (LG == 2) {
+            big_macro16<INV>(a[i], tw, l, m_lo, 4u, 0u, 1u);
+        } else {
+            float2 (&v)[4][16] = reinterpret_cast<float2 (&)[4][16]>(a[i]); // row g = j + 16 d2
+#pragma unroll
+            for (int d2 = 0; d2 < 4; ++d2) big_macro16<INV>(v[d2], tw, l, m_lo, 16u, 0u, 1u);
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const unsigned k = l + m_lo * j, kb = k + m_lo;
+                bfly4x2<INV>(v[0][j], v[1][j], v[2][j], v[3][j], tw[k], tw[2 * k], tw[3 * k],
+                             v[0][j + 1], v[1][j + 1], v[2][j + 1], v[3][j + 1], tw[kb], tw[2 * kb], tw[3 * kb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT / 64; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) (base + (long)m_lo * g + 64 * i)[(unsigned)lane] = a[i][g];
+}
+
+template <bool INV>
+static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, int L, hipStream_t s)
+{
+    const long ntiles = nbatch << (2 * (L - 6));
+    const unsigned grid = (unsigned)((ntiles + 3) / 4);
+    hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, L);
+    hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, tw, ntiles, L, 4);
+    switch (L - 8) {
+    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, L); break;
+    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, L); break;
+    case 3: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, L); break;
+    case 4: hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, tw, ntiles, L, 8); break;
+    default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
 template <bool INV>
 static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
 {
@@ -1420,6 +1577,11 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         return hipGetLastError();
+    }
+    if (!generic && p.nfft >= (1 << 18) && p.nfft <= (1 << 24) && (p.nfft & (p.nfft - 1)) == 0 && (__builtin_ctz((unsigned)p.nfft) % 2) == 0) {
+        if (in == out) return hipErrorNotSupported; // the first pass is a global transposition: the C-ABI layer stages in-place calls
+        const int L = __builtin_ctz((unsigned)p.nfft) / 2;
+        return inv ? launch_fftbig<true>(in, out, p.tw, nbatch, in_stride, L, s) : launch_fftbig<false>(in, out, p.tw, nbatch, in_stride, L, s);
     }
     // global-memory stages.  The C-ABI layer routes in-place calls through a temporary and supplies `work`
     // (nbatch * nfft elements) when a generic-radix stage needs an out-of-place step.

@@ -151,7 +151,7 @@ def test_fft_large_sizes_with_big_prime_factors(gpu, redio, oracle, n):
     assert same_bits(redio.Fft(n, True)(gpu.from_numpy(xi).cuda()).cpu().numpy(), oracle.fft(xi, n, True))
 
 
-@pytest.mark.parametrize("n", [16384, 65536])
+@pytest.mark.parametrize("n", [16384, 65536, 262144, 1048576])
 def test_fft_large_global_path(gpu, redio, oracle, n):
     x = oracle.synth_iq(n, 0, n * 2)
     d = gpu.from_numpy(x).cuda()
@@ -163,6 +163,15 @@ def test_fft_large_global_path(gpu, redio, oracle, n):
     # in place
     redio.Fft(n, False)(d, out=d)
     assert same_bits(d.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("n", [1 << 22, 1 << 24])
+def test_fft_multi_pass_powers_of_four(gpu, redio, oracle, n):
+    # 4^11 and 4^12: pass A, pass B and a three-stage last pass / a second pass B (fft_kernels.hip, fftbig_*)
+    x = oracle.synth_iq(n & 0xFFFF, 0, n)
+    d = gpu.from_numpy(x).cuda()
+    for inverse in (False, True):
+        assert same_bits(redio.Fft(n, inverse)(d).cpu().numpy(), oracle.fft(x, n, inverse)), (n, inverse)
 
 
 def test_fft1024_many_blocks_and_inplace(gpu, redio, oracle):
