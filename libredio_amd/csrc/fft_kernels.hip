@@ -1328,20 +1328,20 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
 }
 
 template <bool INV>
-__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int L, int s)
+__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int lgN, int lm)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile() + w;
     if (tile >= ntiles) return;
     float2 *Lw = Ls + w * F64W_REGION;
-    const unsigned N = 1u << (2 * L), m_lo = 1u << (2 * s);
-    const long xf = tile >> (2 * (L - 6));
-    const unsigned tt = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1));
-    const unsigned c = tt & ((m_lo >> 4) - 1), h = tt >> (2 * s - 4); // positions l = 16c + col of block h
+    const unsigned N = 1u << lgN, m_lo = 1u << lm; // rows m_lo = 2^lm apart
+    const long xf = tile >> (lgN - 12);
+    const unsigned tt = (unsigned)(tile & ((1u << (lgN - 12)) - 1));
+    const unsigned c = tt & ((m_lo >> 4) - 1), h = tt >> (lm - 4); // positions l = 16c + col of block h
     const int col = lane & 15, q = lane >> 4;
     float2 *base = data + xf * (long)N + (long)h * 256 * m_lo + 16 * c;
-    const unsigned l = 16 * c + col, fsb = N >> (2 * s + 2);
+    const unsigned l = 16 * c + col, fsb = N >> (lm + 2);
     float2 a[4][16], b[4][16];
     const unsigned lo_ld = col + 16u * m_lo * q, lo_st = col + m_lo * q;
 #pragma unroll
@@ -1362,15 +1362,15 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
 
 // the last LG = 1, 2 or 3 stages: G = 4^LG rows, m_lo = N / G apart; a wave takes 4096 / G neighbouring columns
 template <bool INV, int LG>
-__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int L)
+__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int lgN)
 {
     constexpr int G = 1 << (2 * LG), CPT = 4096 / G; // rows, columns per tile
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = (long)blockIdx.x * 4 + w;
     if (tile >= ntiles) return;
-    const unsigned N = 1u << (2 * L), m_lo = N / G;
-    const long xf = tile >> (2 * (L - 6));
-    const unsigned l0 = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)) * CPT;
+    const unsigned N = 1u << lgN, m_lo = N / G;
+    const long xf = tile >> (lgN - 12);
+    const unsigned l0 = (unsigned)(tile & ((1u << (lgN - 12)) - 1)) * CPT;
     float2 *base = data + xf * (long)N + l0;
     float2 a[CPT / 64][G];
 #pragma unroll
@@ -1403,19 +1403,74 @@ __global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const
         for (int g = 0; g < G; ++g) (base + (long)m_lo * g + 64 * i)[(unsigned)lane] = a[i][g];
 }
 
+// N = 2 * 4^L (32768 ... 8388608): kissfft runs the radix-2 stage first.  The gather pass takes the three stages on
+// (b0, d1, d2) = 32 rows, 4^L * 2 / 32 apart in the source, for 64 neighbouring source columns per wave, entirely in registers
+// (the first phase of fft2k_wave_regs), and writes each column's 32 results as one 256-byte run of the working order; the radix-4
+// stages that remain go through fftbig_mid_kernel / fftbig_last_kernel with rows 32, 8192, ... apart.
 template <bool INV>
-static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, int L, hipStream_t s)
+__global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
+                                                            long ntiles, int lgN)
 {
-    const long ntiles = nbatch << (2 * (L - 6));
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = (long)blockIdx.x * 4 + w;
+    if (tile >= ntiles) return;
+    const unsigned N = 1u << lgN, S = N >> 5; // S: source row stride
+    const int nd = (lgN - 5) / 2;             // base-4 digits of a source column index
+    const long xf = tile >> (lgN - 11);
+    const unsigned c = (unsigned)(tile & ((1u << (lgN - 11)) - 1)); // source columns 64c .. 64c + 63
+    const float2 *src = in + xf * in_stride + 64 * c;
+    float2 *dst = out + xf * (long)N;
+    float2 a[4][8]; // [d2][b0 + 2 d1]
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[d2][j] = (src + (long)S * (16 * (j & 1) + 4 * (j >> 1) + d2))[(unsigned)lane];
+    const float2 w0 = tw[0u], w1 = tw[N >> 3], w2 = tw[2 * (N >> 3)], w3 = tw[3 * (N >> 3)];
+    RD_SCHED_BARRIER();
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2) {
+#pragma unroll
+        for (int d1 = 0; d1 < 4; ++d1) bfly2(a[d2][2 * d1], a[d2][2 * d1 + 1], w0);
+        bfly4x2<INV>(a[d2][0], a[d2][2], a[d2][4], a[d2][6], w0, w0, w0, a[d2][1], a[d2][3], a[d2][5], a[d2][7], w1, w2, w3);
+    }
+    const unsigned fs = N >> 5; // stage on d2: sub-length 8, k = b0 + 2 d1
+#pragma unroll
+    for (int k = 0; k < 8; k += 2)
+        bfly4x2<INV>(a[0][k], a[1][k], a[2][k], a[3][k], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs],
+                     a[0][k + 1], a[1][k + 1], a[2][k + 1], a[3][k + 1], tw[(k + 1) * fs], tw[2 * (k + 1) * fs], tw[3 * (k + 1) * fs]);
+    // source column r = 64 c + lane is column h = digit reversal of r (nd digits) of the working array; 32 rows per column
+    unsigned h = 0;
+    for (int d = 0, rr = 64 * c + lane; d < nd; ++d, rr >>= 2) h = (h << 2) | (rr & 3);
+    float4 *o = reinterpret_cast<float4 *>(dst + 32l * h);
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) o[(8 * d2 + j) / 2] = make_float4(a[d2][j].x, a[d2][j].y, a[d2][j + 1].x, a[d2][j + 1].y); // row b0 + 2 d1 + 8 d2
+}
+
+template <bool INV>
+static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, int lgN, hipStream_t s)
+{
+    const long ntiles = nbatch << (lgN - 12);
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
-    hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, L);
-    hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, tw, ntiles, L, 4);
-    switch (L - 8) {
-    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, L); break;
-    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, L); break;
-    case 3: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, L); break;
-    case 4: hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, tw, ntiles, L, 8); break;
-    default: return hipErrorNotSupported;
+    int lm, left; // rows of the next pass are 2^lm apart; radix-4 stages left
+    if (lgN & 1) { // 2 * 4^L
+        const long nt2 = nbatch << (lgN - 11);
+        hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN);
+        lm = 5; left = (lgN - 5) / 2;
+    } else {
+        hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2);
+        lm = 8; left = (lgN - 8) / 2;
+    }
+    while (left >= 4) {
+        hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN, lm);
+        lm += 8; left -= 4;
+    }
+    switch (left) {
+    case 0: break;
+    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN); break;
+    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN); break;
+    default: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN); break;
     }
     return hipGetLastError();
 }
@@ -1578,10 +1633,10 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         return hipGetLastError();
     }
-    if (!generic && p.nfft >= (1 << 18) && p.nfft <= (1 << 24) && (p.nfft & (p.nfft - 1)) == 0 && (__builtin_ctz((unsigned)p.nfft) % 2) == 0) {
+    if (!generic && p.nfft >= (1 << 15) && p.nfft <= (1 << 24) && (p.nfft & (p.nfft - 1)) == 0) { // 32768, 131072 ... 16777216 (16384 and 65536 above)
         if (in == out) return hipErrorNotSupported; // the first pass is a global transposition: the C-ABI layer stages in-place calls
-        const int L = __builtin_ctz((unsigned)p.nfft) / 2;
-        return inv ? launch_fftbig<true>(in, out, p.tw, nbatch, in_stride, L, s) : launch_fftbig<false>(in, out, p.tw, nbatch, in_stride, L, s);
+        const int lgN = __builtin_ctz((unsigned)p.nfft);
+        return inv ? launch_fftbig<true>(in, out, p.tw, nbatch, in_stride, lgN, s) : launch_fftbig<false>(in, out, p.tw, nbatch, in_stride, lgN, s);
     }
     // global-memory stages.  The C-ABI layer routes in-place calls through a temporary and supplies `work`
     // (nbatch * nfft elements) when a generic-radix stage needs an out-of-place step.

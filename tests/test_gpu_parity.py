@@ -151,7 +151,7 @@ def test_fft_large_sizes_with_big_prime_factors(gpu, redio, oracle, n):
     assert same_bits(redio.Fft(n, True)(gpu.from_numpy(xi).cuda()).cpu().numpy(), oracle.fft(xi, n, True))
 
 
-@pytest.mark.parametrize("n", [16384, 65536, 262144, 1048576])
+@pytest.mark.parametrize("n", [16384, 32768, 65536, 131072, 262144, 524288, 1048576])
 def test_fft_large_global_path(gpu, redio, oracle, n):
     x = oracle.synth_iq(n, 0, n * 2)
     d = gpu.from_numpy(x).cuda()
@@ -165,9 +165,9 @@ def test_fft_large_global_path(gpu, redio, oracle, n):
     assert same_bits(d.cpu().numpy(), got)
 
 
-@pytest.mark.parametrize("n", [1 << 22, 1 << 24])
+@pytest.mark.parametrize("n", [1 << 21, 1 << 22, 1 << 23, 1 << 24])
 def test_fft_multi_pass_powers_of_four(gpu, redio, oracle, n):
-    # 4^11 and 4^12: pass A, pass B and a three-stage last pass / a second pass B (fft_kernels.hip, fftbig_*)
+    # 2 * 4^10, 4^11, 2 * 4^11, 4^12: gather pass, in-place four-stage passes, register-only last stages (fft_kernels.hip, fftbig_*)
     x = oracle.synth_iq(n & 0xFFFF, 0, n)
     d = gpu.from_numpy(x).cuda()
     for inverse in (False, True):
