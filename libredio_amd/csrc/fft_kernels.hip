@@ -1270,6 +1270,15 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
 // neighbouring positions; the last one to three stages (rows 65536 apart) need no regrouping at all: a lane keeps whole
 // columns in registers and every load and store is 512 contiguous bytes.  16 B/sample per pass.  Twiddle index of the stage
 // with sub-length m: (e mod m) * N / (4 m), exactly kissfft's k * fstride.
+// a wave-uniform row pointer kept in scalar registers: with a run-time row stride the compiler otherwise folds the lane
+// offset into a 64-bit vector address per row and runs out of registers
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <bool INV, typename TwPtr>
 __device__ __forceinline__ void big_macro16(float2 (&a)[16], TwPtr tw, unsigned l, unsigned m_lo, unsigned fs, unsigned kk, unsigned m)
 {
@@ -1365,6 +1374,7 @@ template <bool INV, int LG>
 __global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int lgN)
 {
     constexpr int G = 1 << (2 * LG), CPT = 4096 / G; // rows, columns per tile
+    constexpr int GG = G < 16 ? G : 16, NG = G / GG; // row g = 16 d2 + j lives in a[.][d2][j]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = (long)blockIdx.x * 4 + w;
     if (tile >= ntiles) return;
@@ -1372,35 +1382,38 @@ __global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const
     const long xf = tile >> (lgN - 12);
     const unsigned l0 = (unsigned)(tile & ((1u << (lgN - 12)) - 1)) * CPT;
     float2 *base = data + xf * (long)N + l0;
-    float2 a[CPT / 64][G];
+    float2 a[CPT / 64][NG][GG];
 #pragma unroll
     for (int i = 0; i < CPT / 64; ++i)
 #pragma unroll
-        for (int g = 0; g < G; ++g) a[i][g] = (base + (long)m_lo * g + 64 * i)[(unsigned)lane];
+        for (int g = 0; g < G; ++g) a[i][g / GG][g % GG] = uniform_ptr(base + (long)m_lo * g + 64 * i)[(unsigned)lane];
     RD_SCHED_BARRIER();
 #pragma unroll
     for (int i = 0; i < CPT / 64; ++i) {
         const unsigned l = l0 + 64 * i + lane;
         if constexpr (LG == 1) {
-            bfly4<INV>(a[i][0], a[i][1], a[i][2], a[i][3], tw[l], tw[2 * l], tw[3 * l]);
+            bfly4<INV>(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], tw[l], tw[2 * l], tw[3 * l]);
         } else if constexpr (LG == 2) {
-            big_macro16<INV>(a[i], tw, l, m_lo, 4u, 0u, 1u);
+            big_macro16<INV>(a[i][0], tw, l, m_lo, 4u, 0u, 1u);
         } else {
-            float2 (&v)[4][16] = reinterpret_cast<float2 (&)[4][16]>(a[i]); // row g = j + 16 d2
 #pragma unroll
-            for (int d2 = 0; d2 < 4; ++d2) big_macro16<INV>(v[d2], tw, l, m_lo, 16u, 0u, 1u);
+            for (int d2 = 0; d2 < 4; ++d2) {
+                big_macro16<INV>(a[i][d2], tw, l, m_lo, 16u, 0u, 1u);
+                RD_SCHED_BARRIER(); // keeps the other groups' twiddle loads from being hoisted here (64 points are live)
+            }
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                const unsigned k = l + m_lo * j, kb = k + m_lo;
-                bfly4x2<INV>(v[0][j], v[1][j], v[2][j], v[3][j], tw[k], tw[2 * k], tw[3 * k],
-                             v[0][j + 1], v[1][j + 1], v[2][j + 1], v[3][j + 1], tw[kb], tw[2 * kb], tw[3 * kb]);
+            for (int jj = 0; jj < 16; jj += 2) {
+                const unsigned k = l + m_lo * jj, kb = k + m_lo;
+                bfly4x2<INV>(a[i][0][jj], a[i][1][jj], a[i][2][jj], a[i][3][jj], tw[k], tw[2 * k], tw[3 * k],
+                             a[i][0][jj + 1], a[i][1][jj + 1], a[i][2][jj + 1], a[i][3][jj + 1], tw[kb], tw[2 * kb], tw[3 * kb]);
+                if ((jj & 6) == 6) RD_SCHED_BARRIER();
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < CPT / 64; ++i)
 #pragma unroll
-        for (int g = 0; g < G; ++g) (base + (long)m_lo * g + 64 * i)[(unsigned)lane] = a[i][g];
+        for (int g = 0; g < G; ++g) uniform_ptr(base + (long)m_lo * g + 64 * i)[(unsigned)lane] = a[i][g / GG][g % GG];
 }
 
 // N = 2 * 4^L (32768 ... 8388608): kissfft runs the radix-2 stage first.  The gather pass takes the three stages on
