@@ -1279,22 +1279,44 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
     return p;
 }
 
-template <bool INV, typename TwPtr>
-__device__ __forceinline__ void big_macro16(float2 (&a)[16], TwPtr tw, unsigned l, unsigned m_lo, unsigned fs, unsigned kk, unsigned m)
+// twiddle n k N / (4 m) of the stage with sub-length m: straight from kissfft's table (stride fs = N / (4 m)), or from the
+// pass-ordered copy T[(n - 1) m + k] (fftbig_tables_build), where lanes with neighbouring k read neighbouring entries --
+// in the table order a wave's 64 twiddles of an in-place pass sit in 64 different cache lines
+struct TwGather {
+    const float2 *tw; unsigned fs;
+    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return tw[n * k * fs]; }
+};
+struct TwOrdered {
+    const float2 *T; unsigned m;
+    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[(n - 1) * m + k]; }
+};
+template <bool INV, typename TA, typename TB>
+__device__ __forceinline__ void big_macro16(float2 (&a)[16], TA ta, TB tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
 {
     {
         const unsigned k = l + m_lo * kk;
-        const float2 t1 = tw[k * fs], t2 = tw[2 * k * fs], t3 = tw[3 * k * fs];
+        const float2 t1 = ta.get(1, k), t2 = ta.get(2, k), t3 = ta.get(3, k);
 #pragma unroll
         for (int q = 0; q < 4; q += 2)
             bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
     }
-    const unsigned fs2 = fs >> 2;
 #pragma unroll
     for (int u = 0; u < 4; u += 2) {
         const unsigned k = l + m_lo * (kk + u * m), kb = k + m_lo * m;
-        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k * fs2], tw[2 * k * fs2], tw[3 * k * fs2],
-                     a[u + 1], a[u + 5], a[u + 9], a[u + 13], tw[kb * fs2], tw[2 * kb * fs2], tw[3 * kb * fs2]);
+        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tb.get(1, k), tb.get(2, k), tb.get(3, k),
+                     a[u + 1], a[u + 5], a[u + 9], a[u + 13], tb.get(1, kb), tb.get(2, kb), tb.get(3, kb));
+    }
+}
+// the ordered copy of one pass: stage t (sub-length m_lo 4^t) starts at m_lo (4^t - 1) and holds 3 m_lo 4^t entries
+__device__ __forceinline__ TwOrdered tw_ordered_stage(const float2 *T, unsigned m_lo, int t) { return TwOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
+__global__ __launch_bounds__(256) void fftbig_tables_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned m_lo, int nstages, unsigned N)
+{
+    const unsigned total = m_lo * ((1u << (2 * nstages)) - 1);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int t = 0;
+        while (i >= m_lo * ((1u << (2 * (t + 1))) - 1)) ++t;
+        const unsigned m = m_lo << (2 * t), r = i - m_lo * ((1u << (2 * t)) - 1), n = r / m + 1, k = r - (n - 1) * m;
+        T[i] = tw[n * k * (N / (4 * m))];
     }
 }
 
@@ -1321,10 +1343,10 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
         for (int j = 0; j < 16; ++j) a[i][j] = (src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src]; // source row rev4(16 (4i + q) + j)
     RD_SCHED_BARRIER();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw, 0u, 1u, N >> 2, 0u, 1u);
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], TwGather{tw, N >> 2}, TwGather{tw, N >> 4}, 0u, 1u, 0u, 1u);
     f64w_exchange<false, true>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw, 0u, 1u, N >> 6, (unsigned)col, 16u);
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], TwGather{tw, N >> 6}, TwGather{tw, N >> 8}, 0u, 1u, (unsigned)col, 16u);
     // column r = 16c + 4q + x of the source is column h = digit reversal of r (L - 4 digits) of the working array
     unsigned rc = 0;
     for (int d = 0, cc = c; d < L - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
@@ -1337,7 +1359,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
 }
 
 template <bool INV>
-__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int lgN, int lm)
+__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ T, long ntiles, int lgN, int lm)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1350,7 +1372,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
     const unsigned c = tt & ((m_lo >> 4) - 1), h = tt >> (lm - 4); // positions l = 16c + col of block h
     const int col = lane & 15, q = lane >> 4;
     float2 *base = data + xf * (long)N + (long)h * 256 * m_lo + 16 * c;
-    const unsigned l = 16 * c + col, fsb = N >> (lm + 2);
+    const unsigned l = 16 * c + col;
     float2 a[4][16], b[4][16];
     const unsigned lo_ld = col + 16u * m_lo * q, lo_st = col + m_lo * q;
 #pragma unroll
@@ -1359,10 +1381,10 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
         for (int j = 0; j < 16; ++j) a[i][j] = (base + (long)m_lo * (64 * i + j))[lo_ld]; // row 16 (4i + q) + j
     RD_SCHED_BARRIER();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw, l, m_lo, fsb, 0u, 1u);
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw_ordered_stage(T, m_lo, 0), tw_ordered_stage(T, m_lo, 1), l, m_lo, 0u, 1u);
     f64w_exchange<false, false>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw, l, m_lo, fsb >> 4, (unsigned)(q + 4 * x), 16u);
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw_ordered_stage(T, m_lo, 2), tw_ordered_stage(T, m_lo, 3), l, m_lo, (unsigned)(q + 4 * x), 16u);
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -1371,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
 
 // the last LG = 1, 2 or 3 stages: G = 4^LG rows, m_lo = N / G apart; a wave takes 4096 / G neighbouring columns
 template <bool INV, int LG>
-__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, long ntiles, int lgN)
+__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, const float2 *__restrict__ T, long ntiles, int lgN)
 {
     constexpr int G = 1 << (2 * LG), CPT = 4096 / G; // rows, columns per tile
     constexpr int GG = G < 16 ? G : 16, NG = G / GG; // row g = 16 d2 + j lives in a[.][d2][j]
@@ -1394,11 +1416,11 @@ __global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const
         if constexpr (LG == 1) {
             bfly4<INV>(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], tw[l], tw[2 * l], tw[3 * l]);
         } else if constexpr (LG == 2) {
-            big_macro16<INV>(a[i][0], tw, l, m_lo, 4u, 0u, 1u);
+            big_macro16<INV>(a[i][0], TwGather{tw, 4u}, TwGather{tw, 1u}, l, m_lo, 0u, 1u);
         } else {
 #pragma unroll
             for (int d2 = 0; d2 < 4; ++d2) {
-                big_macro16<INV>(a[i][d2], tw, l, m_lo, 16u, 0u, 1u);
+                big_macro16<INV>(a[i][d2], tw_ordered_stage(T, m_lo, 0), tw_ordered_stage(T, m_lo, 1), l, m_lo, 0u, 1u);
                 RD_SCHED_BARRIER(); // keeps the other groups' twiddle loads from being hoisted here (64 points are live)
             }
 #pragma unroll
@@ -1461,29 +1483,63 @@ __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, fl
         for (int j = 0; j < 8; j += 2) o[(8 * d2 + j) / 2] = make_float4(a[d2][j].x, a[d2][j].y, a[d2][j + 1].x, a[d2][j + 1].y); // row b0 + 2 d1 + 8 d2
 }
 
+// the passes after the gather pass: rows 2^lm apart, `left` radix-4 stages to go
+static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384 && nfft != F64K_N; }
+static void fftbig_after_first(int lgN, int &lm, int &left)
+{
+    if (lgN & 1) { lm = 5; left = (lgN - 5) / 2; } // 2 * 4^L: the gather pass did the radix-2 stage and two radix-4 stages
+    else { lm = 8; left = (lgN - 8) / 2; }
+}
+size_t fftbig_tables_elems(int nfft)
+{
+    if (!fftbig_size(nfft)) return 0;
+    const int lgN = __builtin_ctz((unsigned)nfft);
+    int lm, left;
+    fftbig_after_first(lgN, lm, left);
+    size_t total = 0;
+    for (; left >= 4; lm += 8, left -= 4) total += (size_t)255 << lm;
+    if (left == 3) total += (size_t)15 << (lgN - 6);
+    return total;
+}
+hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s)
+{
+    if (!fftbig_size(nfft)) return hipErrorInvalidValue;
+    const int lgN = __builtin_ctz((unsigned)nfft);
+    int lm, left;
+    fftbig_after_first(lgN, lm, left);
+    float2 *T = tables;
+    for (; left >= 4; lm += 8, left -= 4) {
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm, 4, (unsigned)nfft);
+        T += (size_t)255 << lm;
+    }
+    if (left == 3) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft);
+    return hipGetLastError();
+}
+
 template <bool INV>
-static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, int lgN, hipStream_t s)
+static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, const float2 *tables, long nbatch, long in_stride, int lgN,
+                                hipStream_t s)
 {
     const long ntiles = nbatch << (lgN - 12);
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
-    int lm, left; // rows of the next pass are 2^lm apart; radix-4 stages left
-    if (lgN & 1) { // 2 * 4^L
+    if (lgN & 1) {
         const long nt2 = nbatch << (lgN - 11);
         hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN);
-        lm = 5; left = (lgN - 5) / 2;
     } else {
         hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2);
-        lm = 8; left = (lgN - 8) / 2;
     }
-    while (left >= 4) {
-        hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN, lm);
-        lm += 8; left -= 4;
+    int lm, left;
+    fftbig_after_first(lgN, lm, left);
+    const float2 *T = tables;
+    for (; left >= 4; lm += 8, left -= 4) {
+        hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T, ntiles, lgN, lm);
+        T += (size_t)255 << lm;
     }
     switch (left) {
     case 0: break;
-    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN); break;
-    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN); break;
-    default: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, ntiles, lgN); break;
+    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN); break;
+    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN); break;
+    default: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN); break;
     }
     return hipGetLastError();
 }
@@ -1646,10 +1702,11 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         return hipGetLastError();
     }
-    if (!generic && p.nfft >= (1 << 15) && p.nfft <= (1 << 24) && (p.nfft & (p.nfft - 1)) == 0) { // 32768, 131072 ... 16777216 (16384 and 65536 above)
+    if (fftbig_size(p.nfft) && p.tw_pass) { // 32768, 131072 ... 16777216 (16384 and 65536 above)
         if (in == out) return hipErrorNotSupported; // the first pass is a global transposition: the C-ABI layer stages in-place calls
         const int lgN = __builtin_ctz((unsigned)p.nfft);
-        return inv ? launch_fftbig<true>(in, out, p.tw, nbatch, in_stride, lgN, s) : launch_fftbig<false>(in, out, p.tw, nbatch, in_stride, lgN, s);
+        return inv ? launch_fftbig<true>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s)
+                   : launch_fftbig<false>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s);
     }
     // global-memory stages.  The C-ABI layer routes in-place calls through a temporary and supplies `work`
     // (nbatch * nfft elements) when a generic-radix stage needs an out-of-place step.

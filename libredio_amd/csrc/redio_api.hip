@@ -297,7 +297,7 @@ extern "C" int redio_convolve_f32(const float *u, size_t nu, const float *v, siz
 struct redio_fft {
     int device;
     FftPlanDev dev;
-    float2 *d_tw;
+    float2 *d_tw, *d_tw_pass;
     int *d_leaf, *d_leaf_pos;
     float2 *d_tmp; // for in-place calls on the global-memory path
     size_t tmp_elems;
@@ -314,7 +314,7 @@ extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
     redio_fft *p = new (std::nothrow) redio_fft();
     if (!p) return REDIO_ERR_NOMEM;
     memset(&p->dev, 0, sizeof(p->dev));
-    p->device = dev; p->d_tw = nullptr; p->d_leaf = p->d_leaf_pos = nullptr; p->d_tmp = nullptr; p->tmp_elems = 0;
+    p->device = dev; p->d_tw = nullptr; p->d_tw_pass = nullptr; p->d_leaf = p->d_leaf_pos = nullptr; p->d_tmp = nullptr; p->tmp_elems = 0;
     p->dev.nfft = nfft; p->dev.inverse = inverse ? 1 : 0;
     p->dev.nstages = fft_plan_stages(nfft, p->dev.st, FFT_MAX_STAGES);
     if (p->dev.nstages < 0) { delete p; return REDIO_ERR_UNSUPPORTED; }
@@ -348,6 +348,18 @@ extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
         return hip_rc(e);
     }
     p->dev.tw = p->d_tw;
+    p->dev.tw_pass = nullptr;
+    if (const size_t ne = fftbig_tables_elems(nfft)) { // the multi-pass sizes read their twiddles in pass order
+        e = hipMalloc((void **)&p->d_tw_pass, ne * sizeof(float2));
+        if (e == hipSuccess) e = fftbig_tables_build(p->d_tw, p->d_tw_pass, nfft, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) {
+            hipFree(p->d_tw); hipFree(p->d_leaf); hipFree(p->d_leaf_pos); hipFree(p->d_tw_pass);
+            delete p;
+            return hip_rc(e);
+        }
+        p->dev.tw_pass = p->d_tw_pass;
+    }
     p->dev.leaf_src = p->d_leaf;
     p->dev.leaf_pos = p->d_leaf_pos;
     *h = p;
@@ -357,6 +369,7 @@ extern "C" int redio_fft_destroy(redio_fft *h)
 {
     if (!h) return REDIO_OK;
     hipFree(h->d_tw);
+    if (h->d_tw_pass) hipFree(h->d_tw_pass);
     hipFree(h->d_leaf);
     hipFree(h->d_leaf_pos);
     if (h->d_tmp) hipFree(h->d_tmp);

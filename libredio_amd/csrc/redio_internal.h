@@ -19,6 +19,7 @@ struct FftPlanDev {
     int nstages;
     FftStage st[FFT_MAX_STAGES];
     const float2 *tw;     // device twiddle table, nfft entries
+    const float2 *tw_pass; // powers of two from 32768 up: the same values re-ordered per pass (fftbig_tables_*), else null
     const int *leaf_src;  // device table: leaf position -> input index (digit reversal), nfft entries
     const int *leaf_pos;  // the inverse: input index -> leaf position
     unsigned magic_m[FFT_MAX_STAGES]; // ceil(2^32 / m) per stage and ceil(2^32 / nfft): exact quotients by __umulhi for
@@ -26,6 +27,9 @@ struct FftPlanDev {
 };
 // in != out on the paths that say so (hipErrorNotSupported otherwise: the C-ABI layer stages the input); work
 // (nfft*nbatch float2) is needed by the global-memory path when the size has a prime factor above 5
+// per-pass twiddle tables of the multi-pass transforms: element count for nfft (0: none needed) and the device-side build
+size_t fftbig_tables_elems(int nfft);
+hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s);
 hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0,
                       float2 *work = nullptr);
 
