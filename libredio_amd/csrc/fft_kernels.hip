@@ -731,6 +731,57 @@ __device__ __forceinline__ void macro16_x4(float2 (&a)[4][16], FftTw15 &T0, Load
         }
     }
 }
+// ---- twiddle access of the tile passes (65536 points and the larger powers of two) -----------------
+// a wave-uniform row pointer kept in scalar registers: with a run-time row stride the compiler otherwise folds the lane
+// offset into a 64-bit vector address per row and runs out of registers
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// twiddle n k N / (4 m) of the stage with sub-length m: straight from kissfft's table (stride fs = N / (4 m)), or from the
+// pass-ordered copy T[(n - 1) m + k] (fftbig_tables_build), where lanes with neighbouring k read neighbouring entries --
+// in the table order a wave's 64 twiddles of an in-place pass sit in 64 different cache lines
+struct TwGather {
+    const float2 *tw; unsigned fs;
+    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return tw[n * k * fs]; }
+};
+struct TwOrdered {
+    const float2 *T; unsigned m;
+    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[(n - 1) * m + k]; }
+};
+template <bool INV, typename TA, typename TB>
+__device__ __forceinline__ void big_macro16(float2 (&a)[16], TA ta, TB tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
+{
+    {
+        const unsigned k = l + m_lo * kk;
+        const float2 t1 = ta.get(1, k), t2 = ta.get(2, k), t3 = ta.get(3, k);
+#pragma unroll
+        for (int q = 0; q < 4; q += 2)
+            bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u += 2) {
+        const unsigned k = l + m_lo * (kk + u * m), kb = k + m_lo * m;
+        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tb.get(1, k), tb.get(2, k), tb.get(3, k),
+                     a[u + 1], a[u + 5], a[u + 9], a[u + 13], tb.get(1, kb), tb.get(2, kb), tb.get(3, kb));
+    }
+}
+// the ordered copy of one pass: stage t (sub-length m_lo 4^t) starts at m_lo (4^t - 1) and holds 3 m_lo 4^t entries
+__device__ __forceinline__ TwOrdered tw_ordered_stage(const float2 *T, unsigned m_lo, int t) { return TwOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
+__global__ __launch_bounds__(256) void fftbig_tables_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned m_lo, int nstages, unsigned N)
+{
+    const unsigned total = m_lo * ((1u << (2 * nstages)) - 1);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int t = 0;
+        while (i >= m_lo * ((1u << (2 * (t + 1))) - 1)) ++t;
+        const unsigned m = m_lo << (2 * t), r = i - m_lo * ((1u << (2 * t)) - 1), n = r / m + 1, k = r - (n - 1) * m;
+        T[i] = tw[n * k * (N / (4 * m))];
+    }
+}
+
 // ---- N = 65536, one wavefront per 256 x 16 tile ---------------------------------------------------
 // The same two passes of four stages, but a tile belongs to ONE wave: lane (col = lane & 15, q = lane >> 4) loads
 // four 16-row groups of its column straight from memory into registers (64 points per lane), runs stages t = 0, 1,
@@ -773,53 +824,11 @@ __device__ __forceinline__ void f64w_exchange(float2 (&a)[4][16], float2 (&b)[4]
     }
 }
 
-template <bool INV, int PASS>
-__global__ __launch_bounds__(256, 2) void fft64k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
-                                                          long ntiles)
-{
-    __shared__ float2 Ls[4 * F64W_REGION];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long tile = f64w_first_tile() + w;
-    if (tile >= ntiles) return; // wave-uniform; no workgroup barrier below
-    float2 *Lw = Ls + w * F64W_REGION;
-    const long xf = tile >> 4;
-    const int c = (int)(tile & 15), col = lane & 15, q = lane >> 4;
-    // addresses = wave-uniform pointer + compile-time row + one 32-bit lane offset (scalar base + vector offset loads)
-    const float2 *src = (PASS == 0 ? in + xf * in_stride : out + xf * F64K_N) + F64K_COLS * c;
-    float2 *dst = out + xf * F64K_N;
-    const unsigned lo_q1 = col + 256u * q, lo_q4 = col + 1024u * q, lo_q16 = col + 4096u * q;
-    float2 a[4][16], b[4][16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { // row 16 (4i + q) + j in transform order; pass 0 reads the digit-reversed one
-            if (PASS == 0) a[i][j] = (src + 256 * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_q4];
-            else a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f64k_macro_regs<INV>(a[i], tw, PASS, 0, 0, F64K_COLS * c + col);
-    f64w_exchange<false, PASS == 0>(a, b, Lw, lane);
-#pragma unroll
-    for (int x = 0; x < 4; ++x) f64k_macro_regs<INV>(b[x], tw, PASS, 2, PASS == 0 ? col : q + 4 * x, F64K_COLS * c + col);
-    if (PASS == 0) { // lane = (row s = lane & 15, column 4q + x): 128-byte runs of the transposed layout, f64k_p0_dst
-        const int rc = ((c & 3) << 2) | (c >> 2);
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) (dst + 256 * (64 * x + rc) + 16 * j)[lo_q16] = b[x][j];
-    } else {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) (dst + F64K_COLS * c + 256 * (4 * x + 16 * j))[lo_q1] = b[x][j];
-    }
-}
-
 // overlap-save middle pass: forward pass 1, spectrum product, inverse pass 0 on the same tile.  After the forward
 // stages lane (col, q) holds rows s + 16 j, s = q + 4 x: in the inverse transform's digit-reversed order that IS
 // group 4 q + x with rows in rev2 order, so the inverse starts from registers without another exchange.
 __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out,
-                                                                 const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
+                                                                 const float2 *__restrict__ Tf, const float2 *__restrict__ tw_i,
                                                                  const float2 *__restrict__ Hc, long ntiles)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
@@ -838,10 +847,10 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f64k_macro_regs<false>(a[i], tw_f, 1, 0, 0, F64K_COLS * c + col);
+    for (int i = 0; i < 4; ++i) big_macro16<false>(a[i], tw_ordered_stage(Tf, 256u, 0), tw_ordered_stage(Tf, 256u, 1), (unsigned)(F64K_COLS * c + col), 256u, 0u, 1u);
     f64w_exchange<false, false>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) f64k_macro_regs<false>(b[x], tw_f, 1, 2, q + 4 * x, F64K_COLS * c + col);
+    for (int x = 0; x < 4; ++x) big_macro16<false>(b[x], tw_ordered_stage(Tf, 256u, 2), tw_ordered_stage(Tf, 256u, 3), (unsigned)(F64K_COLS * c + col), 256u, (unsigned)(q + 4 * x), 16u);
     const float2 *hc = Hc + F64K_COLS * c;
 #pragma unroll
     for (int x = 0; x < 4; ++x) { // sixteen spectrum taps as one batch of loads (the compiler would wait for them one by one)
@@ -866,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
 }
 
 __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
-                                                                  const float2 *__restrict__ tw_i, long hop, float scale, long ntiles)
+                                                                  const float2 *__restrict__ Ti, long hop, float scale, long ntiles)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -884,10 +893,10 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f64k_macro_regs<true>(a[i], tw_i, 1, 0, 0, F64K_COLS * c + col);
+    for (int i = 0; i < 4; ++i) big_macro16<true>(a[i], tw_ordered_stage(Ti, 256u, 0), tw_ordered_stage(Ti, 256u, 1), (unsigned)(F64K_COLS * c + col), 256u, 0u, 1u);
     f64w_exchange<false, false>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) f64k_macro_regs<true>(b[x], tw_i, 1, 2, q + 4 * x, F64K_COLS * c + col);
+    for (int x = 0; x < 4; ++x) big_macro16<true>(b[x], tw_ordered_stage(Ti, 256u, 2), tw_ordered_stage(Ti, 256u, 3), (unsigned)(F64K_COLS * c + col), 256u, (unsigned)(q + 4 * x), 16u);
     const long lim = hop - F64K_COLS * c - (long)lo_q1; // pos < hop
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -1270,56 +1279,6 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
 // neighbouring positions; the last one to three stages (rows 65536 apart) need no regrouping at all: a lane keeps whole
 // columns in registers and every load and store is 512 contiguous bytes.  16 B/sample per pass.  Twiddle index of the stage
 // with sub-length m: (e mod m) * N / (4 m), exactly kissfft's k * fstride.
-// a wave-uniform row pointer kept in scalar registers: with a run-time row stride the compiler otherwise folds the lane
-// offset into a 64-bit vector address per row and runs out of registers
-template <typename T>
-__device__ __forceinline__ T *uniform_ptr(T *p)
-{
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// twiddle n k N / (4 m) of the stage with sub-length m: straight from kissfft's table (stride fs = N / (4 m)), or from the
-// pass-ordered copy T[(n - 1) m + k] (fftbig_tables_build), where lanes with neighbouring k read neighbouring entries --
-// in the table order a wave's 64 twiddles of an in-place pass sit in 64 different cache lines
-struct TwGather {
-    const float2 *tw; unsigned fs;
-    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return tw[n * k * fs]; }
-};
-struct TwOrdered {
-    const float2 *T; unsigned m;
-    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[(n - 1) * m + k]; }
-};
-template <bool INV, typename TA, typename TB>
-__device__ __forceinline__ void big_macro16(float2 (&a)[16], TA ta, TB tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
-{
-    {
-        const unsigned k = l + m_lo * kk;
-        const float2 t1 = ta.get(1, k), t2 = ta.get(2, k), t3 = ta.get(3, k);
-#pragma unroll
-        for (int q = 0; q < 4; q += 2)
-            bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u += 2) {
-        const unsigned k = l + m_lo * (kk + u * m), kb = k + m_lo * m;
-        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tb.get(1, k), tb.get(2, k), tb.get(3, k),
-                     a[u + 1], a[u + 5], a[u + 9], a[u + 13], tb.get(1, kb), tb.get(2, kb), tb.get(3, kb));
-    }
-}
-// the ordered copy of one pass: stage t (sub-length m_lo 4^t) starts at m_lo (4^t - 1) and holds 3 m_lo 4^t entries
-__device__ __forceinline__ TwOrdered tw_ordered_stage(const float2 *T, unsigned m_lo, int t) { return TwOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
-__global__ __launch_bounds__(256) void fftbig_tables_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned m_lo, int nstages, unsigned N)
-{
-    const unsigned total = m_lo * ((1u << (2 * nstages)) - 1);
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        int t = 0;
-        while (i >= m_lo * ((1u << (2 * (t + 1))) - 1)) ++t;
-        const unsigned m = m_lo << (2 * t), r = i - m_lo * ((1u << (2 * t)) - 1), n = r / m + 1, k = r - (n - 1) * m;
-        T[i] = tw[n * k * (N / (4 * m))];
-    }
-}
-
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
                                                            long ntiles, int L)
@@ -1484,7 +1443,7 @@ __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, fl
 }
 
 // the passes after the gather pass: rows 2^lm apart, `left` radix-4 stages to go
-static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384 && nfft != F64K_N; }
+static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384; }
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
     if (lgN & 1) { lm = 5; left = (lgN - 5) / 2; } // 2 * 4^L: the gather pass did the radix-2 stage and two radix-4 stages
@@ -1544,24 +1503,15 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     return hipGetLastError();
 }
 
-template <bool INV>
-static hipError_t launch_fft64k(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, hipStream_t s)
+hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
+                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, hipStream_t s)
 {
-    const long ntiles = nbatch * 16;
-    const unsigned grid = (unsigned)((ntiles + 3) / 4);
-    hipLaunchKernelGGL((fft64k_wave_kernel<INV, 0>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles);
-    hipLaunchKernelGGL((fft64k_wave_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles);
-    return hipGetLastError();
-}
-
-hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
-                            float2 *out, long nblk, float scale, hipStream_t s)
-{
+    if (!Tf || !Ti) return hipErrorInvalidValue; // the plans' pass-ordered twiddle copies (fftbig_tables_build)
     const long ntiles = nblk * 16;
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
-    hipLaunchKernelGGL((fft64k_wave_kernel<false, 0>), dim3(grid), dim3(256), 0, s, x, a, tw_f, hop, ntiles);
-    hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3(grid), dim3(256), 0, s, a, b, tw_f, tw_i, Hc, ntiles);
-    hipLaunchKernelGGL(ovsave64k_last_wave_kernel, dim3(grid), dim3(256), 0, s, b, out, tw_i, hop, scale, ntiles);
+    hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3(grid), dim3(256), 0, s, x, a, tw_f, hop, ntiles, 8);
+    hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3(grid), dim3(256), 0, s, a, b, Tf, tw_i, Hc, ntiles);
+    hipLaunchKernelGGL(ovsave64k_last_wave_kernel, dim3(grid), dim3(256), 0, s, b, out, Ti, hop, scale, ntiles);
     return hipGetLastError();
 }
 
@@ -1636,10 +1586,6 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         else hipLaunchKernelGGL(fft16k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
         return hipGetLastError();
     }
-    if (p.nfft == F64K_N) {
-        if (in == out) return hipErrorNotSupported; // pass 0 is a global transposition: the C-ABI layer stages in-place calls
-        return inv ? launch_fft64k<true>(in, out, p.tw, nbatch, in_stride, s) : launch_fft64k<false>(in, out, p.tw, nbatch, in_stride, s);
-    }
     {   // sizes with a compile-time pass list
         hipError_t e = hipErrorNotSupported;
         switch (p.nfft) {
@@ -1702,7 +1648,7 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         else hipLaunchKernelGGL(kf, dim3((unsigned)nbatch), dim3(nt), lds, s, p, in, out, in_stride);
         return hipGetLastError();
     }
-    if (fftbig_size(p.nfft) && p.tw_pass) { // 32768, 131072 ... 16777216 (16384 and 65536 above)
+    if (fftbig_size(p.nfft) && p.tw_pass) { // 32768, 65536, 131072 ... 16777216 (16384 above)
         if (in == out) return hipErrorNotSupported; // the first pass is a global transposition: the C-ABI layer stages in-place calls
         const int lgN = __builtin_ctz((unsigned)p.nfft);
         return inv ? launch_fftbig<true>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s)

@@ -140,7 +140,7 @@ extern "C" int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_
         const long total = (long)(nb * (size_t)h->nfft);
         if (h->nfft == F64K_N) { // three fused passes (fft_kernels.hip), bit-identical to the generic sequence below
             OV_TRY(launch_ovsave64k((const float2 *)d_in + b0 * h->hop, (long)h->hop, h->d_a, h->d_b, redio_fft_twiddles_dev(h->fw),
-                                    redio_fft_twiddles_dev(h->bw), h->d_Hc, (float2 *)d_out + b0 * h->hop, (long)nb, scale, st));
+                                    redio_fft_twiddles_dev(h->bw), redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc, (float2 *)d_out + b0 * h->hop, (long)nb, scale, st));
             continue;
         }
         int rc = redio_fft_enqueue_strided(h->fw, (const float2 *)d_in + b0 * h->hop, h->d_a, nb, (long)h->hop, st);

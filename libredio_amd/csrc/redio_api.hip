@@ -423,6 +423,7 @@ extern "C" int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d
 }
 
 const float2 *redio_fft_twiddles_dev(const redio_fft *h) { return h ? h->dev.tw : nullptr; }
+const float2 *redio_fft_twiddles_pass_dev(const redio_fft *h) { return h ? h->dev.tw_pass : nullptr; }
 
 // ---------------------------------------------------------------- chain plan
 struct redio_chain {

@@ -41,8 +41,8 @@ hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const 
 hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                             float scale, hipStream_t s); // the same at nfft 16384
 // overlap-save at nfft 65536: x (block b at x + b*hop) -> out (hop valid samples per block), work buffers a, b
-hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Hc,
-                            float2 *out, long nblk, float scale, hipStream_t s);
+hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
+                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, hipStream_t s);
 
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
@@ -58,3 +58,4 @@ hipError_t launch_synth_f32(float *out, uint32_t seed, uint64_t first, long n, h
 // redio_api.hip: the device twiddle table behind a public FFT handle (library-internal)
 struct redio_fft;
 const float2 *redio_fft_twiddles_dev(const redio_fft *h);
+const float2 *redio_fft_twiddles_pass_dev(const redio_fft *h); // the pass-ordered copy (multi-pass sizes), else null
