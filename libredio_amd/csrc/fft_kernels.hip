@@ -693,14 +693,29 @@ __global__ __launch_bounds__(256) void fft_global_generic_stage_kernel(FftPlanDe
 // tw[n (kB + u step) fsB].  The 15 values are loaded as one batch (behind a scheduling barrier where the caller wants the
 // next group's batch in flight during the current group's arithmetic); the compiler otherwise sinks each load to its use.
 struct FftTw15 { float2 t[15]; };
+// the one-wave programs (2048 and 4096 points, also as the quarters of 8192 and 16384) read their twiddles from a
+// stage-ordered copy of the table: the stage with sub-length m = NS / (4 fs) starts at m - ML (ML = 1 for 4096 = 4^6,
+// 2 for 2048 = 2 * 4^5) and holds T[(n - 1) m + k] = tw[n k fs] (fftbig_tables_build), so that lanes with neighbouring k
+// read neighbouring entries (in table order the 64 twiddles of a wave's stage-4 load are spread over 16 to 64 cache lines)
+template <int NS, int ML>
+struct TwProgram { const float2 *T; };
+template <int NS, int ML>
+__device__ __forceinline__ float2 tw_get(TwProgram<NS, ML> p, unsigned k, unsigned fs, unsigned n)
+{
+    const unsigned m = NS / (4 * fs);
+    return p.T[(m - ML) + (n - 1) * m + k];
+}
+template <typename TwPtr>
+__device__ __forceinline__ float2 tw_get(TwPtr tw, unsigned k, unsigned fs, unsigned n) { return tw[n * k * fs]; }
+
 template <typename TwPtr>
 __device__ __forceinline__ void tw15_load(FftTw15 &T, TwPtr tw, unsigned kA, unsigned fsA, unsigned kB, unsigned step, unsigned fsB)
 {
-    T.t[0] = tw[kA * fsA]; T.t[1] = tw[2 * kA * fsA]; T.t[2] = tw[3 * kA * fsA];
+    T.t[0] = tw_get(tw, kA, fsA, 1); T.t[1] = tw_get(tw, kA, fsA, 2); T.t[2] = tw_get(tw, kA, fsA, 3);
 #pragma unroll
     for (unsigned u = 0; u < 4; ++u) {
         const unsigned k = kB + u * step;
-        T.t[3 + 3 * u] = tw[k * fsB]; T.t[4 + 3 * u] = tw[2 * k * fsB]; T.t[5 + 3 * u] = tw[3 * k * fsB];
+        T.t[3 + 3 * u] = tw_get(tw, k, fsB, 1); T.t[4 + 3 * u] = tw_get(tw, k, fsB, 2); T.t[5 + 3 * u] = tw_get(tw, k, fsB, 3);
     }
 }
 template <bool INV>
@@ -975,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void fft4k_wave_kernel(const float2 *in, fl
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 1024 * (j & 3) + 256 * (j >> 2) + 64 * i)[(unsigned)lane];
     RD_SCHED_BARRIER(); // all 64 loads requested before the arithmetic starts
-    fft4k_wave_regs<INV>(a, b, tw, Ls + w * F4W_REGION, lane);
+    fft4k_wave_regs<INV>(a, b, TwProgram<4096, 1>{tw}, Ls + w * F4W_REGION, lane); // tw: the plan's stage-ordered copy
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1004,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 1024 * (j & 3) + 256 * (j >> 2) + 64 * i)[(unsigned)lane];
     RD_SCHED_BARRIER();
-    fft4k_wave_regs<false>(a, b, tw_f, Lw, lane);
+    fft4k_wave_regs<false>(a, b, TwProgram<4096, 1>{tw_f}, Lw, lane); // tw_f, tw_i: the plans' stage-ordered copies
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1017,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
     }
     int lane_i = lane;
     asm volatile("" : "+v"(lane_i)); // recompute the twiddle offsets: keeping the forward transform's sixty alive spills them
-    fft4k_wave_regs<true>(a, b, tw_i, Lw, lane_i);
+    fft4k_wave_regs<true>(a, b, TwProgram<4096, 1>{tw_i}, Lw, lane_i);
     const long lim = hop - lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1038,7 +1053,7 @@ struct TwEvery4W {
     __device__ __forceinline__ float2 operator[](unsigned i) const { return p[4u * i]; }
 };
 template <bool INV>
-__global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+__global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long in_stride)
 {
     __shared__ float2 Ls[4 * F4W_REGION + 4096];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1050,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, f
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
     RD_SCHED_BARRIER();
-    fft4k_wave_regs<INV>(a, b, TwEvery4W{tw}, Ls + w * F4W_REGION, lane);
+    fft4k_wave_regs<INV>(a, b, TwProgram<4096, 1>{T}, Ls + w * F4W_REGION, lane);
     float2 *X = Ls + 4 * F4W_REGION; // [q][1024]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1077,7 +1092,8 @@ __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, f
 // block, one write of the outputs; same operations as transform -> multiply -> transform -> scaled copy.
 constexpr int OV16W_YS = 1040; // stride of one inverse wave's image (bank spread for the lane & 3 scatter)
 __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ tw_f,
-                                                                const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc,
+                                                                const float2 *__restrict__ tw_i, const float2 *__restrict__ Tf,
+                                                                const float2 *__restrict__ Ti, const float2 *__restrict__ Hc,
                                                                 float2 *__restrict__ out, float scale)
 {
     __shared__ float2 Ls[4096 + 4 * OV16W_YS];
@@ -1092,7 +1108,7 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
     RD_SCHED_BARRIER();
-    fft4k_wave_regs<false>(a, b, TwEvery4W{tw_f}, Lw, lane);
+    fft4k_wave_regs<false>(a, b, TwProgram<4096, 1>{Tf}, Lw, lane);
     __syncthreads(); // every wave is done with its private image
 #pragma unroll
     for (int r = 0; r < 4; ++r) { // d4 = r
@@ -1119,7 +1135,7 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
     __syncthreads(); // the images are free again
     int lane_i = lane;
     asm volatile("" : "+v"(lane_i)); // fresh twiddle offsets for the inverse (keeping the forward ones alive spills)
-    fft4k_wave_regs<true>(b, a, TwEvery4W{tw_i}, Lw, lane_i);
+    fft4k_wave_regs<true>(b, a, TwProgram<4096, 1>{Ti}, Lw, lane_i);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) { // d3 = r, as in fft16k_wave_kernel
@@ -1153,7 +1169,7 @@ __device__ __forceinline__ void fft2k_wave_regs(float2 (&a)[4][8], float2 (&b)[2
 {
     const unsigned hi = lane >> 4, low = lane & 15;
     {
-        const float2 w0 = tw[0u], w1 = tw[256u], w2 = tw[512u], w3 = tw[768u];
+        const float2 w0 = tw_get(tw, 0u, 256u, 1), w1 = tw_get(tw, 1u, 256u, 1), w2 = tw_get(tw, 1u, 256u, 2), w3 = tw_get(tw, 1u, 256u, 3);
         RD_SCHED_BARRIER();
 #pragma unroll
         for (int d2 = 0; d2 < 4; ++d2) {
@@ -1231,7 +1247,7 @@ __global__ __launch_bounds__(256) void fft2k_wave_kernel(const float2 *in, float
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[d2][j] = (src + 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[(unsigned)lane]; // j = b0 + 2 d1
     RD_SCHED_BARRIER();
-    fft2k_wave_regs<INV>(a, b, tw, Ls + w * F4W_REGION, lane);
+    fft2k_wave_regs<INV>(a, b, TwProgram<2048, 2>{tw}, Ls + w * F4W_REGION, lane); // tw: the plan's stage-ordered copy
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1240,7 +1256,7 @@ __global__ __launch_bounds__(256) void fft2k_wave_kernel(const float2 *in, float
 
 // 8192: wave q runs the 2048-point program on x[4 n + q]; the last stage (m = 2048) across the waves, as in fft16k_wave_kernel
 template <bool INV>
-__global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+__global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long in_stride)
 {
     __shared__ float2 Ls[4 * F4W_REGION]; // the wave-private images, then (after a barrier) the [q][1024] image of the last stage
     static_assert(4 * F4W_REGION >= 4096, "the shared image fits where the private ones were");
@@ -1253,7 +1269,7 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
     RD_SCHED_BARRIER();
-    fft2k_wave_regs<INV>(a, b, TwEvery4W{tw}, Ls + w * F4W_REGION, lane);
+    fft2k_wave_regs<INV>(a, b, TwProgram<2048, 2>{T}, Ls + w * F4W_REGION, lane);
     float2 *X = Ls;
 #pragma unroll
     for (int r = 0; r < 2; ++r) { // slot = r
@@ -1451,6 +1467,8 @@ static void fftbig_after_first(int lgN, int &lm, int &left)
 }
 size_t fftbig_tables_elems(int nfft)
 {
+    if (nfft == 4096 || nfft == 16384) return 4095; // the one-wave 4096-point program: stages of sub-length 1 ... 1024
+    if (nfft == 2048 || nfft == 8192) return 2046;  // the 2048-point program: sub-lengths 2 ... 512
     if (!fftbig_size(nfft)) return 0;
     const int lgN = __builtin_ctz((unsigned)nfft);
     int lm, left;
@@ -1462,6 +1480,11 @@ size_t fftbig_tables_elems(int nfft)
 }
 hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s)
 {
+    if (nfft == 4096 || nfft == 16384 || nfft == 2048 || nfft == 8192) { // a quarter of 8192 / 16384 uses every fourth entry: the same values
+        const bool p4 = nfft == 4096 || nfft == 16384;
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(16), dim3(256), 0, s, tw, tables, p4 ? 1u : 2u, p4 ? 6 : 5, (unsigned)nfft);
+        return hipGetLastError();
+    }
     if (!fftbig_size(nfft)) return hipErrorInvalidValue;
     const int lgN = __builtin_ctz((unsigned)nfft);
     int lm, left;
@@ -1515,17 +1538,19 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
     return hipGetLastError();
 }
 
-hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
+hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s)
 {
-    hipLaunchKernelGGL(ovsave4k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, nblk, scale);
+    if (!Tf || !Ti) return hipErrorInvalidValue; // the plans' stage-ordered twiddle copies
+    hipLaunchKernelGGL(ovsave4k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, Tf, Ti, Hc, out, nblk, scale);
     return hipGetLastError();
 }
 
-hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                            float scale, hipStream_t s)
+hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Tf, const float2 *Ti, const float2 *Hc,
+                            float2 *out, long nblk, float scale, hipStream_t s)
 {
-    hipLaunchKernelGGL(ovsave16k_wave_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, hop, tw_f, tw_i, Hc, out, scale);
+    if (!Tf || !Ti) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ovsave16k_wave_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, hop, tw_f, tw_i, Tf, Ti, Hc, out, scale);
     return hipGetLastError();
 }
 
@@ -1551,13 +1576,15 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     case 512: return launch_fft_p2<9>(in, out, p.tw, nbatch, in_stride, inv, s);
     case 2048: {
         const unsigned grid = (unsigned)((nbatch + 3) / 4);
-        if (inv) hipLaunchKernelGGL(fft2k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
-        else hipLaunchKernelGGL(fft2k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
+        if (!p.tw_pass) return hipErrorInvalidValue;
+        if (inv) hipLaunchKernelGGL(fft2k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw_pass, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft2k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw_pass, nbatch, in_stride);
         return hipGetLastError();
     }
     case 8192:
-        if (inv) hipLaunchKernelGGL(fft8k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
-        else hipLaunchKernelGGL(fft8k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
+        if (!p.tw_pass) return hipErrorInvalidValue;
+        if (inv) hipLaunchKernelGGL(fft8k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, p.tw_pass, in_stride);
+        else hipLaunchKernelGGL(fft8k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, p.tw_pass, in_stride);
         return hipGetLastError();
     default: break;
     }
@@ -1577,13 +1604,15 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     }
     if (p.nfft == 4096) {
         const unsigned grid = (unsigned)((nbatch + 3) / 4);
-        if (inv) hipLaunchKernelGGL(fft4k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
-        else hipLaunchKernelGGL(fft4k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw, nbatch, in_stride);
+        if (!p.tw_pass) return hipErrorInvalidValue;
+        if (inv) hipLaunchKernelGGL(fft4k_wave_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, p.tw_pass, nbatch, in_stride);
+        else hipLaunchKernelGGL(fft4k_wave_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, p.tw_pass, nbatch, in_stride);
         return hipGetLastError();
     }
     if (p.nfft == 16384) {
-        if (inv) hipLaunchKernelGGL(fft16k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
-        else hipLaunchKernelGGL(fft16k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, in_stride);
+        if (!p.tw_pass) return hipErrorInvalidValue;
+        if (inv) hipLaunchKernelGGL(fft16k_wave_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, p.tw_pass, in_stride);
+        else hipLaunchKernelGGL(fft16k_wave_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, s, in, out, p.tw, p.tw_pass, in_stride);
         return hipGetLastError();
     }
     {   // sizes with a compile-time pass list

@@ -33,13 +33,14 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
 hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, hipStream_t s, long in_stride = 0,
                       float2 *work = nullptr);
 
-// overlap-save at nfft 1024 (one wave per block) and 4096: one kernel, no work buffers
+// overlap-save at nfft 1024 (one wave per block) and 4096: one kernel, no work buffers; at 4096 / 16384 tw_f / tw_i (4096) and
+// Tf / Ti (16384) are the plans' stage-ordered twiddle copies (redio_fft_twiddles_pass_dev)
 hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s);
 hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s);
-hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
-                            float scale, hipStream_t s); // the same at nfft 16384
+hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Tf, const float2 *Ti, const float2 *Hc,
+                            float2 *out, long nblk, float scale, hipStream_t s); // the same at nfft 16384
 // overlap-save at nfft 65536: x (block b at x + b*hop) -> out (hop valid samples per block), work buffers a, b
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
                             const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, hipStream_t s);
