@@ -370,6 +370,14 @@ struct FftCt {
             if (L.p[s] > 5) return false;
         return true;
     }
+    // the stage-ordered twiddle copy of the plan (redio_api.hip): stage s holds T[toff(s) + (n - 1) m + k] = tw[n k fstride],
+    // n = 1 .. p - 1, k < m, so lanes with neighbouring k read neighbouring entries
+    static constexpr int toff(int s)
+    {
+        int o = 0;
+        for (int u = 0; u < s; ++u) o += (L.p[u] - 1) * L.m[u];
+        return o;
+    }
 };
 
 struct CtView { // one transform inside the padded batch image
@@ -380,12 +388,12 @@ struct CtView { // one transform inside the padded batch image
 // one radix-P butterfly on P contiguous register values: index k inside the sub-length m, twiddle stride fs
 // (the argument lists of fft_stage_butterfly_gk)
 template <int P, bool INV>
-__device__ __forceinline__ void fftct_bfly(float2 (&a)[P], const float2 *__restrict__ tw, int k, int fs, int m)
+__device__ __forceinline__ void fftct_bfly(float2 (&a)[P], const float2 *__restrict__ Ts, const float2 *__restrict__ tw, int k, int fs, int m)
 {
-    if constexpr (P == 2) bfly2(a[0], a[1], tw[k * fs]);
-    else if constexpr (P == 3) bfly3(a[0], a[1], a[2], tw[k * fs], tw[2 * k * fs], tw[fs * m]);
-    else if constexpr (P == 4) bfly4<INV>(a[0], a[1], a[2], a[3], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs]);
-    else bfly5(a[0], a[1], a[2], a[3], a[4], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs], tw[4 * k * fs], tw[fs * m], tw[fs * 2 * m]);
+    if constexpr (P == 2) bfly2(a[0], a[1], Ts[k]);
+    else if constexpr (P == 3) bfly3(a[0], a[1], a[2], Ts[k], Ts[m + k], tw[fs * m]);
+    else if constexpr (P == 4) bfly4<INV>(a[0], a[1], a[2], a[3], Ts[k], Ts[m + k], Ts[2 * m + k]);
+    else bfly5(a[0], a[1], a[2], a[3], a[4], Ts[k], Ts[m + k], Ts[2 * m + k], Ts[3 * m + k], tw[fs * m], tw[fs * 2 * m]);
 }
 
 template <int NTH>
@@ -396,7 +404,7 @@ __device__ __forceinline__ void fftct_sync()
 }
 
 template <int N, bool INV, int S, int NTH = 256, int EPTS = FftCt<N>::E>
-__device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restrict__ tw, int tid)
+__device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restrict__ tw, const float2 *__restrict__ T, int tid)
 {
     using F = FftCt<N>;
     if constexpr (S >= 0) {
@@ -418,7 +426,7 @@ __device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restric
                     float2 b[P];
 #pragma unroll
                     for (int i = 0; i < P; ++i) b[i] = a[q * P + i];
-                    fftct_bfly<P, INV>(b, tw, kk, FS, M);
+                    fftct_bfly<P, INV>(b, T + F::toff(S), tw, kk, FS, M);
 #pragma unroll
                     for (int i = 0; i < P; ++i) a[q * P + i] = b[i];
                 }
@@ -427,7 +435,7 @@ __device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restric
                     float2 b[PO];
 #pragma unroll
                     for (int i = 0; i < PO; ++i) b[i] = a[u + P * i];
-                    fftct_bfly<PO, INV>(b, tw, kk + u * M, FS2, P * M);
+                    fftct_bfly<PO, INV>(b, T + F::toff(S - 1), tw, kk + u * M, FS2, P * M);
 #pragma unroll
                     for (int i = 0; i < PO; ++i) a[u + P * i] = b[i];
                 }
@@ -435,16 +443,21 @@ __device__ __forceinline__ void fftct_stages(float2 *Ls, const float2 *__restric
                 for (int j = 0; j < G; ++j) Ls[F::phys(base + j * M)] = a[j];
             }
             fftct_sync<NTH>();
-            fftct_stages<N, INV, S - 2, NTH, EPTS>(Ls, tw, tid);
+            fftct_stages<N, INV, S - 2, NTH, EPTS>(Ls, tw, T, tid);
         } else {
-            constexpr FftStage st = {P, M, FS};
 #pragma unroll 1
             for (int bb = tid; bb < EPTS / P; bb += NTH) {
                 const int xf = bb / (N / P), b = bb % (N / P);
-                fft_stage_butterfly_gk<INV>(CtView{Ls, xf * N}, tw, st, b / M, b % M);
+                const int base = xf * N + (b / M) * P * M + (b % M);
+                float2 a[P];
+#pragma unroll
+                for (int j = 0; j < P; ++j) a[j] = Ls[F::phys(base + j * M)];
+                fftct_bfly<P, INV>(a, T + F::toff(S), tw, b % M, FS, M);
+#pragma unroll
+                for (int j = 0; j < P; ++j) Ls[F::phys(base + j * M)] = a[j];
             }
             fftct_sync<NTH>();
-            fftct_stages<N, INV, S - 1, NTH, EPTS>(Ls, tw, tid);
+            fftct_stages<N, INV, S - 1, NTH, EPTS>(Ls, tw, T, tid);
         }
     }
 }
@@ -458,7 +471,7 @@ struct FftCtW {
     static constexpr int LDS_W = (EW + (EW >> 3) + 8 + 1) & ~1; // float2 per wave
 };
 template <int N, bool INV>
-__global__ __launch_bounds__(256) void fft_ct_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch, long in_stride)
+__global__ __launch_bounds__(256) void fft_ct_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long nbatch, long in_stride)
 {
     using F = FftCt<N>;
     using W = FftCtW<N>;
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(256) void fft_ct_wave_kernel(const float2 *in, floa
         Ls[F::phys(xf * N + F::leaf_pos(n))] = in[b * in_stride + n];
     }
     wave_lds_fence();
-    fftct_stages<N, INV, F::L.n - 1, 64, W::EW>(Ls, tw, lane);
+    fftct_stages<N, INV, F::L.n - 1, 64, W::EW>(Ls, tw, T, lane);
 #pragma unroll 4
     for (int e = lane; e < W::EW; e += 64) {
         const int xf = e / N;
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(256) void fft_ct_wave_kernel(const float2 *in, floa
 }
 
 template <int N, bool INV>
-__global__ __launch_bounds__(256) void fft_ct_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch, long in_stride)
+__global__ __launch_bounds__(256) void fft_ct_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long nbatch, long in_stride)
 {
     using F = FftCt<N>;
     static_assert(F::supported(), "radices up to 5 only");
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(256) void fft_ct_kernel(const float2 *in, float2 *o
         Ls[F::phys(xf * N + F::leaf_pos(n))] = in[b * in_stride + n];
     }
     __syncthreads();
-    fftct_stages<N, INV, F::L.n - 1>(Ls, tw, tid);
+    fftct_stages<N, INV, F::L.n - 1>(Ls, tw, T, tid);
 #pragma unroll 4
     for (int e = tid; e < F::E; e += 256) {
         const int xf = e / N;
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(256) void fft_ct_kernel(const float2 *in, float2 *o
 // one transform per NTH-thread workgroup: 1281 ... 2048 points with 128 threads (two waves meet at the barriers instead of
 // four), more than 5120 points with 512 (more waves to hide the LDS round trips of a 50-70 KiB image)
 template <int N, bool INV, int NTH = 128>
-__global__ __launch_bounds__(NTH) void fft_ct_pair_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride)
+__global__ __launch_bounds__(NTH) void fft_ct_pair_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long in_stride)
 {
     using F = FftCt<N>;
     static_assert(F::supported(), "radices up to 5 only");
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(NTH) void fft_ct_pair_kernel(const float2 *in, floa
 #pragma unroll 4
     for (int n = tid; n < N; n += NTH) Ls[F::phys(F::leaf_pos(n))] = src[n];
     __syncthreads();
-    fftct_stages<N, INV, F::L.n - 1, NTH, N>(Ls, tw, tid);
+    fftct_stages<N, INV, F::L.n - 1, NTH, N>(Ls, tw, T, tid);
     float2 *dst = out + (long)blockIdx.x * N;
 #pragma unroll 4
     for (int n = tid; n < N; n += NTH) dst[n] = Ls[F::phys(n)];
@@ -532,7 +545,7 @@ static hipError_t launch_fft_ct(const FftPlanDev &p, const float2 *in, float2 *o
 {
     using F = FftCt<N>;
     // the compile-time list must be the plan's (it is the same algorithm; a mismatch would mean a different build)
-    if (p.nstages != F::L.n) return hipErrorNotSupported;
+    if (p.nstages != F::L.n || !p.tw_pass) return hipErrorNotSupported;
     for (int i = 0; i < F::L.n; ++i)
         if (p.st[i].p != F::L.p[i] || p.st[i].m != F::L.m[i] || p.st[i].fstride != F::L.fs[i]) return hipErrorNotSupported;
     // measured per size: one transform (or a few) per wave wins from 600 to 1280 points (+2 ... +21 %) and at 384 (+13 %);
@@ -548,13 +561,13 @@ static hipError_t launch_fft_ct(const FftPlanDev &p, const float2 *in, float2 *o
         }
         const long nwaves = (nbatch + W::TW - 1) / W::TW;
         const unsigned gridw = (unsigned)((nwaves + 3) / 4);
-        if (inv) hipLaunchKernelGGL(wi, dim3(gridw), dim3(256), ldsw, s, in, out, p.tw, nbatch, in_stride);
-        else hipLaunchKernelGGL(wf, dim3(gridw), dim3(256), ldsw, s, in, out, p.tw, nbatch, in_stride);
+        if (inv) hipLaunchKernelGGL(wi, dim3(gridw), dim3(256), ldsw, s, in, out, p.tw, p.tw_pass, nbatch, in_stride);
+        else hipLaunchKernelGGL(wf, dim3(gridw), dim3(256), ldsw, s, in, out, p.tw, p.tw_pass, nbatch, in_stride);
         return hipGetLastError();
     } else if constexpr (N > 1280 && N <= 2048) { // measured +9 ... +18 % over two transforms per 256-thread workgroup; slower above 2048
         const size_t ldsp = (size_t)(N + (N >> 3) + 8) * sizeof(float2);
-        if (inv) hipLaunchKernelGGL((fft_ct_pair_kernel<N, true>), dim3((unsigned)nbatch), dim3(128), ldsp, s, in, out, p.tw, in_stride);
-        else hipLaunchKernelGGL((fft_ct_pair_kernel<N, false>), dim3((unsigned)nbatch), dim3(128), ldsp, s, in, out, p.tw, in_stride);
+        if (inv) hipLaunchKernelGGL((fft_ct_pair_kernel<N, true>), dim3((unsigned)nbatch), dim3(128), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
+        else hipLaunchKernelGGL((fft_ct_pair_kernel<N, false>), dim3((unsigned)nbatch), dim3(128), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
         return hipGetLastError();
     } else if constexpr (N > 5120) { // eight waves on one transform: measured +10 ... +26 % over four (5120 itself is faster with four)
         const size_t ldsp = (size_t)(N + (N >> 3) + 8) * sizeof(float2);
@@ -562,8 +575,8 @@ static hipError_t launch_fft_ct(const FftPlanDev &p, const float2 *in, float2 *o
         auto ki5 = fft_ct_pair_kernel<N, true, 512>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki5 : kf5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         if (e != hipSuccess) return e;
-        if (inv) hipLaunchKernelGGL(ki5, dim3((unsigned)nbatch), dim3(512), ldsp, s, in, out, p.tw, in_stride);
-        else hipLaunchKernelGGL(kf5, dim3((unsigned)nbatch), dim3(512), ldsp, s, in, out, p.tw, in_stride);
+        if (inv) hipLaunchKernelGGL(ki5, dim3((unsigned)nbatch), dim3(512), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
+        else hipLaunchKernelGGL(kf5, dim3((unsigned)nbatch), dim3(512), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
         return hipGetLastError();
     } else {
         const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
@@ -574,8 +587,8 @@ static hipError_t launch_fft_ct(const FftPlanDev &p, const float2 *in, float2 *o
             if (e != hipSuccess) return e;
         }
         const unsigned grid = (unsigned)((nbatch + F::T - 1) / F::T);
-        if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
-        else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
+        if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, p.tw, p.tw_pass, nbatch, in_stride);
+        else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, p.tw, p.tw_pass, nbatch, in_stride);
         return hipGetLastError();
     }
 }
@@ -1048,10 +1061,6 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
 // leaves F_q[k], k = 1024 d5 + 256 d4 + 64 d3 + lane, in its registers.  The last kissfft stage (m = 4096) needs the four
 // F_q[k] of one k in one thread: four rounds (d3 = r) through a 32 KiB LDS image, after which thread (wave w, lane) owns
 // k = 1024 w + 256 d4 + 64 r + lane and stores X[k + 4096 rr] (512-byte runs).
-struct TwEvery4W {
-    const float2 *p;
-    __device__ __forceinline__ float2 operator[](unsigned i) const { return p[4u * i]; }
-};
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long in_stride)
 {

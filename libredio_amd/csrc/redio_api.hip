@@ -349,7 +349,24 @@ extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
     }
     p->dev.tw = p->d_tw;
     p->dev.tw_pass = nullptr;
-    if (const size_t ne = fftbig_tables_elems(nfft)) { // the multi-pass sizes read their twiddles in pass order
+    bool smooth = nfft <= 8192 && (nfft & (nfft - 1)) != 0; // radix-2/3/4/5 sizes that are not powers of two: the compile-time kernels
+    for (int i = 0; i < p->dev.nstages; ++i) smooth = smooth && p->dev.st[i].p <= 5;
+    if (smooth) { // stage-ordered copy, FftCt<N>::toff: stage s holds T[(n - 1) m + k] = tw[n k fstride]
+        std::vector<float2> ord;
+        for (int i = 0; i < p->dev.nstages; ++i) {
+            const FftStage &st = p->dev.st[i];
+            for (int n = 1; n < st.p; ++n)
+                for (int k = 0; k < st.m; ++k) ord.push_back(tw[(size_t)n * k * st.fstride]);
+        }
+        e = hipMalloc((void **)&p->d_tw_pass, ord.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(p->d_tw_pass, ord.data(), ord.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            hipFree(p->d_tw); hipFree(p->d_leaf); hipFree(p->d_leaf_pos); hipFree(p->d_tw_pass);
+            delete p;
+            return hip_rc(e);
+        }
+        p->dev.tw_pass = p->d_tw_pass;
+    } else if (const size_t ne = fftbig_tables_elems(nfft)) { // the multi-pass sizes read their twiddles in pass order
         e = hipMalloc((void **)&p->d_tw_pass, ne * sizeof(float2));
         if (e == hipSuccess) e = fftbig_tables_build(p->d_tw, p->d_tw_pass, nfft, nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
