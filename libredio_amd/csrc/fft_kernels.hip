@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, f
             const int jj = d4 + 4 * w;                 // d5 = w
             const unsigned k = 1024u * w + 256u * d4 + 64u * r + lane;
             float2 f0 = X[64 * jj + lane], f1 = X[1024 + 64 * jj + lane], f2 = X[2048 + 64 * jj + lane], f3 = X[3072 + 64 * jj + lane];
-            bfly4<INV>(f0, f1, f2, f3, tw[k], tw[2 * k], tw[3 * k]);
+            const TwOrdered lst = tw_ordered_stage(T, 1u, 6);
+            bfly4<INV>(f0, f1, f2, f3, lst.get(1, k), lst.get(2, k), lst.get(3, k));
             dst[k] = f0; dst[k + 4096] = f1; dst[k + 8192] = f2; dst[k + 12288] = f3;
         }
     }
@@ -1132,7 +1133,8 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
             float2 f[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = X[1024 * q + 256 * w + 64 * d3 + lane];
-            bfly4<false>(f[0], f[1], f[2], f[3], tw_f[k], tw_f[2 * k], tw_f[3 * k]);
+            const TwOrdered lst = tw_ordered_stage(Tf, 1u, 6);
+            bfly4<false>(f[0], f[1], f[2], f[3], lst.get(1, k), lst.get(2, k), lst.get(3, k));
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 Y[OV16W_YS * (lane & 3) + 64 * (rr + 4 * w) + 16 * d3 + (lane >> 2)] = cmul_rn(f[rr], Hc[k + 4096u * rr]);
@@ -1159,7 +1161,8 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
             float2 f[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = X[1024 * q + 64 * jj + lane_i];
-            bfly4<true>(f[0], f[1], f[2], f[3], tw_i[k], tw_i[2 * k], tw_i[3 * k]);
+            const TwOrdered lsti = tw_ordered_stage(Ti, 1u, 6);
+            bfly4<true>(f[0], f[1], f[2], f[3], lsti.get(1, k), lsti.get(2, k), lsti.get(3, k));
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 if ((long)(k + 4096u * rr) < hop) dst[k + 4096u * rr] = make_float2(mul_rn(f[rr].x, scale), mul_rn(f[rr].y, scale));
@@ -1291,7 +1294,8 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
             const int jj = d4 + 4 * w; // d5 = w
             const unsigned k = 512u * w + 128u * d4 + 64u * r + lane;
             float2 f0 = X[64 * jj + lane], f1 = X[1024 + 64 * jj + lane], f2 = X[2048 + 64 * jj + lane], f3 = X[3072 + 64 * jj + lane];
-            bfly4<INV>(f0, f1, f2, f3, tw[k], tw[2 * k], tw[3 * k]);
+            const TwOrdered lst = tw_ordered_stage(T, 2u, 5);
+            bfly4<INV>(f0, f1, f2, f3, lst.get(1, k), lst.get(2, k), lst.get(3, k));
             dst[k] = f0; dst[k + 2048] = f1; dst[k + 4096] = f2; dst[k + 6144] = f3;
         }
     }
@@ -1476,8 +1480,10 @@ static void fftbig_after_first(int lgN, int &lm, int &left)
 }
 size_t fftbig_tables_elems(int nfft)
 {
-    if (nfft == 4096 || nfft == 16384) return 4095; // the one-wave 4096-point program: stages of sub-length 1 ... 1024
-    if (nfft == 2048 || nfft == 8192) return 2046;  // the 2048-point program: sub-lengths 2 ... 512
+    if (nfft == 4096) return 4095;  // the one-wave 4096-point program: stages of sub-length 1 ... 1024
+    if (nfft == 16384) return 16383; // ... and the last stage across the four waves (sub-length 4096)
+    if (nfft == 2048) return 2046;  // the 2048-point program: sub-lengths 2 ... 512
+    if (nfft == 8192) return 8190;  // ... and the last stage (sub-length 2048)
     if (!fftbig_size(nfft)) return 0;
     const int lgN = __builtin_ctz((unsigned)nfft);
     int lm, left;
@@ -1491,7 +1497,7 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
 {
     if (nfft == 4096 || nfft == 16384 || nfft == 2048 || nfft == 8192) { // a quarter of 8192 / 16384 uses every fourth entry: the same values
         const bool p4 = nfft == 4096 || nfft == 16384;
-        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(16), dim3(256), 0, s, tw, tables, p4 ? 1u : 2u, p4 ? 6 : 5, (unsigned)nfft);
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(64), dim3(256), 0, s, tw, tables, p4 ? 1u : 2u, (p4 ? 6 : 5) + (nfft > 4096 ? 1 : 0), (unsigned)nfft);
         return hipGetLastError();
     }
     if (!fftbig_size(nfft)) return hipErrorInvalidValue;
