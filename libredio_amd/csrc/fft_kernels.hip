@@ -569,6 +569,15 @@ static hipError_t launch_fft_ct(const FftPlanDev &p, const float2 *in, float2 *o
         if (inv) hipLaunchKernelGGL((fft_ct_pair_kernel<N, true>), dim3((unsigned)nbatch), dim3(128), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
         else hipLaunchKernelGGL((fft_ct_pair_kernel<N, false>), dim3((unsigned)nbatch), dim3(128), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
         return hipGetLastError();
+    } else if constexpr (N > 8192) { // 8193 ... 16384 points: the image takes most of a CU's LDS; sixteen waves on it
+        const size_t ldsp = (size_t)(N + (N >> 3) + 8) * sizeof(float2);
+        auto kf10 = fft_ct_pair_kernel<N, false, 1024>;
+        auto ki10 = fft_ct_pair_kernel<N, true, 1024>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inv ? ki10 : kf10), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+        if (e != hipSuccess) return e;
+        if (inv) hipLaunchKernelGGL(ki10, dim3((unsigned)nbatch), dim3(1024), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
+        else hipLaunchKernelGGL(kf10, dim3((unsigned)nbatch), dim3(1024), ldsp, s, in, out, p.tw, p.tw_pass, in_stride);
+        return hipGetLastError();
     } else if constexpr (N > 5120) { // eight waves on one transform: measured +10 ... +26 % over four (5120 itself is faster with four)
         const size_t ldsp = (size_t)(N + (N >> 3) + 8) * sizeof(float2);
         auto kf5 = fft_ct_pair_kernel<N, false, 512>;
@@ -1653,6 +1662,11 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
             REDIO_CT(5000) REDIO_CT(5120) REDIO_CT(5184) REDIO_CT(5400) REDIO_CT(5625) REDIO_CT(5760) REDIO_CT(5832) REDIO_CT(6000)
             REDIO_CT(6075) REDIO_CT(6144) REDIO_CT(6250) REDIO_CT(6400) REDIO_CT(6480) REDIO_CT(6561) REDIO_CT(6750) REDIO_CT(6912)
             REDIO_CT(7200) REDIO_CT(7290) REDIO_CT(7500) REDIO_CT(7680) REDIO_CT(7776) REDIO_CT(8000) REDIO_CT(8100)
+            REDIO_CT(8640) REDIO_CT(8748) REDIO_CT(9000) REDIO_CT(9216) REDIO_CT(9375) REDIO_CT(9600) REDIO_CT(9720) REDIO_CT(10000)
+            REDIO_CT(10125) REDIO_CT(10240) REDIO_CT(10368) REDIO_CT(10800) REDIO_CT(10935) REDIO_CT(11250) REDIO_CT(11520) REDIO_CT(11664)
+            REDIO_CT(12000) REDIO_CT(12150) REDIO_CT(12288) REDIO_CT(12500) REDIO_CT(12800) REDIO_CT(12960) REDIO_CT(13122) REDIO_CT(13500)
+            REDIO_CT(13824) REDIO_CT(14400) REDIO_CT(14580) REDIO_CT(15000) REDIO_CT(15360) REDIO_CT(15552) REDIO_CT(15625) REDIO_CT(16000)
+            REDIO_CT(16200)
 #undef REDIO_CT
         default: break;
         }
