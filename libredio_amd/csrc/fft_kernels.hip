@@ -1275,6 +1275,47 @@ __global__ __launch_bounds__(256) void fft2k_wave_kernel(const float2 *in, float
         for (int j = 0; j < 16; ++j) (dst + 128 * (j & 3) + 512 * (j >> 2) + 64 * r)[(unsigned)lane] = b[r][j];
 }
 
+// overlap-save with 2048-point blocks, one wavefront per block (the 4096-point scheme): after the forward stages a lane holds
+// e = lane + 64 (slot + 2 d4 + 8 d5); as input of the inverse transform that is the same lane with d2 + 4 d1 + 16 b0 =
+// slot + 2 d4 + 8 d5, a renaming of registers.
+__global__ __launch_bounds__(256) void ovsave2k_wave_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ Tf,
+                                                            const float2 *__restrict__ Ti, const float2 *__restrict__ Hc,
+                                                            float2 *__restrict__ out, long nblk, float scale)
+{
+    __shared__ float2 Ls[4 * F4W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long blk = (long)blockIdx.x * 4 + w;
+    if (blk >= nblk) return; // wave-uniform
+    const float2 *src = x + blk * hop;
+    float2 *dst = out + blk * hop;
+    float2 *Lw = Ls + w * F4W_REGION;
+    float2 a[4][8], b[2][16];
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[d2][j] = (src + 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[(unsigned)lane];
+    RD_SCHED_BARRIER();
+    fft2k_wave_regs<false>(a, b, TwProgram<2048, 2>{Tf}, Lw, lane);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q5 = r + 2 * (j & 3) + 8 * (j >> 2); // position lane + 64 q5
+            a[q5 & 3][(q5 >> 4) + 2 * ((q5 >> 2) & 3)] = cmul_rn(b[r][j], (Hc + 64 * q5)[(unsigned)lane]);
+        }
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i)); // fresh twiddle offsets for the inverse
+    fft2k_wave_regs<true>(a, b, TwProgram<2048, 2>{Ti}, Lw, lane_i);
+    const long lim = hop - lane;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = 128 * (j & 3) + 512 * (j >> 2) + 64 * r;
+            if (e < lim) (dst + e)[(unsigned)lane] = make_float2(mul_rn(b[r][j].x, scale), mul_rn(b[r][j].y, scale));
+        }
+}
+
 // 8192: wave q runs the 2048-point program on x[4 n + q]; the last stage (m = 2048) across the waves, as in fft16k_wave_kernel
 template <bool INV>
 __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long in_stride)
@@ -1567,6 +1608,14 @@ hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *Tf, const fl
 {
     if (!Tf || !Ti) return hipErrorInvalidValue; // the plans' stage-ordered twiddle copies
     hipLaunchKernelGGL(ovsave4k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, Tf, Ti, Hc, out, nblk, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_ovsave2k(const float2 *x, long hop, const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s)
+{
+    if (!Tf || !Ti) return hipErrorInvalidValue; // the plans' stage-ordered twiddle copies
+    hipLaunchKernelGGL(ovsave2k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, Tf, Ti, Hc, out, nblk, scale);
     return hipGetLastError();
 }
 

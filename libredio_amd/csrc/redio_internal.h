@@ -37,6 +37,8 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
 // Tf / Ti (16384) are the plans' stage-ordered twiddle copies (redio_fft_twiddles_pass_dev)
 hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s);
+hipError_t launch_ovsave2k(const float2 *x, long hop, const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s); // 2048-point blocks, the same scheme
 hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s);
 hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Tf, const float2 *Ti, const float2 *Hc,

@@ -88,7 +88,7 @@ if "c5" in which or "c5only" in which:
         hop = 65536 - k + 1
         b = 8 * 65536 / hop + 8
         print(f"C5 overlap-save N=65536 K={k}: {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  {b*out.numel()/ms/1e6:.0f} GB/s algorithmic ({b*out.numel()/ms/1e6/8000:.1%})")
-    for nfft, k in (((1024, 127), (1024, 63), (4096, 127), (4096, 1025), (16384, 127), (16384, 4097)) if "c5" in which else ()):
+    for nfft, k in (((1024, 127), (1024, 63), (2048, 127), (2048, 513), (8192, 127), (32768, 127), (4096, 127), (4096, 1025), (16384, 127), (16384, 4097)) if "c5" in which else ()):
         taps = R.dsputils.lpf_corrected(k, 0.08)
         x = R.synth_iq(0x5EED0005, 0, n)
         plan = R.OverlapSave(taps, nfft)
