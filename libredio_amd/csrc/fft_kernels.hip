@@ -1522,6 +1522,81 @@ __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, fl
 }
 
 // the passes after the gather pass: rows 2^lm apart, `left` radix-4 stages to go
+// overlap-save with 8192-point blocks: four wavefronts, the ovsave16k scheme on the 2048-point program.  The forward last stage
+// runs in rounds over d5; thread (w, lane) of a round owns k = lane + 64 slot + 128 w + 512 r (slot = 0, 1), and sample
+// n = k + 2048 rr of the spectrum belongs to inverse wave n & 3 at position n >> 2 = lane' + 64 (d2' + 4 d1' + 16 b0') with
+// lane' = (lane >> 2) + 16 slot + 32 (w & 1), d2' = (w >> 1) + 2 (r & 1), d1' = (r >> 1) + 2 (rr & 1), b0' = rr >> 1.
+constexpr int OV8W_YS = 528; // stride of one inverse wave's image of a round (8 registers x 64 lanes, padded)
+__global__ __launch_bounds__(256) void ovsave8k_wave_kernel(const float2 *__restrict__ x, long hop, const float2 *__restrict__ Tf,
+                                                            const float2 *__restrict__ Ti, const float2 *__restrict__ Hc,
+                                                            float2 *__restrict__ out, float scale)
+{
+    __shared__ float2 Ls[4 * F4W_REGION];
+    static_assert(2048 + 4 * OV8W_YS <= 4 * F4W_REGION && 4096 <= 4 * F4W_REGION, "the shared images live where the private ones were");
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float2 *src = x + (long)blockIdx.x * hop + w;
+    float2 *dst = out + (long)blockIdx.x * hop;
+    float2 *X = Ls, *Y = Ls + 2048, *Lw = Ls + w * F4W_REGION;
+    float2 a[4][8], b[2][16];
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
+    RD_SCHED_BARRIER();
+    fft2k_wave_regs<false>(a, b, TwProgram<2048, 2>{Tf}, Lw, lane);
+    const TwOrdered lf = tw_ordered_stage(Tf, 2u, 5);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { // d5 = r
+        __syncthreads(); // private images / the previous round's images are no longer read
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot)
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) X[512 * w + 64 * (slot + 2 * d4) + lane] = b[slot][d4 + 4 * r];
+        __syncthreads();
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const unsigned k = lane + 64u * slot + 128u * w + 512u * r;
+            float2 f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = X[512 * q + 64 * (slot + 2 * w) + lane];
+            bfly4<false>(f[0], f[1], f[2], f[3], lf.get(1, k), lf.get(2, k), lf.get(3, k));
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                Y[OV8W_YS * (lane & 3) + 64 * ((w >> 1) + 2 * (rr & 1) + 4 * (rr >> 1)) + (lane >> 2) + 16 * slot + 32 * (w & 1)] =
+                    cmul_rn(f[rr], Hc[k + 2048u * rr]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) { // inverse sub-transform w: register d2' = (i8 & 1) + 2 (r & 1), d1' = (r >> 1) + 2 ((i8 >> 1) & 1), b0' = i8 >> 2
+            a[(i8 & 1) + 2 * (r & 1)][(i8 >> 2) + 2 * ((r >> 1) + 2 * ((i8 >> 1) & 1))] = Y[OV8W_YS * w + 64 * i8 + lane];
+        }
+    }
+    __syncthreads(); // the images are free again
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i)); // fresh twiddle offsets for the inverse
+    fft2k_wave_regs<true>(a, b, TwProgram<2048, 2>{Ti}, Lw, lane_i);
+    const TwOrdered li = tw_ordered_stage(Ti, 2u, 5);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { // slot = r, as in fft8k_wave_kernel
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[1024 * w + 64 * j + lane_i] = b[r][j];
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const int jj = d4 + 4 * w;
+            const unsigned k = 512u * w + 128u * d4 + 64u * r + lane_i;
+            float2 f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = X[1024 * q + 64 * jj + lane_i];
+            bfly4<true>(f[0], f[1], f[2], f[3], li.get(1, k), li.get(2, k), li.get(3, k));
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if ((long)(k + 2048u * rr) < hop) dst[k + 2048u * rr] = make_float2(mul_rn(f[rr].x, scale), mul_rn(f[rr].y, scale));
+        }
+    }
+}
+
 static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384; }
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
@@ -1616,6 +1691,14 @@ hipError_t launch_ovsave2k(const float2 *x, long hop, const float2 *Tf, const fl
 {
     if (!Tf || !Ti) return hipErrorInvalidValue; // the plans' stage-ordered twiddle copies
     hipLaunchKernelGGL(ovsave2k_wave_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, x, hop, Tf, Ti, Hc, out, nblk, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_ovsave8k(const float2 *x, long hop, const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s)
+{
+    if (!Tf || !Ti) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ovsave8k_wave_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, hop, Tf, Ti, Hc, out, scale);
     return hipGetLastError();
 }
 

@@ -130,6 +130,11 @@ extern "C" int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_
                                (float2 *)d_out, (long)nblk, scale, st));
         return REDIO_OK;
     }
+    if (h->nfft == 8192) {
+        OV_TRY(launch_ovsave8k((const float2 *)d_in, (long)h->hop, redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc,
+                               (float2 *)d_out, (long)nblk, scale, st));
+        return REDIO_OK;
+    }
     if (h->nfft == 4096) { // block load, both transforms, product, scale and store in one kernel (fft_kernels.hip)
         OV_TRY(launch_ovsave4k((const float2 *)d_in, (long)h->hop, redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc,
                                (float2 *)d_out, (long)nblk, scale, st));

@@ -39,6 +39,8 @@ hipError_t launch_ovsave1k(const float2 *x, long hop, const float2 *tw_f, const 
                            float scale, hipStream_t s);
 hipError_t launch_ovsave2k(const float2 *x, long hop, const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s); // 2048-point blocks, the same scheme
+hipError_t launch_ovsave8k(const float2 *x, long hop, const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk,
+                           float scale, hipStream_t s); // 8192-point blocks: four waves per block
 hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Hc, float2 *out, long nblk,
                            float scale, hipStream_t s);
 hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Tf, const float2 *Ti, const float2 *Hc,
