@@ -12,4 +12,4 @@ cd /tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_c5_fetch -- python3 $R/tools/bench_configs.py c5only > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p_c5_write -- python3 $R/tools/bench_configs.py c5only > /dev/null 2>&1
 cd $R
-for k in "fft64k_wave_kernel<false, 0>" ovsave64k_mid_wave ovsave64k_last_wave; do echo "== $k"; python3 profiles/pmc_summary.py "$k" gpurun_out/p_c5_fetch gpurun_out/p_c5_write; done
+for k in "fftbig_first_kernel<false>" ovsave64k_mid_wave ovsave64k_last_wave; do echo "== $k"; python3 profiles/pmc_summary.py "$k" gpurun_out/p_c5_fetch gpurun_out/p_c5_write; done
