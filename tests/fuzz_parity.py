@@ -35,8 +35,9 @@ while time.time() < t_end:
         want = O.fir(x[off:], taps, d, fused)
         check("fir", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, cplx, fused, n, off))
     elif which == 1:    # FFT, any size
-        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 17)), 3 * 2 ** int(rng.integers(0, 12)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 8)),
-                            int(rng.integers(3000, 70000))]))
+        smooth = lambda lim: int(min(2 ** int(rng.integers(0, 15)) * 3 ** int(rng.integers(0, 9)) * 5 ** int(rng.integers(0, 6)), lim))
+        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 21)), 3 * 2 ** int(rng.integers(0, 12)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 8)),
+                            smooth(16384), smooth(16384), int(rng.integers(3000, 70000))]))
         inv = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 70 if n < 4000 else 4))
         x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n * nb)
         d = torch.from_numpy(x).cuda()
