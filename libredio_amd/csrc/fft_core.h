@@ -525,18 +525,4 @@ RD_HD void f64k_macro_regs(float2 (&a)[16], TwPtr tw, int pass, int t, int kk, i
     }
 }
 
-// the same two stages on a tile in LDS: group grp (0..15) of column `col`.  Same butterflies and twiddles as two
-// calls of f64k_tile_butterfly per row.
-template <bool INV, typename Ptr, typename TwPtr>
-RD_HD void f64k_tile_macro(Ptr L, TwPtr tw, int pass, int t, int col, int grp, int k0)
-{
-    const int m = 1 << (2 * t);
-    const int blk = grp >> (2 * t), kk = grp & (m - 1);
-    const int base = blk * 16 * m + kk;
-    float2 a[16];
-    for (int j = 0; j < 16; ++j) a[j] = L[(base + j * m) * F64K_LD + col];
-    f64k_macro_regs<INV>(a, tw, pass, t, kk, k0);
-    for (int j = 0; j < 16; ++j) L[(base + j * m) * F64K_LD + col] = a[j];
-}
-
 } // namespace redio
