@@ -1597,6 +1597,147 @@ __global__ __launch_bounds__(256) void ovsave8k_wave_kernel(const float2 *__rest
     }
 }
 
+// ---- any radix-2/3/4/5 size above 16384: tile passes with a run-time stage list -------------------------------------
+// The same decomposition as the power-of-two passes, table-driven: the stages are cut (innermost first) into groups whose
+// radices multiply to G <= 256 rows; a 256-thread workgroup takes G rows x 16 neighbouring columns into LDS, runs the group's
+// stages down the columns and writes the tile back.  The first group gathers the digit-reversed input (rows N / G apart in the
+// source, 16 neighbouring source columns) and writes every column as one run of G positions of the working order; the later
+// groups work in place on rows m_lo apart.  One pass per group instead of one launch per stage.
+struct FtpMagic { unsigned ml[12]; unsigned g; }; // ceil(2^32 / d) of the group's sub-lengths in rows and of G: exact quotients of numbers below 2^16
+template <bool INV>
+__global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const float2 *src, float2 *dst, int s_hi, int s_lo, int G, int m_lo,
+                                                            int first, long in_stride, int tiles_per_xf, int lcw, FtpMagic mg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *L = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, N = p.nfft, CW = 1 << lcw, LD = CW + 1; // CW columns per tile (a power of two), padded rows
+    int *rowsrc = reinterpret_cast<int *>(L + G * LD), *hcol = rowsrc + G; // per-tile index tables (first pass)
+    const long xf = blockIdx.x / tiles_per_xf;
+    const int tt = blockIdx.x - (int)(xf * tiles_per_xf);
+    // columns of this tile: first pass: source columns r = CW tt + col (r < N / G); later: l = CW c + col of block h
+    const int ncolblk = first ? 0 : (m_lo + CW - 1) >> lcw;
+    const int c = first ? tt : tt % ncolblk, h = first ? 0 : tt / ncolblk;
+    const int width = first ? N / G : m_lo;
+    const int ncol = width - CW * c < CW ? width - CW * c : CW;
+    const float2 *in = first ? src + xf * in_stride : dst + xf * (long)N;
+    float2 *out = dst + xf * (long)N;
+    if (first) {
+        for (int g = tid; g < G; g += 256) { // row g of the working order = source row with the group's digits reversed
+            int rs = 0;
+            for (int s = s_hi; s >= s_lo; --s) rs += ((g / p.st[s].m) % p.st[s].p) * p.st[s].fstride;
+            rowsrc[g] = rs;
+        }
+        for (int col = tid; col < ncol; col += 256) { // source column r -> column of the working order (the outer stages' digits)
+            const int r = CW * c + col;
+            int hh = 0;
+            for (int s = s_lo - 1; s >= 0; --s) hh += ((r / p.st[s].fstride) % p.st[s].p) * (p.st[s].m / G);
+            hcol[col] = hh;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < G * CW; e += 256) {
+        const int g = e >> lcw, col = e & (CW - 1);
+        if (col >= ncol) continue;
+        const int idx = first ? rowsrc[g] + CW * c + col : h * G * m_lo + g * m_lo + CW * c + col;
+        L[g * LD + col] = in[idx];
+    }
+    __syncthreads();
+    for (int s = s_hi; s >= s_lo; --s) { // innermost stage of the group first
+        const int P = p.st[s].p, m = p.st[s].m, fs = p.st[s].fstride, ml = m / m_lo; // ml: sub-length in rows
+        const int nb = G / P;
+        for (int e = tid; e < nb * CW; e += 256) {
+            const int bf = e >> lcw, col = e & (CW - 1);
+            if (col >= ncol) continue;
+            const int blk = ml == 1 ? bf : (int)__umulhi((unsigned)bf, mg.ml[s_hi - s]), kl = bf - blk * ml;
+            const int row0 = blk * P * ml + kl;
+            const int k = (first ? 0 : CW * c + col) + m_lo * kl; // e mod m
+            float2 *q = L + row0 * LD + col;
+            const int rs = ml * LD;
+            if (P == 2) {
+                float2 a0 = q[0], a1 = q[rs];
+                bfly2(a0, a1, p.tw[k * fs]);
+                q[0] = a0; q[rs] = a1;
+            } else if (P == 3) {
+                float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs];
+                bfly3(a0, a1, a2, p.tw[k * fs], p.tw[2 * k * fs], p.tw[fs * m]);
+                q[0] = a0; q[rs] = a1; q[2 * rs] = a2;
+            } else if (P == 4) {
+                float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs];
+                bfly4<INV>(a0, a1, a2, a3, p.tw[k * fs], p.tw[2 * k * fs], p.tw[3 * k * fs]);
+                q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3;
+            } else {
+                float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs], a4 = q[4 * rs];
+                bfly5(a0, a1, a2, a3, a4, p.tw[k * fs], p.tw[2 * k * fs], p.tw[3 * k * fs], p.tw[4 * k * fs], p.tw[fs * m], p.tw[fs * 2 * m]);
+                q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3; q[4 * rs] = a4;
+            }
+        }
+        __syncthreads();
+    }
+    if (first) { // source column r -> column hh of the working order (the outer stages' digits), G contiguous positions each
+        for (int e = tid; e < G * CW; e += 256) {
+            const int col = (int)__umulhi((unsigned)e, mg.g), g = e - col * G;
+            if (col >= ncol) continue;
+            out[(long)hcol[col] * G + g] = L[g * LD + col];
+        }
+    } else {
+        for (int e = tid; e < G * CW; e += 256) {
+            const int g = e >> lcw, col = e & (CW - 1);
+            if (col >= ncol) continue;
+            out[h * G * m_lo + g * m_lo + CW * c + col] = L[g * LD + col];
+        }
+    }
+}
+
+// cut the stages (innermost first) into the fewest groups of at most 256 rows, then as evenly as that count allows
+static int fft_tile_groups(const FftPlanDev &p, int limit, int *lo_of /* [nstages]: s_lo of the group starting at s_hi */)
+{
+    int n = 0;
+    for (int s_hi = p.nstages - 1; s_hi >= 0; ++n) {
+        int G = 1, s_lo = s_hi + 1;
+        while (s_lo - 1 >= 0 && G * p.st[s_lo - 1].p <= limit) { --s_lo; G *= p.st[s_lo].p; }
+        if (s_lo > s_hi) return 1 << 20; // a single radix above the limit
+        if (lo_of) lo_of[s_hi] = s_lo;
+        s_hi = s_lo - 1;
+    }
+    return n;
+}
+template <bool INV>
+static hipError_t launch_fft_tile_passes(const FftPlanDev &p, const float2 *in, float2 *out, long nbatch, long in_stride, hipStream_t s)
+{
+    int lo_of[FFT_MAX_STAGES];
+    const int npass = fft_tile_groups(p, 256, nullptr);
+    int limit = 256;
+    for (int cand = 8; cand < 256; ++cand)
+        if (fft_tile_groups(p, cand, nullptr) == npass) { limit = cand; break; }
+    fft_tile_groups(p, limit, lo_of);
+    int m_lo = 1;
+    bool first = true;
+    for (int s_hi = p.nstages - 1; s_hi >= 0;) {
+        const int s_lo = lo_of[s_hi];
+        int G = 1;
+        for (int t = s_lo; t <= s_hi; ++t) G *= p.st[t].p;
+        int lcw = 4; // columns per tile: 16 ... 256, about 4096 points per tile
+        while (lcw < 8 && (G << (lcw + 1)) <= 4096) ++lcw;
+        const int CW = 1 << lcw, width = first ? p.nfft / G : m_lo;
+        const int colblk = (width + CW - 1) / CW;
+        const int tiles = first ? colblk : colblk * (p.nfft / (G * m_lo));
+        const size_t lds = (size_t)G * (CW + 1) * sizeof(float2) + (size_t)(G + CW) * sizeof(int);
+        FtpMagic mg = {};
+        if (s_hi - s_lo >= 12) return hipErrorNotSupported;
+        for (int t = s_hi; t >= s_lo; --t) {
+            const unsigned ml = (unsigned)(p.st[t].m / m_lo);
+            mg.ml[s_hi - t] = ml > 1 ? (unsigned)((0x100000000ull + ml - 1) / ml) : 0u;
+        }
+        mg.g = G > 1 ? (unsigned)((0x100000000ull + G - 1) / G) : 0u;
+        hipLaunchKernelGGL(fft_tile_pass_kernel<INV>, dim3((unsigned)(nbatch * tiles)), dim3(256), lds, s, p, in, out, s_hi, s_lo, G, m_lo,
+                           first ? 1 : 0, in_stride, tiles, lcw, mg);
+        m_lo *= G;
+        s_hi = s_lo - 1;
+        first = false;
+    }
+    return hipGetLastError();
+}
+
 static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384; }
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
@@ -1843,6 +1984,11 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         const int lgN = __builtin_ctz((unsigned)p.nfft);
         return inv ? launch_fftbig<true>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s)
                    : launch_fftbig<false>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s);
+    }
+    if (!generic && p.nfft > 16384) { // radix-2/3/4/5 sizes that are not powers of two: one pass per group of stages
+        if (in == out) return hipErrorNotSupported; // the first pass is a global transposition: the C-ABI layer stages in-place calls
+        if (nbatch * (long)((p.nfft + 15) / 16) > 0x7fffffffl) return hipErrorInvalidValue;
+        return inv ? launch_fft_tile_passes<true>(p, in, out, nbatch, in_stride, s) : launch_fft_tile_passes<false>(p, in, out, nbatch, in_stride, s);
     }
     // global-memory stages.  The C-ABI layer routes in-place calls through a temporary and supplies `work`
     // (nbatch * nfft elements) when a generic-radix stage needs an out-of-place step.

@@ -165,6 +165,23 @@ def test_fft_large_global_path(gpu, redio, oracle, n):
     assert same_bits(d.cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("n", [16875, 17280, 18000, 20000, 30000, 48000, 50000, 65610, 78125, 100000, 196608, 250000, 1000000, 1594323])
+def test_fft_large_mixed_radix_tile_passes(gpu, redio, oracle, n):
+    # radix-2/3/4/5 sizes above 16384 that are not powers of two: one LDS tile pass per group of stages (fft_tile_pass_kernel)
+    nb = 3 if n < 100000 else 1
+    x = oracle.synth_iq(n & 0xFFFF, 0, n * nb)
+    d = gpu.from_numpy(x).cuda()
+    for inverse in (False, True):
+        assert same_bits(redio.Fft(n, inverse)(d).cpu().numpy(), oracle.fft(x, n, inverse)), (n, inverse)
+    want = oracle.fft(x, n, False)
+    redio.Fft(n, False)(d, out=d)  # in place: staged by the C-ABI layer
+    assert same_bits(d.cpu().numpy(), want)
+    if n <= 50000:  # strided blocks
+        xs = oracle.synth_iq(n + 1, 0, n + 2 * (n - 7))
+        got = redio.Fft(n, False).strided(gpu.from_numpy(xs).cuda(), 3, n - 7).cpu().numpy()
+        assert same_bits(got, np.concatenate([oracle.fft(xs[b * (n - 7): b * (n - 7) + n], n, False) for b in range(3)]))
+
+
 @pytest.mark.parametrize("n", [1 << 21, 1 << 22, 1 << 23, 1 << 24])
 def test_fft_multi_pass_powers_of_four(gpu, redio, oracle, n):
     # 2 * 4^10, 4^11, 2 * 4^11, 4^12: gather pass, in-place four-stage passes, register-only last stages (fft_kernels.hip, fftbig_*)
