@@ -1645,6 +1645,9 @@ __global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const 
     for (int s = s_hi; s >= s_lo; --s) { // innermost stage of the group first
         const int P = p.st[s].p, m = p.st[s].m, fs = p.st[s].fstride, ml = m / m_lo; // ml: sub-length in rows
         const int nb = G / P;
+        int toff = 0; // the stage's block of the stage-ordered twiddle copy: T[(n - 1) m + k] = tw[n k fstride]
+        for (int u = 0; u < s; ++u) toff += (p.st[u].p - 1) * p.st[u].m;
+        const float2 *__restrict__ T = p.tw_pass + toff;
         for (int e = tid; e < nb * CW; e += 256) {
             const int bf = e >> lcw, col = e & (CW - 1);
             if (col >= ncol) continue;
@@ -1655,19 +1658,19 @@ __global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const 
             const int rs = ml * LD;
             if (P == 2) {
                 float2 a0 = q[0], a1 = q[rs];
-                bfly2(a0, a1, p.tw[k * fs]);
+                bfly2(a0, a1, T[k]);
                 q[0] = a0; q[rs] = a1;
             } else if (P == 3) {
                 float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs];
-                bfly3(a0, a1, a2, p.tw[k * fs], p.tw[2 * k * fs], p.tw[fs * m]);
+                bfly3(a0, a1, a2, T[k], T[m + k], p.tw[fs * m]);
                 q[0] = a0; q[rs] = a1; q[2 * rs] = a2;
             } else if (P == 4) {
                 float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs];
-                bfly4<INV>(a0, a1, a2, a3, p.tw[k * fs], p.tw[2 * k * fs], p.tw[3 * k * fs]);
+                bfly4<INV>(a0, a1, a2, a3, T[k], T[m + k], T[2 * m + k]);
                 q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3;
             } else {
                 float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs], a4 = q[4 * rs];
-                bfly5(a0, a1, a2, a3, a4, p.tw[k * fs], p.tw[2 * k * fs], p.tw[3 * k * fs], p.tw[4 * k * fs], p.tw[fs * m], p.tw[fs * 2 * m]);
+                bfly5(a0, a1, a2, a3, a4, T[k], T[m + k], T[2 * m + k], T[3 * m + k], p.tw[fs * m], p.tw[fs * 2 * m]);
                 q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3; q[4 * rs] = a4;
             }
         }
@@ -1985,7 +1988,7 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         return inv ? launch_fftbig<true>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s)
                    : launch_fftbig<false>(in, out, p.tw, p.tw_pass, nbatch, in_stride, lgN, s);
     }
-    if (!generic && p.nfft > 16384) { // radix-2/3/4/5 sizes that are not powers of two: one pass per group of stages
+    if (!generic && p.nfft > 16384 && p.tw_pass) { // radix-2/3/4/5 sizes that are not powers of two: one pass per group of stages
         if (in == out) return hipErrorNotSupported; // the first pass is a global transposition: the C-ABI layer stages in-place calls
         if (nbatch * (long)((p.nfft + 15) / 16) > 0x7fffffffl) return hipErrorInvalidValue;
         return inv ? launch_fft_tile_passes<true>(p, in, out, nbatch, in_stride, s) : launch_fft_tile_passes<false>(p, in, out, nbatch, in_stride, s);

@@ -349,7 +349,7 @@ extern "C" int redio_fft_create(redio_fft **h, int nfft, int inverse)
     }
     p->dev.tw = p->d_tw;
     p->dev.tw_pass = nullptr;
-    bool smooth = nfft < 16384 && (nfft & (nfft - 1)) != 0; // radix-2/3/4/5 sizes that are not powers of two: the compile-time kernels
+    bool smooth = (nfft & (nfft - 1)) != 0; // every radix-2/3/4/5 size that is not a power of two (compile-time kernels, tile passes)
     for (int i = 0; i < p->dev.nstages; ++i) smooth = smooth && p->dev.st[i].p <= 5;
     if (smooth) { // stage-ordered copy, FftCt<N>::toff: stage s holds T[(n - 1) m + k] = tw[n k fstride]
         std::vector<float2> ord;
