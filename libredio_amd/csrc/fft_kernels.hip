@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
 }
 
 // ---- N = 16384 = 4 x 4096: four wavefronts, one sub-transform each, last stage across them -------------------
-// Wave q runs the one-wave 4096-point program on x[4 n + q] (its twiddles are every fourth entry of the table), which
+// Wave q runs the one-wave 4096-point program on x[4 n + q] (its twiddles are every fourth entry of the table, read from the stage-ordered copy T), which
 // leaves F_q[k], k = 1024 d5 + 256 d4 + 64 d3 + lane, in its registers.  The last kissfft stage (m = 4096) needs the four
 // F_q[k] of one k in one thread: four rounds (d3 = r) through a 32 KiB LDS image, after which thread (wave w, lane) owns
 // k = 1024 w + 256 d4 + 64 r + lane and stores X[k + 4096 rr] (512-byte runs).
