@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
 // with sub-length m: (e mod m) * N / (4 m), exactly kissfft's k * fstride.
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
-                                                           long ntiles, int L)
+                                                           long ntiles, int L, const float2 *__restrict__ mulH = nullptr)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1379,6 +1379,18 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src]; // source row rev4(16 (4i + q) + j)
+    if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
+        const float2 *hsrc = mulH + 16 * c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 hv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hv[j] = (hsrc + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src];
+            RD_SCHED_BARRIER();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[i][j] = cmul_rn(a[i][j], hv[j]);
+        }
+    }
     RD_SCHED_BARRIER();
 #pragma unroll
     for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], TwGather{tw, N >> 2}, TwGather{tw, N >> 4}, 0u, 1u, 0u, 1u);
@@ -1397,7 +1409,8 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
 }
 
 template <bool INV>
-__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ T, long ntiles, int lgN, int lm)
+__global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ T, long ntiles, int lgN, int lm, float2 *__restrict__ vout = nullptr,
+                                                         long hop = 0, float scale = 1.0f)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1426,12 +1439,18 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) (base + (long)m_lo * (4 * x + 16 * j))[lo_st] = b[x][j]; // row q + 4x + 16j
+        for (int j = 0; j < 16; ++j) {
+            if (vout) { // overlap-save: this was the last pass; 1/N and only the hop valid outputs, packed
+                const long e = (long)h * 256 * m_lo + (long)m_lo * (q + 4 * x + 16 * j) + l;
+                if (e < hop) vout[xf * hop + e] = make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale));
+            } else (base + (long)m_lo * (4 * x + 16 * j))[lo_st] = b[x][j]; // row q + 4x + 16j
+        }
 }
 
 // the last LG = 1, 2 or 3 stages: G = 4^LG rows, m_lo = N / G apart; a wave takes 4096 / G neighbouring columns
 template <bool INV, int LG>
-__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, const float2 *__restrict__ T, long ntiles, int lgN)
+__global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const float2 *__restrict__ tw, const float2 *__restrict__ T, long ntiles, int lgN,
+                                                          float2 *__restrict__ vout = nullptr, long hop = 0, float scale = 1.0f)
 {
     constexpr int G = 1 << (2 * LG), CPT = 4096 / G; // rows, columns per tile
     constexpr int GG = G < 16 ? G : 16, NG = G / GG; // row g = 16 d2 + j lives in a[.][d2][j]
@@ -1473,7 +1492,13 @@ __global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const
 #pragma unroll
     for (int i = 0; i < CPT / 64; ++i)
 #pragma unroll
-        for (int g = 0; g < G; ++g) uniform_ptr(base + (long)m_lo * g + 64 * i)[(unsigned)lane] = a[i][g / GG][g % GG];
+        for (int g = 0; g < G; ++g) {
+            if (vout) { // overlap-save: 1/N and only the hop valid outputs, packed
+                const long e = (long)m_lo * g + l0 + 64 * i + lane;
+                const float2 v = a[i][g / GG][g % GG];
+                if (e < hop) vout[xf * hop + e] = make_float2(mul_rn(v.x, scale), mul_rn(v.y, scale));
+            } else uniform_ptr(base + (long)m_lo * g + 64 * i)[(unsigned)lane] = a[i][g / GG][g % GG];
+        }
 }
 
 // N = 2 * 4^L (32768 ... 8388608): kissfft runs the radix-2 stage first.  The gather pass takes the three stages on
@@ -1482,7 +1507,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_last_kernel(float2 *data, const
 // stages that remain go through fftbig_mid_kernel / fftbig_last_kernel with rows 32, 8192, ... apart.
 template <bool INV>
 __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
-                                                            long ntiles, int lgN)
+                                                            long ntiles, int lgN, const float2 *__restrict__ mulH = nullptr)
 {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = (long)blockIdx.x * 4 + w;
@@ -1498,6 +1523,12 @@ __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, fl
     for (int d2 = 0; d2 < 4; ++d2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[d2][j] = (src + (long)S * (16 * (j & 1) + 4 * (j >> 1) + d2))[(unsigned)lane];
+    if (mulH) { // overlap-save: the spectrum product on the way in
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[d2][j] = cmul_rn(a[d2][j], (mulH + 64 * c + (long)S * (16 * (j & 1) + 4 * (j >> 1) + d2))[(unsigned)lane]);
+    }
     const float2 w0 = tw[0u], w1 = tw[N >> 3], w2 = tw[2 * (N >> 3)], w3 = tw[3 * (N >> 3)];
     RD_SCHED_BARRIER();
 #pragma unroll
@@ -1782,32 +1813,49 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
     return hipGetLastError();
 }
 
+// mulH: multiply the input by this spectrum on the way into the first pass; vout: the last pass stores 1/N-scaled outputs
+// below hop, packed per block, there instead of in `out` (the two overlap-save steps that would otherwise be passes of their own)
 template <bool INV>
 static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, const float2 *tables, long nbatch, long in_stride, int lgN,
-                                hipStream_t s)
+                                hipStream_t s, const float2 *mulH = nullptr, float2 *vout = nullptr, long hop = 0, float scale = 1.0f)
 {
     const long ntiles = nbatch << (lgN - 12);
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
     if (lgN & 1) {
         const long nt2 = nbatch << (lgN - 11);
-        hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN);
+        hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN, mulH);
     } else {
-        hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2);
+        hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH);
     }
     int lm, left;
     fftbig_after_first(lgN, lm, left);
     const float2 *T = tables;
     for (; left >= 4; lm += 8, left -= 4) {
-        hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T, ntiles, lgN, lm);
+        float2 *vo = left == 4 ? vout : nullptr; // the last pass of all
+        hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T, ntiles, lgN, lm, vo, hop, scale);
         T += (size_t)255 << lm;
     }
     switch (left) {
     case 0: break;
-    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN); break;
-    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN); break;
-    default: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN); break;
+    case 1: hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN, vout, hop, scale); break;
+    case 2: hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN, vout, hop, scale); break;
+    default: hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN, vout, hop, scale); break;
     }
     return hipGetLastError();
+}
+
+// overlap-save with a block size of the multi-pass family (32768, 131072 ...; 65536 has the three-pass scheme below): forward
+// transform of the hop-strided blocks into `a`, then the inverse from `a` through `b` with the spectrum product folded into its
+// first pass and the scaled copy of the valid outputs into its last -- six passes instead of eight
+bool ovsave_big_size(int nfft) { return fftbig_size(nfft) && nfft != F64K_N; }
+hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const float2 *x, long hop, float2 *a, float2 *b, const float2 *Hc,
+                             float2 *out, long nblk, float scale, hipStream_t s)
+{
+    if (!ovsave_big_size(fw.nfft) || fw.nfft != bw.nfft || !fw.tw_pass || !bw.tw_pass) return hipErrorInvalidValue;
+    const int lgN = __builtin_ctz((unsigned)fw.nfft);
+    hipError_t e = launch_fftbig<false>(x, a, fw.tw, fw.tw_pass, nblk, hop, lgN, s);
+    if (e != hipSuccess) return e;
+    return launch_fftbig<true>(a, b, bw.tw, bw.tw_pass, nblk, (long)fw.nfft, lgN, s, Hc, out, hop, scale);
 }
 
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,

@@ -154,6 +154,11 @@ extern "C" int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_
                                     redio_fft_twiddles_dev(h->bw), redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc, (float2 *)d_out + b0 * h->hop, (long)nb, scale, st));
             continue;
         }
+        if (ovsave_big_size(h->nfft)) { // the product and the scaled copy ride on the inverse transform's first and last pass
+            OV_TRY(launch_ovsave_big(*redio_fft_plan_dev(h->fw), *redio_fft_plan_dev(h->bw), (const float2 *)d_in + b0 * h->hop, (long)h->hop, h->d_a,
+                                     h->d_b, h->d_Hc, (float2 *)d_out + b0 * h->hop, (long)nb, scale, st));
+            continue;
+        }
         int rc = redio_fft_enqueue_strided(h->fw, (const float2 *)d_in + b0 * h->hop, h->d_a, nb, (long)h->hop, st);
         if (rc) return rc;
         hipLaunchKernelGGL(ovsave_mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h->d_a, h->d_Hc, total, h->nfft);

@@ -439,6 +439,7 @@ extern "C" int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d
     return hip_rc(e);
 }
 
+const FftPlanDev *redio_fft_plan_dev(const redio_fft *h) { return h ? &h->dev : nullptr; }
 const float2 *redio_fft_twiddles_dev(const redio_fft *h) { return h ? h->dev.tw : nullptr; }
 const float2 *redio_fft_twiddles_pass_dev(const redio_fft *h) { return h ? h->dev.tw_pass : nullptr; }
 

@@ -58,9 +58,14 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
 hipError_t launch_synth_iq(float2 *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
 hipError_t launch_synth_f32(float *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
 
+// overlap-save with a block size of the multi-pass transform family (32768, 131072 ...): six passes
+bool ovsave_big_size(int nfft);
+hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const float2 *x, long hop, float2 *a, float2 *b, const float2 *Hc,
+                             float2 *out, long nblk, float scale, hipStream_t s);
 } // namespace redio
 
 // redio_api.hip: the device twiddle table behind a public FFT handle (library-internal)
 struct redio_fft;
+const redio::FftPlanDev *redio_fft_plan_dev(const redio_fft *h);
 const float2 *redio_fft_twiddles_dev(const redio_fft *h);
 const float2 *redio_fft_twiddles_pass_dev(const redio_fft *h); // the pass-ordered copy (multi-pass sizes), else null
