@@ -184,6 +184,21 @@ __global__ __launch_bounds__(256) void fft64_kernel(const float2 *in, float2 *ou
     }
 }
 
+// the one-wave programs (2048 and 4096 points, also as the quarters of 8192 and 16384) read their twiddles from a
+// stage-ordered copy of the table: the stage with sub-length m = NS / (4 fs) starts at m - ML (ML = 1 for 4096 = 4^6,
+// 2 for 2048 = 2 * 4^5) and holds T[(n - 1) m + k] = tw[n k fs] (fftbig_tables_build), so that lanes with neighbouring k
+// read neighbouring entries (in table order the 64 twiddles of a wave's stage-4 load are spread over 16 to 64 cache lines)
+template <int NS, int ML>
+struct TwProgram { const float2 *T; };
+template <int NS, int ML>
+__device__ __forceinline__ float2 tw_get(TwProgram<NS, ML> p, unsigned k, unsigned fs, unsigned n)
+{
+    const unsigned m = NS / (4 * fs);
+    return p.T[(m - ML) + (n - 1) * m + k];
+}
+template <typename TwPtr>
+__device__ __forceinline__ float2 tw_get(TwPtr tw, unsigned k, unsigned fs, unsigned n) { return tw[n * k * fs]; }
+
 // ---- small powers of two and N = 2 * 4^L up to 512 (2, 4, 8, 16, 32, 128, 512; 2048 and 8192 have their own kernels below): compile-time stages in LDS
 // kissfft factors 2 * 4^L as 4, 4, ..., 4, 2 with the radix-2 stage innermost.  One 256-thread workgroup
 // handles 4096 points (8192 for the largest size): max(1, 4096 / N) transforms.  Coalesced load with the
@@ -209,8 +224,8 @@ struct FftP2 {
     }
 };
 
-template <int LOG2N, bool INV, int M>
-__device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict__ tw, int tid)
+template <int LOG2N, bool INV, int M, typename TwPtr>
+__device__ __forceinline__ void fftp2_rest(float2 *Ls, TwPtr tw, int tid)
 {
     using F = FftP2<LOG2N>;
     constexpr int N = F::N, E = F::E;
@@ -224,13 +239,13 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict_
             float2 a[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) a[j] = Ls[F::phys(base + j * M)];
-            const float2 t1 = tw[kk * FS], t2 = tw[2 * kk * FS], t3 = tw[3 * kk * FS];
+            const float2 t1 = tw_get(tw, (unsigned)kk, (unsigned)FS, 1), t2 = tw_get(tw, (unsigned)kk, (unsigned)FS, 2), t3 = tw_get(tw, (unsigned)kk, (unsigned)FS, 3);
 #pragma unroll
             for (int q = 0; q < 4; ++q) bfly4<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k2 = kk + u * M;
-                bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw[k2 * FS2], tw[2 * k2 * FS2], tw[3 * k2 * FS2]);
+                bfly4<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tw_get(tw, (unsigned)k2, (unsigned)FS2, 1), tw_get(tw, (unsigned)k2, (unsigned)FS2, 2), tw_get(tw, (unsigned)k2, (unsigned)FS2, 3));
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) Ls[F::phys(base + j * M)] = a[j];
@@ -245,7 +260,7 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict_
             const int blk = gl / M, kk = gl % M;
             const int base = xf * N + blk * 4 * M + kk;
             float2 a0 = Ls[F::phys(base)], a1 = Ls[F::phys(base + M)], a2 = Ls[F::phys(base + 2 * M)], a3 = Ls[F::phys(base + 3 * M)];
-            bfly4<INV>(a0, a1, a2, a3, tw[kk * FS], tw[2 * kk * FS], tw[3 * kk * FS]);
+            bfly4<INV>(a0, a1, a2, a3, tw_get(tw, (unsigned)kk, (unsigned)FS, 1), tw_get(tw, (unsigned)kk, (unsigned)FS, 2), tw_get(tw, (unsigned)kk, (unsigned)FS, 3));
             Ls[F::phys(base)] = a0; Ls[F::phys(base + M)] = a1; Ls[F::phys(base + 2 * M)] = a2; Ls[F::phys(base + 3 * M)] = a3;
         }
         __syncthreads();
@@ -253,7 +268,8 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, const float2 *__restrict_
 }
 
 template <int LOG2N, bool INV>
-__global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long nbatch, long in_stride)
+__global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ Tord,
+                                                     long nbatch, long in_stride)
 {
     using F = FftP2<LOG2N>;
     constexpr int N = F::N, E = F::E, T = F::T;
@@ -294,7 +310,8 @@ __global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *o
             for (int j = 0; j < 8; ++j) Ls[F::phys(8 * g + j)] = a[j];
         }
         __syncthreads();
-        fftp2_rest<LOG2N, INV, 8>(Ls, tw, tid);
+        if constexpr (LOG2N == 9) fftp2_rest<LOG2N, INV, 8>(Ls, TwProgram<512, 2>{Tord}, tid); // 512: the stage-ordered copy (+6 %; nothing below)
+        else fftp2_rest<LOG2N, INV, 8>(Ls, tw, tid);
     }
 #pragma unroll 4
     for (int e = tid; e < E; e += 256) {
@@ -304,7 +321,8 @@ __global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *o
 }
 
 template <int LOG2N>
-static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw, long nbatch, long in_stride, bool inv, hipStream_t s)
+static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw, const float2 *Tord, long nbatch, long in_stride, bool inv,
+                                hipStream_t s)
 {
     using F = FftP2<LOG2N>;
     const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
@@ -315,8 +333,9 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
         if (e != hipSuccess) return e;
     }
     const unsigned grid = (unsigned)((nbatch + F::T - 1) / F::T);
-    if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, tw, nbatch, in_stride);
-    else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, tw, nbatch, in_stride);
+    if (LOG2N == 9 && !Tord) return hipErrorInvalidValue;
+    if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, tw, Tord, nbatch, in_stride);
+    else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, tw, Tord, nbatch, in_stride);
     return hipGetLastError();
 }
 
@@ -715,21 +734,6 @@ __global__ __launch_bounds__(256) void fft_global_generic_stage_kernel(FftPlanDe
 // tw[n (kB + u step) fsB].  The 15 values are loaded as one batch (behind a scheduling barrier where the caller wants the
 // next group's batch in flight during the current group's arithmetic); the compiler otherwise sinks each load to its use.
 struct FftTw15 { float2 t[15]; };
-// the one-wave programs (2048 and 4096 points, also as the quarters of 8192 and 16384) read their twiddles from a
-// stage-ordered copy of the table: the stage with sub-length m = NS / (4 fs) starts at m - ML (ML = 1 for 4096 = 4^6,
-// 2 for 2048 = 2 * 4^5) and holds T[(n - 1) m + k] = tw[n k fs] (fftbig_tables_build), so that lanes with neighbouring k
-// read neighbouring entries (in table order the 64 twiddles of a wave's stage-4 load are spread over 16 to 64 cache lines)
-template <int NS, int ML>
-struct TwProgram { const float2 *T; };
-template <int NS, int ML>
-__device__ __forceinline__ float2 tw_get(TwProgram<NS, ML> p, unsigned k, unsigned fs, unsigned n)
-{
-    const unsigned m = NS / (4 * fs);
-    return p.T[(m - ML) + (n - 1) * m + k];
-}
-template <typename TwPtr>
-__device__ __forceinline__ float2 tw_get(TwPtr tw, unsigned k, unsigned fs, unsigned n) { return tw[n * k * fs]; }
-
 template <typename TwPtr>
 __device__ __forceinline__ void tw15_load(FftTw15 &T, TwPtr tw, unsigned kA, unsigned fsA, unsigned kB, unsigned step, unsigned fsB)
 {
@@ -1782,6 +1786,7 @@ size_t fftbig_tables_elems(int nfft)
 {
     if (nfft == 4096) return 4095;  // the one-wave 4096-point program: stages of sub-length 1 ... 1024
     if (nfft == 16384) return 16383; // ... and the last stage across the four waves (sub-length 4096)
+    if (nfft == 512) return 510;    // fft_p2_kernel<9>: sub-lengths 2 ... 128
     if (nfft == 2048) return 2046;  // the 2048-point program: sub-lengths 2 ... 512
     if (nfft == 8192) return 8190;  // ... and the last stage (sub-length 2048)
     if (!fftbig_size(nfft)) return 0;
@@ -1795,6 +1800,10 @@ size_t fftbig_tables_elems(int nfft)
 }
 hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s)
 {
+    if (nfft == 512) {
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2), dim3(256), 0, s, tw, tables, 2u, 4, 512u);
+        return hipGetLastError();
+    }
     if (nfft == 4096 || nfft == 16384 || nfft == 2048 || nfft == 8192) { // a quarter of 8192 / 16384 uses every fourth entry: the same values
         const bool p4 = nfft == 4096 || nfft == 16384;
         hipLaunchKernelGGL(fftbig_tables_kernel, dim3(64), dim3(256), 0, s, tw, tables, p4 ? 1u : 2u, (p4 ? 6 : 5) + (nfft > 4096 ? 1 : 0), (unsigned)nfft);
@@ -1915,13 +1924,13 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
         return hipGetLastError();
     }
     switch (p.nfft) { // 2 * 4^L, and the two powers of four below 64
-    case 2: return launch_fft_p2<1>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 4: return launch_fft_p2<2>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 8: return launch_fft_p2<3>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 16: return launch_fft_p2<4>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 32: return launch_fft_p2<5>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 128: return launch_fft_p2<7>(in, out, p.tw, nbatch, in_stride, inv, s);
-    case 512: return launch_fft_p2<9>(in, out, p.tw, nbatch, in_stride, inv, s);
+    case 2: return launch_fft_p2<1>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
+    case 4: return launch_fft_p2<2>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
+    case 8: return launch_fft_p2<3>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
+    case 16: return launch_fft_p2<4>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
+    case 32: return launch_fft_p2<5>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
+    case 128: return launch_fft_p2<7>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
+    case 512: return launch_fft_p2<9>(in, out, p.tw, p.tw_pass, nbatch, in_stride, inv, s);
     case 2048: {
         const unsigned grid = (unsigned)((nbatch + 3) / 4);
         if (!p.tw_pass) return hipErrorInvalidValue;
