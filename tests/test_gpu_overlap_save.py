@@ -11,7 +11,7 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-@pytest.mark.parametrize("nfft,k", [(1024, 127), (1024, 1), (1024, 1024), (1024, 500), (2048, 127), (2048, 1), (2048, 2048), (2048, 700), (8192, 127), (8192, 1), (8192, 8192), (8192, 3000), (32768, 1000), (32768, 32768), (131072, 127), (262144, 40000), (524288, 1), (4096, 63), (4096, 1025), (4096, 4096), (4096, 1), (16384, 127), (16384, 8193), (16384, 16384), (65536, 8193), (65536, 127), (256, 256), (64, 1)])
+@pytest.mark.parametrize("nfft,k", [(1024, 127), (1024, 1), (1024, 1024), (1024, 500), (2048, 127), (2048, 1), (2048, 2048), (2048, 700), (8192, 127), (8192, 1), (8192, 8192), (8192, 3000), (32768, 1000), (32768, 32768), (131072, 127), (262144, 40000), (524288, 1), (2097152, 127), (4096, 63), (4096, 1025), (4096, 4096), (4096, 1), (16384, 127), (16384, 8193), (16384, 16384), (65536, 8193), (65536, 127), (256, 256), (64, 1)])
 def test_overlap_save_bit_exact_and_close_to_direct(gpu, redio, oracle, nfft, k):
     taps = oracle.lpf_corrected(k, 0.02) if k > 1 else np.array([0.75], np.float32)
     hop = nfft - k + 1
