@@ -10,10 +10,15 @@ per GPU (torch.distributed.run); the stream is time-sliced, every rank owns its 
 (with the 126-sample FIR halo inside the slice), there is no data-path collective, and value is the
 samples of all ranks over the slowest rank's time ("weak" scaling).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant (only) kernel, chain_fir_fft1k_kernel:
-algorithmic bytes = 9.6 B per input sample (8 B read + 8/5 B written) over the kernel's
-mean duration measured with HIP events on the launch stream.  `cpu_baseline` is the CPU oracle
-(oracle/, a port of the reference's algorithm) timed on this host on a bounded prefix.
+Rank 0 prints ONE JSON line.  `value` is exactly what the flags time (W warm-up launches, then K launches between
+two barriers).  `roofline` is for the dominant (only) kernel, chain_v4_kernel: algorithmic bytes = 9.6 B per input
+sample (8 B read + 8/5 B written) over the kernel's mean duration in the timed region, measured with HIP
+events on the launch stream; `launch_ms_series` are those per-launch times.  The chip raises its clock over the first
+~100 launches of a burst, so after the headline the same launch is repeated `--steady` more times (default 300) and
+reported as `steady_state` with its own kernel time and fraction -- never as `value`.  `roofline.traffic` comes from
+the rocprofv3 PMC passes of a separate run (`traffic_source`).  `cpu_baseline` is the CPU oracle (oracle/, a port of
+the reference's algorithm) timed on this host on a bounded sample: all cores as independent replicas (`value`), one
+core, and the reference's own structure -- a thread per block with a heap Vec per message (`kpn_pipeline`).
 """
 import argparse
 import ctypes as C
@@ -34,17 +39,17 @@ SEED = 0x5EED0002                         # 0x5EED0000 + config id (SURVEY.md 8d
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steady", type=int, default=300, help="further launches after the timed region, reported as steady_state (0 = skip)")
     ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (default 2^28 = 2 GiB)")
     ap.add_argument("--unfused", action="store_true", help="run FIR and FFT as two kernels (12.8 B/sample)")
     ap.add_argument("--exact", action="store_true", help="reference rounding (mul+add) instead of fmaf in the FIR")
-    ap.add_argument("--variant", type=int, default=0, help="fused kernel generation (0 = current, 1 = first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=23, help="slice per CPU thread")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
     return ap.parse_args()
 
 
@@ -96,10 +101,18 @@ def cpu_baseline(log2n, min_seconds=12.0):
             t.join()
         wall = time.perf_counter() - t0
         total = sum(done)
+    # the reference's own structure: one thread per block, one heap Vec per message, queue hand-off
+    kdone, kmsgs, kwall = O.kpn_chain_baseline(min_seconds / 2, 22, SEED, taps, DECIM, NFFT)
     return {"value": total / wall / 1e6, "unit": "MSamples/s", "cores": cores, "kind": "port",
             "sample": f"{total} samples in {wall:.1f} s: {cores} threads (one per host core), each looping over its own 2^{log2n}-sample "
                       f"slice of the same hash-generated stream through the oracle/ C port (scalar strict-order FIR + kissfft "
-                      f"restatement, gcc -O2, no FMA); one thread alone: {single:.1f} MSamples/s"}
+                      f"restatement, gcc -O2, no FMA); one thread alone: {single:.1f} MSamples/s",
+            "single_core": {"value": single, "unit": "MSamples/s", "cores": 1},
+            "kpn_pipeline": {"value": kdone / kwall / 1e6, "unit": "MSamples/s", "cores": 4, "block_threads": 3,
+                             "sample": f"{kmsgs} messages ({kdone} input samples) in {kwall:.1f} s through source -> [fir 127 taps, keep every "
+                                       f"5th] -> [kiss_fft 1024] -> sink, one OS thread per block, one heap Vec per message, mutex/condvar "
+                                       f"queues (oracle/kpn_baseline.cpp; the structure of src/kissfft/src/kissfft.rs:18-31 and "
+                                       f"src/ratpak.rs:60-185), CPU restatement of the reference"}}
 
 
 def main():
@@ -135,7 +148,6 @@ def main():
     chain = R.Chain(taps, DECIM, NFFT, fused=not a.exact)
     if a.unfused:
         chain.set_unfused(True)
-    chain.set_variant(a.variant)
     nblk = chain.nblocks(n)
     used = nblk * NFFT * DECIM  # input samples that contribute to a spectrum
     # rank r owns the slice that starts at decimated block r*nblk of the global stream (sharding.weak_slice)
@@ -180,10 +192,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # outside the timed region: the same launch repeated --steady more times, per-launch HIP events again
+    steady = None
+    if a.steady > 0:
+        sev = []
+        for _ in range(a.steady + 1):
+            e = C.c_void_p()
+            R.check(lib.redio_event_create(C.byref(e)))
+            sev.append(e)
+        R.check(lib.redio_event_record(sev[0], stream))
+        for k in range(a.steady):
+            chain(x, out)
+            R.check(lib.redio_event_record(sev[k + 1], stream))
+        torch.cuda.synchronize()
+        sms = []
+        for k in range(a.steady):
+            ms = C.c_float()
+            R.check(lib.redio_event_elapsed_ms(sev[k], sev[k + 1], C.byref(ms)))
+            sms.append(ms.value)
+        for e in sev:
+            lib.redio_event_destroy(e)
+        tail = sorted(sms[len(sms) // 3:])          # the last two thirds: past the clock ramp
+        steady = {"launches": a.steady, "after_launches": a.warmup + a.steps,
+                  "kernel_ms_mean": sum(tail) / len(tail), "kernel_ms_median": tail[len(tail) // 2], "kernel_ms_min": tail[0],
+                  "series_every_10th_ms": [round(v, 4) for v in sms[::10]]}
+
     # outside the timed region: the same launch with the reference's rounding (multiply and add rounded
     # separately, dsputils.rs:31) so that both arithmetic modes are on record from one run
     ref_ms = None
-    if not a.exact and not a.unfused and a.variant == 0:
+    if not a.exact and not a.unfused:
         ref_chain = R.Chain(taps, DECIM, NFFT, fused=False)
         e0, e1 = C.c_void_p(), C.c_void_p()
         R.check(lib.redio_event_create(C.byref(e0)))
@@ -205,9 +242,11 @@ def main():
         kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
         ach = alg_bytes / kavg / 1e9
-        traffic = None
-        if a.traffic_json and os.path.exists(a.traffic_json) and a.variant == 0 and not a.unfused and a.log2_samples == 28:
+        traffic, traffic_source = None, None
+        if a.traffic_json and os.path.exists(a.traffic_json) and not a.unfused and a.log2_samples == 28:
             traffic = json.load(open(a.traffic_json)).get("traffic")
+            traffic_source = (os.path.relpath(a.traffic_json, ROOT) + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of a "
+                              "separate run of this command (FETCH_SIZE doubled, the gfx950 correction); not measured by this run")
         rec = {
             "metric": "MSamples/s through FIR+FFT+resample chain",
             "value": world * used * a.steps / dt / 1e6,
@@ -220,14 +259,22 @@ def main():
                                    "(input samples/s; the 5:1 resample step is the polyphase decimation of the FIR: only every "
                                    "fifth FIR output is computed, then consecutive 1024-sample blocks are transformed)",
                        "samples_per_gpu": n, "ntaps": NTAPS, "decim": DECIM, "nfft": NFFT,
-                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else {0: "chain_v4_kernel (fused, wave per block run, halo carried in LDS)", 1: "chain_fir_fft1k_kernel (fused, v1)", 2: "chain_v2_kernel (fused, v2)", 6: "chain_v3_kernel (fused, v3)", 7: "chain_v5_kernel (fused, dynamic queue)"}.get(a.variant, f"fused kernel tuning {a.variant}"),
+                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else "chain_v4_kernel (fused, wave per block run, halo carried in LDS)",
                        "fir_rounding": "mul+add (reference)" if a.exact else "fmaf, reference order",
                        "parallelism": f"time-sliced replicas x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": kavg * 1e3,
                          "frac_of_measured_copy_6290": ach / 6290.0},
+            "launch_ms_series": [round(v, 4) for v in (kms if len(kms) <= 128 else kms[:32] + kms[32::max(1, len(kms) // 96)])],
         }
+        if steady is not None:
+            sk = steady["kernel_ms_mean"] * 1e-3
+            steady.update({"achieved": alg_bytes / sk / 1e9, "unit": "GB/s", "frac": alg_bytes / sk / 1e9 / HBM_PEAK_GBS,
+                           "value_per_gpu": used / sk / 1e6, "value_unit": "MSamples/s",
+                           "note": "the same launch repeated after the timed region (mean of the last two thirds): what the kernel "
+                                   "sustains once the clock transient of a burst is over; reported beside value, never as value"})
+            rec["steady_state"] = steady
         if ref_ms is not None:
             rec["reference_rounding"] = {"kernel_ms": ref_ms, "value_per_gpu": used / ref_ms / 1e3, "unit": "MSamples/s",
                                          "frac": alg_bytes / (ref_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -171,7 +171,10 @@ std::pair<Sender<T>, Receiver<T>> bounded_channel(size_t capacity)
     return {Sender<T>(c), Receiver<T>(c)};
 }
 
-// one named thread per block (src/ratpak.rs:60-185); a hang-up ends the block quietly
+// one named thread per block (src/ratpak.rs:60-185); a hang-up ends the block quietly.  Any other
+// exception a block throws (an assert of the reference: eat/binconv overrun, a wrong fft message size,
+// a converter error, a HIP failure under a kpn::dev block ...) is the reference's panic of THAT task only:
+// the text goes to stderr, the block's endpoints drop with the closure and the hang-up cascades downstream.
 template <typename F>
 std::thread spawn(F &&f)
 {
@@ -179,6 +182,10 @@ std::thread spawn(F &&f)
         try {
             fn();
         } catch (const hangup &) {
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "kpn: block panicked: %s\n", e.what());
+        } catch (...) {
+            std::fprintf(stderr, "kpn: block panicked (unknown exception)\n");
         }
     });
 }

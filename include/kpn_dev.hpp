@@ -179,7 +179,7 @@ inline void ingest_mag(Receiver<View<uint8_t>> u, Sender<View<float>> v)
     }
 }
 
-// kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231) with the constant vector resident on the device
+// kpn::mul_vecs / sum_vecs (kpn.rs:198-203, 227-231) with the constant vector resident on the device
 namespace detail {
 inline int zip_call(bool add, const float *a, const float *b, float *o, size_t n, void *st) { return add ? redio_add_f32(a, b, o, n, st) : redio_mul_f32(a, b, o, n, st); }
 inline int zip_call(bool add, const std::complex<float> *a, const std::complex<float> *b, std::complex<float> *o, size_t n, void *st)

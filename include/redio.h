@@ -9,8 +9,11 @@
  *       (redio_convolve_f32 for dsputils::convolve; kiss_fft.h / samplerate.h for the C symbols the
  *       reference's Rust already binds);
  *   (2) device-resident plans (redio_fir_*, redio_fft_*, redio_chain_*, ...) that take device
- *       pointers and a HIP stream, allocate nothing and never synchronise inside *_enqueue, so a
- *       graph of blocks can keep its streams in HBM.  Throughput numbers use (2).
+ *       pointers and a HIP stream and only launch kernels inside *_enqueue, so a graph of blocks can keep
+ *       its streams in HBM.  Throughput numbers use (2).  Scratch: the few paths that need a plan-owned
+ *       intermediate (the two-kernel chain, staged FFT sizes) size it with the plan's *_reserve(); an
+ *       un-reserved plan grows it on first use (an allocation) and refuses to do so while the stream is
+ *       being captured (REDIO_ERR_NOT_RESERVED).  Everything else never allocates or synchronises.
  *
  * Every function returns REDIO_OK (0) or a negative redio error / positive HIP error code mapped by
  * redio_strerror(); nothing aborts or panics (the reference's unwrap()/assert!/panic! sites become
@@ -34,6 +37,8 @@ enum {
     REDIO_ERR_UNSUPPORTED = -3, /* shape has no kernel (documented per function) */
     REDIO_ERR_NO_DEVICE = -4,   /* no HIP device: the product path never falls back to the CPU */
     REDIO_ERR_ASSERT = -5,      /* an assert!() of the reference would have fired (e.g. fc >= 0.5) */
+    REDIO_ERR_NOT_RESERVED = -6, /* a plan would have to allocate scratch while its stream is being captured */
+    REDIO_ERR_COMM = -7,        /* RCCL: librccl.so not loadable, or a communicator call failed */
     REDIO_ERR_HIP_BASE = -1000  /* -(1000 + hipError_t) */
 };
 const char *redio_strerror(int code);
@@ -109,6 +114,8 @@ typedef struct redio_fft redio_fft;
 int redio_fft_create(redio_fft **h, int nfft, int inverse);
 int redio_fft_destroy(redio_fft *h);
 int redio_fft_enqueue(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, void *stream);
+/* staging for the sizes that need it (in-place calls of the multi-launch path, prime factors above 5 beyond LDS) */
+int redio_fft_reserve(redio_fft *h, size_t nbatch);
 /* messages that start every in_stride samples (overlapping blocks when in_stride < nfft); no aliasing */
 int redio_fft_enqueue_strided(redio_fft *h, const void *d_in, void *d_out, size_t nbatch, long in_stride, void *stream);
 
@@ -124,9 +131,13 @@ size_t redio_chain_nblocks(const redio_chain *h, size_t n_in);
 int redio_chain_is_fused(const redio_chain *h);
 /* force the two-kernel path (for measurement): 0 = fused when available, 1 = never fused */
 int redio_chain_set_unfused(redio_chain *h, int unfused);
-/* kernel generation of the fused path, for A/B measurement: 0 = current (default), 1 = first, 2 = second */
-int redio_chain_set_variant(redio_chain *h, int variant);
+/* sizes the two-kernel path's intermediate for inputs of up to n_in samples, so that enqueue never allocates */
+int redio_chain_reserve(redio_chain *h, size_t n_in);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
+/* diagnostic, per plan: while d_buf (4 x u64 per wave of the launch, device memory) is set, the fused kernel of THIS
+ * plan writes {shader cycles, 100 MHz ticks, start tick, XCC/HW id} per wave into it (tools/clock_probe.py reads the
+ * clock the chip holds from it).  NULL (default) turns it off.  Timings of stamped launches are never quoted. */
+int redio_chain_set_debug_stamps(redio_chain *h, void *d_buf);
 
 /* ---- A9: the bit-exact ingest / slicing path of the shipped graph (src/ratpak.rs:60-76) ----
  * All device-resident; results are bit-identical to the reference arithmetic (oracle_bits.c). */
@@ -145,7 +156,9 @@ int redio_block_sums(const void *d_in_f32, size_t nblocks, size_t block, void *d
 int redio_discretize(const void *d_in_f32, size_t n, void *d_out_u8, void *d_scratch_u32, void *stream);
 /* bitfount::trigger, src/bitfount/src/bitfount.rs:36-85: state persists across calls; feeds nblocks
  * blocks of `block` f32 magnitudes; emitted buffers are appended to d_out with their lengths in
- * lens[] (host).  Synchronous (the adaptive threshold is a scalar recurrence run on the host). */
+ * lens[] (host).  Synchronous (the adaptive threshold is a scalar recurrence run on the host).
+ * If the buffers this call would emit do not fit (more than lens_cap of them, or more than out_cap
+ * floats) nothing is consumed: REDIO_ERR_ARG with the needed counts in *nemit / *total, retry larger. */
 typedef struct redio_trigger redio_trigger;
 int redio_trigger_create(redio_trigger **h);
 int redio_trigger_destroy(redio_trigger *h);
@@ -199,6 +212,50 @@ int redio_pfb_create(redio_pfb **h, const float *proto_taps_host, int nchan, int
 int redio_pfb_destroy(redio_pfb *h);
 size_t redio_pfb_nrows(const redio_pfb *h, size_t n_in);
 int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, int ngroups, void *stream);
+/* scratch of the two-pass shapes for inputs of up to n_in samples (the fused 64-channel kernel needs none) */
+int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups);
+
+/* ---- carried history: the windowed plans above as STREAMS (BASELINE.json configs[1] "history carried") ----
+ * redio_fir_enqueue & co. are stateless per call, like dsputils::convolve (dsputils.rs:30-32), which loses ntaps-1
+ * outputs at every message seam.  A *_stream handle sits on a plan (not owned: destroy the stream first) and keeps the
+ * stream's unconsumed tail (fewer samples than one window) on the device, so that feeding a stream in ANY pieces gives
+ * exactly the bits of one stateless call on the whole stream:
+ *     fir:    y[i] = fold_j x[decim*i + j]*taps[j] for every i whose window has arrived (decimation phase 0 at stream start)
+ *     chain:  spectrum b from decimated samples [b*nfft, (b+1)*nfft) of that y
+ *     pfb:    row t from input rows t .. t+taps_per_branch-1 (layout [row][nchan] only)
+ *     ovsave: block b -> hop outputs, blocks every hop samples from the stream start
+ * enqueue() writes *nout (= redio_*_stream_nout(h, n_new), known before the call) output samples to d_out; the new
+ * samples are read in place (only a seam of fewer than one window is staged through a plan-owned buffer).  It only
+ * launches kernels and small device copies; host-side counters advance at call time, so feed one stream from one
+ * thread in order.  Not graph-capturable (the split changes from call to call).  pending() = samples carried. */
+typedef struct redio_fir_stream redio_fir_stream;
+int redio_fir_stream_create(redio_fir_stream **h, redio_fir *plan);
+int redio_fir_stream_destroy(redio_fir_stream *h);
+int redio_fir_stream_reset(redio_fir_stream *h);
+size_t redio_fir_stream_nout(const redio_fir_stream *h, size_t n_new);
+size_t redio_fir_stream_pending(const redio_fir_stream *h);
+int redio_fir_stream_enqueue(redio_fir_stream *h, const void *d_new, size_t n_new, void *d_out, size_t *nout, void *stream);
+typedef struct redio_chain_stream redio_chain_stream;
+int redio_chain_stream_create(redio_chain_stream **h, redio_chain *plan);
+int redio_chain_stream_destroy(redio_chain_stream *h);
+int redio_chain_stream_reset(redio_chain_stream *h);
+size_t redio_chain_stream_nout(const redio_chain_stream *h, size_t n_new);
+size_t redio_chain_stream_pending(const redio_chain_stream *h);
+int redio_chain_stream_enqueue(redio_chain_stream *h, const void *d_new, size_t n_new, void *d_out, size_t *nout, void *stream);
+typedef struct redio_pfb_stream redio_pfb_stream;
+int redio_pfb_stream_create(redio_pfb_stream **h, redio_pfb *plan);
+int redio_pfb_stream_destroy(redio_pfb_stream *h);
+int redio_pfb_stream_reset(redio_pfb_stream *h);
+size_t redio_pfb_stream_nout(const redio_pfb_stream *h, size_t n_new);
+size_t redio_pfb_stream_pending(const redio_pfb_stream *h);
+int redio_pfb_stream_enqueue(redio_pfb_stream *h, const void *d_new, size_t n_new, void *d_out, size_t *nout, void *stream);
+typedef struct redio_ovsave_stream redio_ovsave_stream;
+int redio_ovsave_stream_create(redio_ovsave_stream **h, redio_ovsave *plan);
+int redio_ovsave_stream_destroy(redio_ovsave_stream *h);
+int redio_ovsave_stream_reset(redio_ovsave_stream *h);
+size_t redio_ovsave_stream_nout(const redio_ovsave_stream *h, size_t n_new);
+size_t redio_ovsave_stream_pending(const redio_ovsave_stream *h);
+int redio_ovsave_stream_enqueue(redio_ovsave_stream *h, const void *d_new, size_t n_new, void *d_out, size_t *nout, void *stream);
 
 /* ---- A6: samplerate::resample's native side, src/samplerate/src/samplerate.rs:59-87 ----
  * nchan independent mono streams that share ratio and block lengths (the reference creates one
@@ -243,7 +300,7 @@ int redio_src_process_host(redio_src *h, const float *data_in, long input_frames
 /* the coefficient table of a converter (coeffs_out may be NULL; it holds half_len + 2 floats) */
 int redio_src_table(int converter, float *coeffs_out, int *half_len, int *increment);
 
-/* ---- kpn vector maps on device: mul_vecs (src/kpn/src/kpn.rs:254-258) and sum_vecs (:227-231) ----
+/* ---- kpn vector maps on device: mul_vecs (src/kpn/src/kpn.rs:198-203) and sum_vecs (:227-231) ----
  * out[i] = a[i] * b[i] / a[i] + b[i] for i < n (the caller passes n = min of the two lengths, as zip does);
  * f32 and Complex<f32> ((ar*br - ai*bi, ar*bi + ai*br), every operation rounded on its own). */
 int redio_mul_f32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);

@@ -91,7 +91,17 @@ def lib():
     _sig(L.redio_chain_nblocks, sz, vp, sz)
     _sig(L.redio_chain_is_fused, i, vp)
     _sig(L.redio_chain_set_unfused, i, vp, i)
-    _sig(L.redio_chain_set_variant, i, vp, i)
+    _sig(L.redio_chain_reserve, i, vp, sz)
+    _sig(L.redio_chain_set_debug_stamps, i, vp, vp)
+    _sig(L.redio_fft_reserve, i, vp, sz)
+    _sig(L.redio_pfb_reserve, i, vp, sz, i)
+    for n in ("fir", "chain", "pfb", "ovsave"):
+        _sig(getattr(L, f"redio_{n}_stream_create"), i, C.POINTER(vp), vp)
+        _sig(getattr(L, f"redio_{n}_stream_destroy"), i, vp)
+        _sig(getattr(L, f"redio_{n}_stream_reset"), i, vp)
+        _sig(getattr(L, f"redio_{n}_stream_nout"), sz, vp, sz)
+        _sig(getattr(L, f"redio_{n}_stream_pending"), sz, vp)
+        _sig(getattr(L, f"redio_{n}_stream_enqueue"), i, vp, vp, sz, vp, C.POINTER(sz), vp)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
     pl = C.POINTER(C.c_long)
     _sig(L.redio_graph_begin, i, vp)
@@ -189,4 +199,4 @@ def check(code, what="redio"):
 
 
 from . import bitfount, dsputils, kissfft, kpn_dev, plans, samplerate  # noqa: E402,F401
-from .plans import Chain, Channelizer, Fft, Fir, Graph, OverlapSave, Src, channelizer_all_to_all, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from .plans import Chain, Channelizer, Fft, Fir, Graph, OverlapSave, Src, Stream, channelizer_all_to_all, current_stream, synth_f32, synth_iq  # noqa: E402,F401

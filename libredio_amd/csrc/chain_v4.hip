@@ -1,10 +1,10 @@
-// chain_v4.hip -- the north-star chain kernel, generation 4: chain_v3's wave-per-block structure
-// (chain_kernels.hip) with two changes to the data movement:
-//   * a wave owns a CONTIGUOUS range of blocks, so consecutive sub-tiles are consecutive in the stream;
+// chain_v4.hip -- the north-star chain kernel: one wavefront per run of consecutive 1024-sample decimated blocks.
+//   * a wave owns a CONTIGUOUS range of blocks, so consecutive sub-tiles (256 outputs) are consecutive in the stream;
 //   * the 122-sample FIR halo that two consecutive sub-tiles share is carried over inside the CU
 //     (one 16-byte LDS read + write per lane) instead of being fetched again: per sub-tile exactly
-//     640 x 16 B = 10 loads per lane of NEW samples.  v3 re-read 8.7 % of its input through L2.
-// Arithmetic, layouts and results are identical to v3 (bit-exact with the oracle).
+//     640 x 16 B = 10 loads per lane of NEW samples;
+//   * the FIR results stay in registers in the operand layout of the one-wave 1024-point transform.
+// Bit-exact with the oracle (FIR fold order of dsputils.rs:30-32, kissfft butterfly order).
 #include "fir_core.h"
 #include "fft_wave.h"
 #include "redio_internal.h"
@@ -128,16 +128,19 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     }
 }
 
+// CU count of the device the calling thread is bound to (kept per device: a process may drive several GPUs)
 static int num_cus_v4()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[dev] = n > 0 ? n : 256;
     }
-    return cus;
+    return cus[dev];
 }
 
 template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false>
@@ -163,11 +166,9 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     return hipGetLastError();
 }
 
-hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, int wps,
+hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                            hipStream_t s, unsigned long long *dbg)
 {
-    if (wps == 3) return launch_v4_t<127, 5, 3, 6>(x, taps, tw, out, nblocks, fused, s, dbg);
-    if (wps == 12) return launch_v4_t<127, 5, 2, 8, false, false>(x, taps, tw, out, nblocks, fused, s, dbg); // twiddles reloaded per block (A/B)
     return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg); // last-stage twiddles resident
 }
 

@@ -1,5 +1,5 @@
 // elementwise.hip -- the vector maps of the kpn plumbing on device:
-//   kpn::mul_vecs  src/kpn/src/kpn.rs:254-258   out[i] = x[i] * c[i]   (zip: the shorter length wins)
+//   kpn::mul_vecs  src/kpn/src/kpn.rs:198-203   out[i] = x[i] * c[i]   (zip: the shorter length wins)
 //   kpn::sum_vecs  src/kpn/src/kpn.rs:227-231   out[i] = x[i] + c[i]
 // for f32 and for Complex<f32> (num 0.1.22: (ar*br - ai*bi, ar*bi + ai*br), every operation rounded on
 // its own -- Rust never contracts).  HBM-bound: 3 words moved per word produced.

@@ -393,6 +393,24 @@ extern "C" int redio_trigger_feed(redio_trigger *t, const void *d_blocks, size_t
     const long trigger_duration = 50;  // :41
     const size_t block_size = 512;     // :38 (only in the OOM bound)
     size_t nemit = 0, total = 0;
+    { // dry run of the scalar recurrence on a copy of the state: what this call would emit.  A result that does not
+      // fit is refused BEFORE anything is consumed (the sums are recomputed by the retry), as redio_rle_feed does.
+        long trig = t->trigger; float thr = t->threshold; size_t len = t->len, ne = 0, tot = 0;
+        for (size_t b = 0; b < nblocks; ++b) {
+            trig -= 1;
+            if (len > 1000 * (size_t)trigger_duration * block_size) len = 1;
+            if (thr == 0.0f) thr = s[b];
+            if (trig < 0) { thr += s[b] / 1000.0f; thr -= thr * 0.002f; }
+            if (s[b] > thr * 4.0f) trig = trigger_duration;
+            if (trig > 1) len += block;
+            if (trig == 0) { tot += len; ++ne; len = 0; }
+        }
+        if (ne > lens_cap || tot > out_cap || (ne && (!d_out || !lens))) {
+            if (nemit_out) *nemit_out = ne;   // the capacities a retry needs
+            if (total_out) *total_out = tot;
+            return REDIO_ERR_ARG;
+        }
+    }
     std::vector<long> src, dst; // pending pushes into the device sample_buffer since the last flush
     auto flush = [&]() -> int {
         if (src.empty()) return REDIO_OK;
@@ -430,10 +448,8 @@ extern "C" int redio_trigger_feed(redio_trigger *t, const void *d_blocks, size_t
         }
         if (t->trigger == 0) {                                         // :78-81
             rc = flush(); if (rc) return rc;
-            if (nemit < lens_cap && total + t->len <= out_cap && d_out) {
-                IN_TRY(hipMemcpyAsync((float *)d_out + total, t->d_buf, t->len * sizeof(float), hipMemcpyDeviceToDevice, st));
-                lens[nemit] = t->len;
-            }
+            if (t->len) IN_TRY(hipMemcpyAsync((float *)d_out + total, t->d_buf, t->len * sizeof(float), hipMemcpyDeviceToDevice, st));
+            lens[nemit] = t->len; // fits: checked by the dry run above
             total += t->len;
             ++nemit;
             t->len = 0;

@@ -64,28 +64,36 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     if (!p) return REDIO_ERR_NOMEM;
     p->device = dev; p->nfft = nfft; p->ntaps = ntaps; p->hop = (size_t)nfft - ntaps + 1;
     p->fw = p->bw = nullptr; p->d_Hc = p->d_a = p->d_b = nullptr;
-    // work buffers: about 64 MiB each, at least one block
+    // work buffers, only for the block sizes whose passes go through memory (the one-kernel sizes keep a block in
+    // registers / LDS): about 64 MiB each, at least one block
+    const bool one_kernel = nfft == 1024 || nfft == 2048 || nfft == 4096 || nfft == 8192 || nfft == 16384;
     p->chunk_blocks = (size_t)(64u << 20) / ((size_t)nfft * sizeof(float2)); // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
     if (p->chunk_blocks < 1) p->chunk_blocks = 1;
     int rc = redio_fft_create(&p->fw, nfft, 0);
     if (rc == REDIO_OK) rc = redio_fft_create(&p->bw, nfft, 1);
     hipError_t e = hipSuccess;
     if (rc == REDIO_OK) {
+        float2 *d_pad = nullptr; // the zero-padded taps, transformed once
         e = hipMalloc((void **)&p->d_Hc, (size_t)nfft * sizeof(float2));
-        if (e == hipSuccess) e = hipMalloc((void **)&p->d_a, p->chunk_blocks * nfft * sizeof(float2));
-        if (e == hipSuccess) e = hipMalloc((void **)&p->d_b, p->chunk_blocks * nfft * sizeof(float2));
+        if (e == hipSuccess && !one_kernel) e = hipMalloc((void **)&p->d_a, p->chunk_blocks * nfft * sizeof(float2));
+        if (e == hipSuccess && !one_kernel) e = hipMalloc((void **)&p->d_b, p->chunk_blocks * nfft * sizeof(float2));
+        if (e == hipSuccess) {
+            if (one_kernel) e = hipMalloc((void **)&d_pad, (size_t)nfft * sizeof(float2));
+            else d_pad = p->d_a;
+        }
         if (e == hipSuccess) {
             std::vector<float2> hp((size_t)nfft, make_float2(0.f, 0.f));
             for (size_t j = 0; j < ntaps; ++j) hp[j].x = taps[j];
-            e = hipMemcpy(p->d_a, hp.data(), (size_t)nfft * sizeof(float2), hipMemcpyHostToDevice);
+            e = hipMemcpy(d_pad, hp.data(), (size_t)nfft * sizeof(float2), hipMemcpyHostToDevice);
         }
         if (e == hipSuccess) {
-            rc = redio_fft_enqueue(p->fw, p->d_a, p->d_Hc, 1, nullptr);
+            rc = redio_fft_enqueue(p->fw, d_pad, p->d_Hc, 1, nullptr);
             if (rc == REDIO_OK) {
                 hipLaunchKernelGGL(ovsave_conj_kernel, dim3((unsigned)((nfft + 255) / 256)), dim3(256), 0, nullptr, p->d_Hc, nfft);
                 e = hipDeviceSynchronize();
             }
         }
+        if (one_kernel && d_pad) hipFree(d_pad);
     }
     if (rc != REDIO_OK || e != hipSuccess) {
         redio_ovsave_destroy(p);
@@ -99,10 +107,14 @@ extern "C" int redio_ovsave_destroy(redio_ovsave *h)
 {
     if (!h) return REDIO_OK;
     redio_fft_destroy(h->fw); redio_fft_destroy(h->bw);
-    hipFree(h->d_Hc); hipFree(h->d_a); hipFree(h->d_b);
+    hipFree(h->d_Hc);
+    if (h->d_a) hipFree(h->d_a);
+    if (h->d_b) hipFree(h->d_b);
     delete h;
     return REDIO_OK;
 }
+
+void redio_ovsave_shape(const redio_ovsave *h, int *nfft, size_t *hop, int *device) { *nfft = h->nfft; *hop = h->hop; *device = h->device; }
 
 extern "C" size_t redio_ovsave_nout(const redio_ovsave *h, size_t n_in)
 {

@@ -134,6 +134,33 @@ extern "C" size_t redio_pfb_nrows(const redio_pfb *h, size_t n_in)
     return T < (size_t)h->taps_per_branch ? 0 : T - (size_t)h->taps_per_branch + 1;
 }
 
+// scratch of the two-pass shapes (branch outputs; transform outputs when regrouping) for inputs of up to n_in samples
+extern "C" int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups)
+{
+    if (!h) return REDIO_ERR_ARG;
+    if (h->fused_kernel) return REDIO_OK;
+    const size_t total = redio_pfb_nrows(h, n_in) * (size_t)h->nchan;
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_rc(e);
+    if (total > h->v_elems) {
+        hipFree(h->d_v); h->d_v = nullptr; h->v_elems = 0;
+        e = hipMalloc((void **)&h->d_v, total * sizeof(float2));
+        if (e != hipSuccess) return hip_rc(e);
+        h->v_elems = total;
+    }
+    if (ngroups > 1 && total > h->w_elems) {
+        hipFree(h->d_w); h->d_w = nullptr; h->w_elems = 0;
+        e = hipMalloc((void **)&h->d_w, total * sizeof(float2));
+        if (e != hipSuccess) return hip_rc(e);
+        h->w_elems = total;
+    }
+    return REDIO_OK;
+}
+void redio_pfb_shape(const redio_pfb *h, int *nchan, int *taps_per_branch, int *device)
+{
+    *nchan = h->nchan; *taps_per_branch = h->taps_per_branch; *device = h->device;
+}
+
 extern "C" int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, int ngroups, void *stream)
 {
     if (!h) return REDIO_ERR_ARG;
@@ -146,17 +173,11 @@ extern "C" int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, vo
     if (!h->fused_kernel) {
         const size_t total = rows * (size_t)h->nchan;
         hipStream_t st = (hipStream_t)stream;
-        if (total > h->v_elems) { // scratch grows on first use / growth only (never inside a captured sequence that ran once before)
-            hipFree(h->d_v); h->d_v = nullptr; h->v_elems = 0;
-            e = hipMalloc((void **)&h->d_v, total * sizeof(float2));
-            if (e != hipSuccess) return hip_rc(e);
-            h->v_elems = total;
-        }
-        if (ngroups > 1 && total > h->w_elems) {
-            hipFree(h->d_w); h->d_w = nullptr; h->w_elems = 0;
-            e = hipMalloc((void **)&h->d_w, total * sizeof(float2));
-            if (e != hipSuccess) return hip_rc(e);
-            h->w_elems = total;
+        if (total > h->v_elems || (ngroups > 1 && total > h->w_elems)) { // un-reserved: grow on first use, never inside a capture
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return REDIO_ERR_NOT_RESERVED;
+            const int rc = redio_pfb_reserve(h, n_in, ngroups);
+            if (rc != REDIO_OK) return rc;
         }
         long blocks = (long)((total + 255) / 256);
         if (blocks > 65536) blocks = 65536;

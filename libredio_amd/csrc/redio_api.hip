@@ -29,6 +29,8 @@ extern "C" const char *redio_strerror(int code)
     case REDIO_ERR_UNSUPPORTED: return "shape not supported by any kernel";
     case REDIO_ERR_NO_DEVICE: return "no HIP device available (libredio has no CPU fallback)";
     case REDIO_ERR_ASSERT: return "the reference would have panicked on this input";
+    case REDIO_ERR_NOT_RESERVED: return "plan scratch not reserved (call the plan's *_reserve before capturing a graph)";
+    case REDIO_ERR_COMM: return "RCCL communicator error (librccl.so missing or a collective failed)";
     default: break;
     }
     if (code <= REDIO_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(REDIO_ERR_HIP_BASE - code));
@@ -244,7 +246,17 @@ extern "C" int redio_convolve_f32(const float *u, size_t nu, const float *v, siz
     if (!cache) cache = new (std::nothrow) ConvCache();
     if (!cache) return REDIO_ERR_NOMEM;
     ConvCache &c = *cache;
-    if (c.device != dev) { // first call of this thread (or the thread moved to another device): start over
+    if (c.device != dev) { // first call of this thread, or the thread moved to another device: release what the
+        if (c.device >= 0) { // old device holds (bound to it while freeing), then start over on the new one
+            hipSetDevice(c.device);
+            if (c.plan) redio_fir_destroy(c.plan);
+            if (c.pin_in) hipHostFree(c.pin_in);
+            if (c.pin_out) hipHostFree(c.pin_out);
+            if (c.d_in) hipFree(c.d_in);
+            if (c.d_out) hipFree(c.d_out);
+            if (c.stream) hipStreamDestroy(c.stream);
+            hipSetDevice(dev);
+        }
         c = ConvCache();
         c.device = dev;
         RD_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
@@ -393,15 +405,29 @@ extern "C" int redio_fft_destroy(redio_fft *h)
     delete h;
     return REDIO_OK;
 }
+// sizes the staging buffer of the sizes that need one (in-place calls on the global-memory path, prime factors above 5
+// beyond LDS) for up to nbatch messages per call; every other size never stages and needs no reservation
+extern "C" int redio_fft_reserve(redio_fft *h, size_t nbatch)
+{
+    if (!h) return REDIO_ERR_ARG;
+    const size_t need = 2 * nbatch * (size_t)h->dev.nfft;
+    if (need <= h->tmp_elems) return REDIO_OK;
+    RD_TRY(hipSetDevice(h->device));
+    if (h->d_tmp) RD_TRY(hipFree(h->d_tmp));
+    h->d_tmp = nullptr; h->tmp_elems = 0;
+    RD_TRY(hipMalloc((void **)&h->d_tmp, need * sizeof(float2)));
+    h->tmp_elems = need;
+    return REDIO_OK;
+}
 // the retry of a launch that asked for staging: tmp = [input copy | work], grown on first use / growth only
 static int fft_enqueue_staged(redio_fft *h, const float2 *d_in, float2 *d_out, size_t nbatch, long in_stride, hipStream_t st)
 {
     const size_t need = nbatch * (size_t)h->dev.nfft;
-    if (2 * need > h->tmp_elems) {
-        if (h->d_tmp) hipFree(h->d_tmp);
-        h->d_tmp = nullptr; h->tmp_elems = 0;
-        RD_TRY(hipMalloc((void **)&h->d_tmp, 2 * need * sizeof(float2)));
-        h->tmp_elems = 2 * need;
+    if (2 * need > h->tmp_elems) { // grown on first use unless redio_fft_reserve() sized it; never during graph capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return REDIO_ERR_NOT_RESERVED;
+        int rc = redio_fft_reserve(h, nbatch);
+        if (rc) return rc;
     }
     const float2 *src = d_in;
     if (d_in == d_out) { // only reachable with contiguous messages (in_stride == nfft)
@@ -450,10 +476,9 @@ struct redio_chain {
     int nfft;
     int fused_ok;
     int force_unfused;
-    int variant; // fused kernel generation: 0 = v3 (wave per block), 1 = v1, 2 = v2 (kept for A/B runs)
-    unsigned *d_queue; // work-queue head of the fused kernel (zeroed on the stream before every launch)
-    float2 *d_mid; // intermediate for the two-kernel path
+    float2 *d_mid; // intermediate for the two-kernel path (redio_chain_reserve)
     size_t mid_elems;
+    unsigned long long *d_stamps; // diagnostic per-wave stamps of THIS plan's launches (redio_chain_set_debug_stamps), else null
 };
 
 extern "C" int redio_chain_create(redio_chain **h, const float *taps, size_t ntaps, size_t decim, int nfft, unsigned flags)
@@ -468,7 +493,6 @@ extern "C" int redio_chain_create(redio_chain **h, const float *taps, size_t nta
     if (rc) { redio_fir_destroy(c->fir); redio_fft_destroy(c->fft); delete c; return rc; }
     c->nfft = nfft;
     c->fused_ok = chain_supported((int)ntaps, (long)decim, nfft) ? 1 : 0;
-    if (hipMalloc((void **)&c->d_queue, 256) != hipSuccess) c->d_queue = nullptr; // the fused kernel falls back to static ranges
     *h = c;
     return REDIO_OK;
 }
@@ -478,7 +502,6 @@ extern "C" int redio_chain_destroy(redio_chain *h)
     redio_fir_destroy(h->fir);
     redio_fft_destroy(h->fft);
     if (h->d_mid) hipFree(h->d_mid);
-    if (h->d_queue) hipFree(h->d_queue);
     delete h;
     return REDIO_OK;
 }
@@ -494,14 +517,29 @@ extern "C" int redio_chain_set_unfused(redio_chain *h, int unfused)
     h->force_unfused = unfused ? 1 : 0;
     return REDIO_OK;
 }
-namespace redio { void chain_set_debug_buffer(unsigned long long *p); }
-// diagnostic: per-wave {shader cycles, 100 MHz ticks} of the v4 chain kernel into a caller buffer (2 x u64 per wave)
-extern "C" int redio_debug_chain_stamps(void *d_buf) { chain_set_debug_buffer((unsigned long long *)d_buf); return REDIO_OK; }
-extern "C" int redio_chain_set_variant(redio_chain *h, int variant)
+extern "C" int redio_chain_set_debug_stamps(redio_chain *h, void *d_buf)
 {
-    if (!h || variant < 0 || (variant > 10 && variant != 31)) return REDIO_ERR_ARG; // every selectable build is bit-identical
-    h->variant = variant;
+    if (!h) return REDIO_ERR_ARG;
+    h->d_stamps = (unsigned long long *)d_buf;
     return REDIO_OK;
+}
+// sizes the two-kernel path's intermediate for inputs of up to n_in samples (allocation; may free a smaller one)
+extern "C" int redio_chain_reserve(redio_chain *h, size_t n_in)
+{
+    if (!h) return REDIO_ERR_ARG;
+    const size_t ny = redio_chain_nblocks(h, n_in) * (size_t)h->nfft;
+    if (ny <= h->mid_elems) return REDIO_OK;
+    RD_TRY(hipSetDevice(h->fir->device));
+    if (h->d_mid) RD_TRY(hipFree(h->d_mid));
+    h->d_mid = nullptr; h->mid_elems = 0;
+    RD_TRY(hipMalloc((void **)&h->d_mid, ny * sizeof(float2)));
+    h->mid_elems = ny;
+    return REDIO_OK;
+}
+static bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
 }
 extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream)
 {
@@ -513,22 +551,32 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     const bool fused_math = (h->fir->flags & REDIO_FIR_FUSED) != 0;
     if (redio_chain_is_fused(h)) {
         hipError_t e = launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
-                                    (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, h->variant, (hipStream_t)stream, h->d_queue);
+                                    (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, (hipStream_t)stream, h->d_stamps);
         if (e != hipErrorNotSupported) return hip_rc(e);
         // e.g. an input pointer the fused kernel cannot take: same results through the two kernels below
     }
-    // two kernels through a plan-owned intermediate (allocated on first use / growth)
+    // two kernels through the plan-owned intermediate.  Sized by redio_chain_reserve(); an un-reserved plan grows it
+    // here on first use -- an allocation, so never while the stream is being captured into a graph.
     size_t ny = nblk * (size_t)h->nfft;
     if (ny > h->mid_elems) {
-        if (h->d_mid) hipFree(h->d_mid);
-        h->d_mid = nullptr; h->mid_elems = 0;
-        RD_TRY(hipMalloc((void **)&h->d_mid, ny * sizeof(float2)));
-        h->mid_elems = ny;
+        if (stream_is_capturing((hipStream_t)stream)) return REDIO_ERR_NOT_RESERVED;
+        int rc = redio_chain_reserve(h, n_in);
+        if (rc) return rc;
     }
     size_t need_in = (ny - 1) * h->fir->decim + h->fir->ntaps; // inputs feeding the kept blocks
     RD_TRY(launch_fir(d_in, (long)need_in, h->fir->d_taps, (int)h->fir->ntaps, (long)h->fir->decim, h->d_mid, (long)ny,
                       true, fused_math, (hipStream_t)stream));
     return redio_fft_enqueue(h->fft, h->d_mid, d_out, nblk, stream);
+}
+
+// shapes of the plans, for the carried-history layer (stream_carry.hip)
+void redio_fir_shape(const redio_fir *h, size_t *ntaps, size_t *decim, unsigned *flags, int *device)
+{
+    *ntaps = h->ntaps; *decim = h->decim; *flags = h->flags; *device = h->device;
+}
+void redio_chain_shape(const redio_chain *h, size_t *ntaps, size_t *decim, int *nfft, int *device)
+{
+    *ntaps = h->fir->ntaps; *decim = h->fir->decim; *nfft = h->nfft; *device = h->fir->device;
 }
 
 // ---------------------------------------------------------------- synthetic input

@@ -52,7 +52,7 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
-                        float2 *out, long nblocks, bool fused, int variant, hipStream_t s, unsigned *queue = nullptr);
+                        float2 *out, long nblocks, bool fused, hipStream_t s, unsigned long long *dbg = nullptr);
 
 // misc_kernels.hip
 hipError_t launch_synth_iq(float2 *out, uint32_t seed, uint64_t first, long n, hipStream_t s);
@@ -63,6 +63,13 @@ bool ovsave_big_size(int nfft);
 hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const float2 *x, long hop, float2 *a, float2 *b, const float2 *Hc,
                              float2 *out, long nblk, float scale, hipStream_t s);
 } // namespace redio
+
+// plan shapes for the carried-history layer (stream_carry.hip); defined next to each plan struct
+struct redio_fir; struct redio_chain; struct redio_pfb; struct redio_ovsave;
+void redio_fir_shape(const redio_fir *h, size_t *ntaps, size_t *decim, unsigned *flags, int *device);
+void redio_chain_shape(const redio_chain *h, size_t *ntaps, size_t *decim, int *nfft, int *device);
+void redio_pfb_shape(const redio_pfb *h, int *nchan, int *taps_per_branch, int *device);
+void redio_ovsave_shape(const redio_ovsave *h, int *nfft, size_t *hop, int *device);
 
 // redio_api.hip: the device twiddle table behind a public FFT handle (library-internal)
 struct redio_fft;

@@ -86,7 +86,7 @@ def _zip(name_f32, name_c32, x, c):
 
 
 def mul_vecs(x, c):
-    """kpn::mul_vecs (kpn.rs:254-258) on device tensors: x[i] * c[i] over the shorter length."""
+    """kpn::mul_vecs (kpn.rs:198-203) on device tensors: x[i] * c[i] over the shorter length."""
     return _zip("redio_mul_f32", "redio_mul_c32", x, c)
 
 

@@ -116,9 +116,13 @@ class Chain:
     def set_unfused(self, unfused):
         check(lib().redio_chain_set_unfused(self._h, int(bool(unfused))), "chain_set_unfused")
 
-    def set_variant(self, variant):
-        """Kernel generation of the fused path (A/B measurement): 0 = current, 1 = first."""
-        check(lib().redio_chain_set_variant(self._h, int(variant)), "chain_set_variant")
+    def reserve(self, n_in):
+        """Size the two-kernel path's intermediate up front (enqueue then never allocates)."""
+        check(lib().redio_chain_reserve(self._h, int(n_in)), "chain_reserve")
+
+    def set_debug_stamps(self, buf):
+        """Diagnostic per-wave stamps of this plan's fused launches into `buf` (int64 CUDA tensor, 4 per wave); None = off."""
+        check(lib().redio_chain_set_debug_stamps(self._h, None if buf is None else C.c_void_p(buf.data_ptr())), "chain_set_debug_stamps")
 
     def __call__(self, x, out=None):
         import torch
@@ -133,6 +137,53 @@ class Chain:
     def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_chain_destroy", self._h)
+            self._h = None
+
+
+class Stream:
+    """redio_{fir,chain,pfb,ovsave}_stream_*: a plan fed as a STREAM with the history carried on the device, so that any
+    segmentation of the input gives the bits of one stateless call on the whole stream (the stateless plans keep the
+    reference's per-message semantics, dsputils.rs:30-32).  `plan` is a Fir, Chain, Channelizer or OverlapSave."""
+
+    def __init__(self, plan):
+        kind = {Fir: "fir", Chain: "chain"}.get(type(plan)) or {"Channelizer": "pfb", "OverlapSave": "ovsave"}[type(plan).__name__]
+        self._kind, self._plan = kind, plan          # the plan must outlive the stream handle
+        self._h = C.c_void_p()
+        check(getattr(lib(), f"redio_{kind}_stream_create")(C.byref(self._h), plan._h), f"{kind}_stream_create")
+
+    def _f(self, name):
+        return getattr(lib(), f"redio_{self._kind}_stream_{name}")
+
+    def nout(self, n_new):
+        return self._f("nout")(self._h, int(n_new))
+
+    @property
+    def pending(self):
+        return self._f("pending")(self._h)
+
+    def reset(self):
+        check(self._f("reset")(self._h), "stream_reset")
+
+    def __call__(self, x, out=None):
+        """Feed the next piece of the stream; returns the output samples that became computable (flat tensor; the
+        chain's are whole spectra of nfft samples, the channelizer's whole rows of nchan samples)."""
+        import torch
+        real = self._kind == "fir" and not self._plan.complex_input
+        want = torch.float32 if real else torch.complex64
+        assert x.dtype == want, f"expected {want}"
+        n = self.nout(x.numel())
+        if out is None:
+            out = torch.empty(max(n, 1), dtype=want, device=x.device)
+        assert out.numel() >= n
+        got = C.c_size_t(0)
+        check(self._f("enqueue")(self._h, _dev_ptr(x) if x.numel() else None, x.numel(), _dev_ptr(out), C.byref(got), current_stream()),
+              f"{self._kind}_stream_enqueue")
+        assert got.value == n
+        return out[:n]
+
+    def __del__(self, _safe_destroy=_safe_destroy):
+        if getattr(self, "_h", None):
+            _safe_destroy(f"redio_{self._kind}_stream_destroy", self._h)
             self._h = None
 
 

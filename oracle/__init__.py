@@ -11,11 +11,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libredio_oracle.so")
+_KPN_SO = os.path.join(_HERE, "_build", "libredio_kpn_baseline.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
-    if (not force and os.path.exists(_SO)
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".cpp"))]
+    if (not force and os.path.exists(_SO) and os.path.exists(_KPN_SO) and os.path.getmtime(_KPN_SO) >= os.path.getmtime(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -356,7 +357,7 @@ def dld(runs, s_rate):
 
 
 def zip_vecs(a, b, add=False):
-    """kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231): elementwise over the shorter length."""
+    """kpn::mul_vecs / sum_vecs (kpn.rs:198-203, 227-231): elementwise over the shorter length."""
     n = min(len(a), len(b))
     if np.iscomplexobj(a) or np.iscomplexobj(b):
         a, b = _c64(a[:n]), _c64(b[:n]); out = np.empty(n, np.complex64)
@@ -365,3 +366,17 @@ def zip_vecs(a, b, add=False):
         a, b = _f32(a[:n]), _f32(b[:n]); out = np.empty(n, np.float32)
         lib().orc_zip_f32(a, b, n, int(add), out)
     return out
+
+
+def kpn_chain_baseline(seconds, log2n, seed, taps, decim, nfft):
+    """bench.py's cpu_baseline leg in the reference's structure (oracle/kpn_baseline.cpp): one thread per block, one heap
+    Vec per message, queue hand-off.  Returns (input samples whose spectra reached the sink, messages, wall seconds)."""
+    lib()
+    K = C.CDLL(_KPN_SO)
+    K.orc_kpn_chain_baseline.restype = C.c_double
+    K.orc_kpn_chain_baseline.argtypes = [C.c_double, C.c_int, C.c_uint32, _f32p, C.c_size_t, C.c_size_t, C.c_int,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    done, msgs = C.c_uint64(0), C.c_uint64(0)
+    wall = K.orc_kpn_chain_baseline(float(seconds), int(log2n), int(seed), t, len(t), int(decim), int(nfft), C.byref(done), C.byref(msgs))
+    return done.value, msgs.value, wall

@@ -139,7 +139,7 @@ void orc_norm_c32(const orc_cpx *x, size_t n, float *out)
     for (size_t i = 0; i < n; ++i) out[i] = hypotf(x[i].r, x[i].i);
 }
 
-/* kpn::mul_vecs (src/kpn/src/kpn.rs:254-258) and kpn::sum_vecs (:227-231): zip of the message with a
+/* kpn::mul_vecs (src/kpn/src/kpn.rs:198-203) and kpn::sum_vecs (:227-231): zip of the message with a
  * constant vector; f32 and Complex<f32> (num 0.1.22 Mul: (ar*br - ai*bi, ar*bi + ai*br)). */
 void orc_zip_f32(const float *a, const float *b, size_t n, int add, float *out)
 {

@@ -107,7 +107,7 @@ size_t orc_trigger_feed(orc_trigger_state *t, const float *blocks, size_t nblock
                         float *out, size_t out_cap, size_t *out_lens, size_t lens_cap, size_t *out_total);
 float  orc_block_sum(const float *x, size_t n); /* sequential f32 sum, bitfount.rs:48 */
 void   orc_norm_c32(const orc_cpx *x, size_t n, float *out); /* Complex::norm = hypotf, src/ratpak.rs:64-68 */
-void   orc_zip_f32(const float *a, const float *b, size_t n, int add, float *out);       /* mul_vecs / sum_vecs, src/kpn/src/kpn.rs:254-258, 227-231 */
+void   orc_zip_f32(const float *a, const float *b, size_t n, int add, float *out);       /* mul_vecs / sum_vecs, src/kpn/src/kpn.rs:198-203, 227-231 */
 void   orc_zip_c32(const orc_cpx *a, const orc_cpx *b, size_t n, int add, orc_cpx *out);
 
 #ifdef __cplusplus

@@ -215,6 +215,22 @@ static int plumbing()
         auto iq = drain(dr);
         CHECK(iq.size() == 2048 && iq[1] == std::complex<float>(x[2], x[3]));
     }
+    { // a block that throws mid-stream is that task's panic only: the process lives and the hang-up cascades
+        auto [a, ar] = channel<int>();
+        auto [b, br] = channel<int>();
+        auto [c, cr] = channel<int>();
+        auto t1 = spawn([s = std::move(a)]() mutable { for (int i = 0; i < 10; ++i) s.send(i); });
+        auto t2 = spawn([r = std::move(ar), s = std::move(b)]() mutable {
+            for (;;) {
+                int v = r.recv();
+                if (v == 3) throw std::out_of_range("block failure injected by the test");
+                s.send_unwrap(v);
+            }
+        });
+        auto t3 = spawn([r = std::move(br), s = std::move(c)]() mutable { for (;;) s.send_unwrap(r.recv() * 2); });
+        t1.join(); t2.join(); t3.join();
+        CHECK((drain(cr) == std::vector<int>{0, 2, 4}));
+    }
     std::puts("plumbing ok");
     return 0;
 }

@@ -309,3 +309,11 @@ extern "C" void emu_fft64k(const float2 *in, float2 *out, int inverse)
         }
     }
 }
+
+// the segmentation arithmetic of the carried-history layer (libredio_amd/csrc/stream_split.h)
+#include "../../libredio_amd/csrc/stream_split.h"
+extern "C" void emu_stream_split(size_t hist, size_t W, size_t H, size_t n, size_t *out5)
+{
+    const redio::StreamSplit s = redio::stream_split(hist, W, H, n);
+    out5[0] = s.nh; out5[1] = s.head_in; out5[2] = s.nb; out5[3] = s.off; out5[4] = s.body_in;
+}

@@ -58,7 +58,7 @@ while time.time() < t_end:
         want = O.chain_fir_fft(x, taps, dd, nfc, fused=fused)
         check("chain", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, nfc, fused, nb, extra))
     elif which == 3:    # overlap-save
-        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 8192, 8192, 32768, 1000, int(rng.integers(2, 12000))]))
+        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 8192, 8192, 32768, 65536, 1000, int(rng.integers(2, 12000))]))
         k = int(rng.integers(1, nfft + 1)); hop = nfft - k + 1
         n = nfft + int(rng.integers(0, 6)) * hop + int(rng.integers(0, hop))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)

@@ -86,6 +86,33 @@ def test_trigger_state_machine_matches_the_reference_walk(gpu, redio, oracle):
     assert want[0][0] == 0.0 and len(want[0]) % 512 == 1       # the first buffer starts as vec!(0.0) (bitfount.rs:43)
 
 
+def test_trigger_refuses_a_result_that_does_not_fit_without_consuming(gpu, redio, oracle):
+    """A completed trigger buffer is never dropped: when the caller's buffers are too small the call consumes nothing,
+    reports what it needs, and the retry with enough room gives exactly the reference walk."""
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    blocks = (0.05 * rng.random((300, 512))).astype(np.float32)
+    blocks[100:107] += 1.0
+    d = gpu.from_numpy(blocks).cuda()
+    want = oracle.Trigger().feed(blocks)
+    assert len(want) == 1
+    L = redio.lib()
+    h = C.c_void_p()
+    assert L.redio_trigger_create(C.byref(h)) == 0
+    out = gpu.empty(len(want[0]) + 8, dtype=gpu.float32, device="cuda")
+    lens = (C.c_size_t * 4)()
+    ne, tot = C.c_size_t(0), C.c_size_t(0)
+    small = len(want[0]) - 1
+    rc = L.redio_trigger_feed(h, C.c_void_p(d.data_ptr()), 300, 512, C.c_void_p(out.data_ptr()), small, lens, 4, C.byref(ne), C.byref(tot), None)
+    assert rc == -1 and ne.value == 1 and tot.value == len(want[0])      # REDIO_ERR_ARG + the capacities a retry needs
+    rc = L.redio_trigger_feed(h, C.c_void_p(d.data_ptr()), 300, 512, C.c_void_p(out.data_ptr()), out.numel(), None, 0, C.byref(ne), C.byref(tot), None)
+    assert rc == -1 and ne.value == 1                                      # no lens array for a call that emits
+    rc = L.redio_trigger_feed(h, C.c_void_p(d.data_ptr()), 300, 512, C.c_void_p(out.data_ptr()), out.numel(), lens, 4, C.byref(ne), C.byref(tot), None)
+    assert rc == 0 and ne.value == 1 and lens[0] == len(want[0])
+    assert np.array_equal(bits(out[:lens[0]].cpu().numpy()), bits(want[0]))
+    L.redio_trigger_destroy(h)
+
+
 def test_shipped_graph_front_end_end_to_end(gpu, redio, oracle):
     """rtl bytes -> data_to_samples -> |x| -> trigger -> discretize, as src/ratpak.rs:60-76 wires them."""
     rng = np.random.default_rng(11)

@@ -44,3 +44,29 @@ def test_overlap_save_many_blocks_chunking(gpu, redio, oracle):
     for b in (0, 8191, 8192, 9000):
         xw = oracle.synth_iq(3, 898 * b, 1024)
         assert np.array_equal(bits(y[898 * b: 898 * (b + 1)].cpu().numpy()), bits(oracle.overlap_save(xw, taps, 1024)))
+
+
+@pytest.mark.parametrize("k", [8193, 127])
+def test_overlap_save_65536_across_the_chunk_loop(gpu, redio, oracle, k):
+    """BASELINE.json configs[4] shape beyond one work-buffer chunk: 65536-point blocks, two full 128-block chunks
+    and a ragged third (261 blocks).  Every block is independent given its own 65536-sample window
+    (dsputils.rs:30-32 semantics per window), so the blocks either side of every chunk seam, the first and the
+    last are compared bit for bit with the oracle run on just that window."""
+    nfft = 65536
+    taps = oracle.lpf_corrected(k, 0.02)
+    hop = nfft - k + 1
+    nblk = 261
+    n = nfft + hop * (nblk - 1) + 1234          # ragged tail that fills no block
+    x = redio.synth_iq(0x5EED0005, 0, n)
+    plan = redio.OverlapSave(taps, nfft)
+    assert plan.nout(n) == nblk * hop
+    y = plan(x)
+    assert y.numel() == nblk * hop
+    for b in (0, 1, 126, 127, 128, 129, 254, 255, 256, 257, nblk - 1):
+        xw = oracle.synth_iq(0x5EED0005, hop * b, nfft)
+        want = oracle.overlap_save(xw, taps, nfft)
+        assert np.array_equal(bits(y[hop * b: hop * (b + 1)].cpu().numpy()), bits(want)), (k, b)
+    # idempotence of the plan (work buffers reused by the second call) and a checksum over all blocks
+    s1 = gpu.view_as_real(y).view(gpu.int32).sum(dtype=gpu.int64).item()
+    y2 = plan(x)
+    assert gpu.equal(y, y2) and s1 == gpu.view_as_real(y2).view(gpu.int32).sum(dtype=gpu.int64).item()

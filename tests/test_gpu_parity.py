@@ -253,12 +253,19 @@ def test_chain_bit_exact(gpu, redio, oracle, fused, nblocks):
     want = oracle.chain_fir_fft(x, taps, 5, 1024, fused=fused)
     got = chain(d).cpu().numpy()
     assert same_bits(got, want)
-    for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 31):  # earlier kernel generations / tunings, kept for A/B measurement
-        chain.set_variant(variant)
-        assert same_bits(chain(d).cpu().numpy(), want), variant
-    chain.set_variant(0)
     chain.set_unfused(True)  # FIR kernel + FFT kernel through an intermediate: same bits
+    chain.reserve(n)         # sized up front: enqueue then never allocates (graph-capturable)
     assert same_bits(chain(d).cpu().numpy(), want)
+    # the diagnostic stamps are per plan: a stamped plan does not leak writes into another plan's launches
+    chain.set_unfused(False)
+    other = redio.Chain(taps, 5, 1024, fused=fused)
+    stamps = gpu.zeros(4 * 4096, dtype=gpu.int64, device="cuda")
+    chain.set_debug_stamps(stamps)
+    assert same_bits(chain(d).cpu().numpy(), want) and int((stamps != 0).sum()) > 0
+    chain.set_debug_stamps(None)
+    stamps.zero_()
+    assert same_bits(other(d).cpu().numpy(), want) and same_bits(chain(d).cpu().numpy(), want)
+    assert int((stamps != 0).sum()) == 0
 
 
 def test_chain_fused_rounding_vs_reference_rounding_tolerance(gpu, redio, oracle):
@@ -322,11 +329,20 @@ def test_chain_full_size_properties(gpu, redio, oracle):
         nb = chain.nblocks(n)
         assert nb == ((n - 127) // 5 + 1) // 1024
         out = chain(x)
-        for b in (0, 1, nb // 2, nb - 1):
+        # a wave owns a run of blocks_per_wave consecutive blocks and carries the FIR halo inside LDS from one
+        # sub-tile to the next (chain_v4.hip): check the first and the last block of EVERY run, whatever the run
+        # length the launcher picked for this device (8 waves per CU), plus every 64th block
+        cus = gpu.cuda.get_device_properties(0).multi_processor_count
+        picks = {0, 1, nb // 2, nb - 1} | set(range(0, nb, 64))
+        for waves in {8 * cus, 12 * cus}:
+            bpw = -(-nb // waves)
+            picks |= set(range(0, nb, bpw)) | {min(b + bpw - 1, nb - 1) for b in range(0, nb, bpw)}
+        outh = out.cpu().numpy()
+        for b in sorted(picks):
             lo = b * 5120
             xw = oracle.synth_iq(0x5EED0002, lo, 5120 + 126)
             want = oracle.chain_fir_fft(xw, taps, 5, 1024, fused=fused)[0]
-            assert same_bits(out[b].cpu().numpy(), want), (fused, b)
+            assert same_bits(outh[b], want), (fused, b)
     s1 = gpu.view_as_real(out).view(gpu.int32).sum(dtype=gpu.int64).item()
     out2 = chain(x * 4.0)
     assert gpu.equal(out2, out * 4.0)

@@ -214,3 +214,33 @@ def test_fast_mode_error_bound_and_state(gpu, redio, oracle):
     a, _ = exact.process(dy, ratio)
     b, _ = fast.process(dy, ratio)
     assert np.array_equal(bits(a.cpu().numpy()), bits(b.cpu().numpy()))
+
+
+def test_c3_256_channels_two_messages(gpu, redio, oracle):
+    """BASELINE.json configs[2] at its channel count: 256 independent mono states (samplerate.rs:61), 2.4 MS/s -> 48 kS/s
+    (ratio 0.02), 2^18 frames per channel in two messages of unequal length.  EXACT is bit-identical to the oracle on
+    channels spread over the whole batch (first / last of every 64-channel group and some inside); FAST stays inside its bound."""
+    nch, n, ratio = 256, 1 << 18, 0.02
+    x = np.stack([oracle.synth_f32(0x5EED0003 + c, 0, n) for c in range(nch)])
+    d = gpu.from_numpy(x).cuda()
+    exact, fast = redio.Src(nch, 1), redio.Src(nch, 1, mode=redio.Src.FAST)
+    check = (0, 1, 31, 63, 64, 100, 127, 128, 191, 192, 200, 254, 255)
+    refs = {c: oracle.Resampler(1) for c in check}
+    tab, half, inc = oracle.src_table(1)
+    pos = np.arange(0.0, half, inc * ratio)
+    K = 2 * len(pos)
+    sum_h = 2 * ratio * np.abs(np.interp(pos, np.arange(half + 2), tab.astype(np.float64))).sum()
+    bound = (K + 1) * 2.0 ** -24 * max(sum_h, 1.0) * np.abs(x).max()
+    total = 0
+    for lo, hi in ((0, 150001), (150001, n)):
+        a, ua = exact.process(d[:, lo:hi].contiguous(), ratio)
+        b, ub = fast.process(d[:, lo:hi].contiguous(), ratio)
+        assert ua == ub == hi - lo and a.shape == b.shape and a.shape[0] == nch
+        total += a.shape[1]
+        an = a.cpu().numpy()
+        for c in check:
+            err, want, wused = refs[c].process(x[c, lo:hi], ratio, int(ratio * (hi - lo) + 1.0))
+            assert err == 0 and wused == ua
+            assert np.array_equal(bits(an[c]), bits(want)), (c, lo, hi)
+        assert (a - b).abs().max().item() <= bound
+    assert abs(total - int(n * ratio)) <= 2      # the output count law over the whole stream

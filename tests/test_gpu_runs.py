@@ -87,7 +87,7 @@ def test_shipped_graph_discretize_to_runs(gpu, redio, oracle):
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 1023, 4096, 100003])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_mul_vecs_sum_vecs_bit_exact(gpu, redio, oracle, n, cplx):
-    # kpn::mul_vecs / sum_vecs (kpn.rs:254-258, 227-231): zip over the shorter length; aligned and unaligned views
+    # kpn::mul_vecs / sum_vecs (kpn.rs:198-203, 227-231): zip over the shorter length; aligned and unaligned views
     from libredio_amd import kpn_dev
     gen = oracle.synth_iq if cplx else oracle.synth_f32
     x, c = gen(31, 0, n + 5), gen(32, 0, n + 9)

@@ -1,0 +1,122 @@
+"""Carried history (redio_*_stream_*): a stream fed in ANY pieces gives exactly the bits of one stateless call on the
+whole stream.  SURVEY.md 8d defines BASELINE.json configs[1] on a stream with the history carried, SURVEY.md 7.4.5 asks
+for results independent of message tiling; the stateless plans keep dsputils::convolve's per-message semantics
+(dsputils.rs:30-32), which drops ntaps-1 outputs at every seam."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def cuts(rng, n, style):
+    if style == "one":
+        return [n]
+    if style == "tiny":       # many messages shorter than a window, some empty
+        out, left = [], n
+        while left:
+            k = int(min(left, rng.integers(0, 40)))
+            out.append(k); left -= k
+        return out
+    if style == "odd":        # odd lengths: the body starts on an odd sample (8-byte aligned only)
+        out, left = [], n
+        while left:
+            k = int(min(left, 2 * int(rng.integers(500, 40000)) + 1))
+            out.append(k); left -= k
+        return out
+    out, left = [], n         # "mixed"
+    while left:
+        k = int(min(left, rng.choice([1, 7, 126, 127, 128, 1000, 5119, 5120, 5121, 5246, 20000, 65536, 100001])))
+        out.append(k); left -= k
+    return out
+
+
+def feed(stream, x, pieces, gpu):
+    outs, pos = [], 0
+    for k in pieces:
+        want = stream.nout(k)
+        y = stream(x[pos:pos + k])
+        assert y.numel() == want
+        outs.append(y.clone())
+        pos += k
+    return gpu.cat(outs) if outs else None
+
+
+@pytest.mark.parametrize("style", ["one", "tiny", "odd", "mixed"])
+@pytest.mark.parametrize("k,d,cplx,fused", [(127, 5, True, True), (127, 5, True, False), (63, 1, False, False), (100, 3, True, False), (1, 1, False, False), (17, 4, False, True), (5, 9, True, False)])
+def test_fir_stream_any_segmentation(gpu, redio, oracle, k, d, cplx, fused, style):
+    rng = np.random.default_rng(k * 131 + d)
+    n = 30000 if style == "tiny" else 300000
+    taps = oracle.synth_f32(5, 0, k)
+    xh = (oracle.synth_iq if cplx else oracle.synth_f32)(77, 0, n)
+    x = gpu.from_numpy(xh).cuda()
+    plan = redio.Fir(taps, d, complex_input=cplx, fused=fused)
+    want = oracle.fir(xh, taps, d, fused)
+    st = redio.Stream(plan)
+    got = feed(st, x, cuts(rng, n, style), gpu).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, style)
+    assert st.pending == max(n - len(want) * d, 0) and st.pending < k
+    # the handle is reusable after reset, and the stateless plan still gives the one-shot result
+    st.reset()
+    assert np.array_equal(bits(feed(st, x, [n], gpu).cpu().numpy()), bits(want))
+    assert np.array_equal(bits(plan(x).cpu().numpy()), bits(want))
+
+
+@pytest.mark.parametrize("style", ["one", "tiny", "odd", "mixed"])
+@pytest.mark.parametrize("k,d,nfft,fused", [(127, 5, 1024, True), (127, 5, 1024, False), (63, 1, 1024, True), (31, 4, 256, False)])
+def test_chain_stream_any_segmentation(gpu, redio, oracle, k, d, nfft, fused, style):
+    rng = np.random.default_rng(k + nfft)
+    nb = 3 if style == "tiny" else 41
+    n = nb * nfft * d + (k - d) + 777          # 777 trailing samples fill no block: they stay pending
+    taps = oracle.lpf_corrected(k, 0.4 / max(d, 2))
+    xh = oracle.synth_iq(0x5EED0002, 0, n)
+    x = gpu.from_numpy(xh).cuda()
+    want = oracle.chain_fir_fft(xh, taps, d, nfft, fused=fused)
+    st = redio.Stream(redio.Chain(taps, d, nfft, fused=fused))
+    got = feed(st, x, cuts(rng, n, style), gpu).cpu().numpy().reshape(-1, nfft)
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, nfft, style)
+    assert st.pending == n - nb * nfft * d
+
+
+@pytest.mark.parametrize("style", ["one", "odd", "mixed"])
+@pytest.mark.parametrize("nchan,p", [(64, 16), (64, 4), (32, 5)])
+def test_channelizer_stream_any_segmentation(gpu, redio, oracle, nchan, p, style):
+    rng = np.random.default_rng(nchan + p)
+    n = nchan * 3000 + 13
+    proto = oracle.synth_f32(9, 0, nchan * p)
+    xh = oracle.synth_iq(0x5EED0004, 0, n)
+    x = gpu.from_numpy(xh).cuda()
+    want = oracle.pfb_channelizer(xh, proto, nchan, p, fused=False)
+    st = redio.Stream(redio.Channelizer(proto, nchan, p, fused=False))
+    got = feed(st, x, cuts(rng, n, style), gpu).cpu().numpy().reshape(-1, nchan)
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nchan, p, style)
+
+
+@pytest.mark.parametrize("style", ["one", "odd", "mixed"])
+@pytest.mark.parametrize("nfft,k", [(1024, 127), (4096, 1025), (65536, 8193), (1000, 100)])
+def test_overlap_save_stream_any_segmentation(gpu, redio, oracle, nfft, k, style):
+    rng = np.random.default_rng(nfft + k)
+    hop = nfft - k + 1
+    n = nfft + hop * (4 if nfft > 4096 else 37) + 55
+    taps = oracle.lpf_corrected(k, 0.02)
+    xh = oracle.synth_iq(0x5EED0005, 0, n)
+    x = gpu.from_numpy(xh).cuda()
+    want = oracle.overlap_save(xh, taps, nfft)
+    st = redio.Stream(redio.OverlapSave(taps, nfft))
+    got = feed(st, x, cuts(rng, n, style), gpu).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nfft, k, style)
+
+
+def test_chain_stream_large_pieces_at_full_rate_path(gpu, redio, oracle):
+    """2^24-sample pieces of a 2^26-sample stream through the fused kernel: equal to the one-shot call, bit for bit."""
+    taps = oracle.lpf_corrected(127, 0.08)
+    n = 1 << 26
+    x = redio.synth_iq(0x5EED0002, 0, n)
+    chain = redio.Chain(taps, 5, 1024, fused=True)
+    one = chain(x).reshape(-1)
+    st = redio.Stream(chain)
+    got = gpu.cat([st(x[i:i + (1 << 24)]).clone() for i in range(0, n, 1 << 24)])
+    assert got.numel() == one.numel() and gpu.equal(got, one)

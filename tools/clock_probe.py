@@ -4,17 +4,15 @@ import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, libredio_amd as R
 lib = R.lib()
-lib.redio_debug_chain_stamps.argtypes = [C.c_void_p]; lib.redio_debug_chain_stamps.restype = C.c_int
 n = 1 << 28
 chain = R.Chain(R.dsputils.lpf_corrected(127, 0.08), 5, 1024, fused=True)
-chain.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 x = R.synth_iq(0x5EED0002, 0, n); out = torch.empty((chain.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
 dbg = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
 for burst in (5, 50, 500):
     for _ in range(burst): chain(x, out)        # load the chip
-    lib.redio_debug_chain_stamps(C.c_void_p(dbg.data_ptr()))
+    chain.set_debug_stamps(dbg)
     chain(x, out); torch.cuda.synchronize()
-    lib.redio_debug_chain_stamps(None)
+    chain.set_debug_stamps(None)
     d = dbg.cpu().numpy().reshape(-1, 4); d = d[d[:, 1] > 0]
     clk = d[:, 0] / d[:, 1] * 100e6
     import numpy as np

@@ -3,14 +3,12 @@ import ctypes as C, sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, libredio_amd as R
 lib = R.lib()
-lib.redio_debug_chain_stamps.argtypes = [C.c_void_p]
 n = 1 << 28
 chain = R.Chain(R.dsputils.lpf_corrected(127, 0.08), 5, 1024, fused=True)
-chain.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 x = R.synth_iq(0x5EED0002, 0, n); out = torch.empty((chain.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
 dbg = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
 for _ in range(300): chain(x, out)
-lib.redio_debug_chain_stamps(C.c_void_p(dbg.data_ptr())); chain(x, out); torch.cuda.synchronize(); lib.redio_debug_chain_stamps(None)
+chain.set_debug_stamps(dbg); chain(x, out); torch.cuda.synchronize(); chain.set_debug_stamps(None)
 d = dbg.cpu().numpy().reshape(-1, 4); d = d[d[:, 1] > 0]
 life = d[:, 1] / 100.0
 xcc = (d[:, 3] >> 32) & 0xF; hw = d[:, 3] & 0xFFFFFFFF
