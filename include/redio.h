@@ -215,6 +215,29 @@ int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, 
 /* scratch of the two-pass shapes for inputs of up to n_in samples (the fused 64-channel kernel needs none) */
 int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups);
 
+/* ---- the channelizer's one exchange step over RCCL / xGMI (the only collective on the path) ----
+ * Time-sharded channelizer: every rank runs redio_pfb_enqueue(..., ngroups = G) on its own slice of the stream and
+ * holds d_grouped = [G groups][its rows][chans_per_rank cf32]; the exchange sends group q to rank q
+ * (ncclGroupStart; ncclSend/ncclRecv per peer; ncclGroupEnd), so that afterwards rank g holds
+ * d_out = [sum(rows_per_rank) rows, in rank (= time) order][chans_per_rank cf32] for ITS channels.
+ * rows_per_rank[G] (host) may be ragged.  Enqueued on `stream`; nothing synchronises.
+ * librccl.so is loaded on first use; REDIO_ERR_COMM (text: redio_comm_last_error) if it is missing or a call fails.
+ * One rank per process: rank 0 calls redio_comm_unique_id, the launcher hands the 128 bytes to every rank, every rank
+ * calls redio_comm_init_rank on its own device.  Several ranks in one process (the reference's thread-per-block host):
+ * redio_comm_init_all(comms, ndev, devices) then redio_pfb_exchange_all, which wraps all ranks' transfers in one group. */
+#define REDIO_COMM_ID_BYTES 128
+typedef struct redio_comm redio_comm;
+int redio_comm_unique_id(void *id128);
+int redio_comm_init_rank(redio_comm **c, int nranks, int rank, const void *id128);
+int redio_comm_init_all(redio_comm **comms, int ndev, const int *devices /* NULL = 0..ndev-1 */);
+int redio_comm_destroy(redio_comm *c);
+int redio_comm_rank(const redio_comm *c);
+int redio_comm_size(const redio_comm *c);
+const char *redio_comm_last_error(void);
+int redio_pfb_exchange(redio_comm *c, const void *d_grouped, void *d_out, const size_t *rows_per_rank, size_t chans_per_rank, void *stream);
+int redio_pfb_exchange_all(redio_comm *const *comms, int ndev, const void *const *d_grouped, void *const *d_out,
+                           const size_t *rows_per_rank, size_t chans_per_rank, void *const *streams);
+
 /* ---- carried history: the windowed plans above as STREAMS (BASELINE.json configs[1] "history carried") ----
  * redio_fir_enqueue & co. are stateless per call, like dsputils::convolve (dsputils.rs:30-32), which loses ntaps-1
  * outputs at every message seam.  A *_stream handle sits on a plan (not owned: destroy the stream first) and keeps the

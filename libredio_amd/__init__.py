@@ -12,7 +12,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_BUILD = os.path.join(_HERE, "_build")
+# REDIO_BUILD_DIR: measurement tools only (tools/ablate.sh loads timing-only experimental builds from another directory)
+_BUILD = os.environ.get("REDIO_BUILD_DIR") or os.path.join(_HERE, "_build")
 LIBREDIO = os.path.join(_BUILD, "libredio.so")
 LIBKISSFFT = os.path.join(_BUILD, "libkissfft.so")
 LIBSAMPLERATE = os.path.join(_BUILD, "libsamplerate.so")
@@ -143,6 +144,15 @@ def lib():
     _sig(L.redio_pfb_destroy, i, vp)
     _sig(L.redio_pfb_nrows, sz, vp, sz)
     _sig(L.redio_pfb_enqueue, i, vp, vp, sz, vp, i, vp)
+    _sig(L.redio_comm_unique_id, i, vp)
+    _sig(L.redio_comm_init_rank, i, C.POINTER(vp), i, i, vp)
+    _sig(L.redio_comm_init_all, i, C.POINTER(vp), i, C.POINTER(i))
+    _sig(L.redio_comm_destroy, i, vp)
+    _sig(L.redio_comm_rank, i, vp)
+    _sig(L.redio_comm_size, i, vp)
+    _sig(L.redio_comm_last_error, C.c_char_p)
+    _sig(L.redio_pfb_exchange, i, vp, vp, vp, psz, sz, vp)
+    _sig(L.redio_pfb_exchange_all, i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), psz, sz, C.POINTER(vp))
     _sig(L.redio_synth_iq, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _sig(L.redio_synth_f32, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _lib = L
@@ -199,4 +209,4 @@ def check(code, what="redio"):
 
 
 from . import bitfount, dsputils, kissfft, kpn_dev, plans, samplerate  # noqa: E402,F401
-from .plans import Chain, Channelizer, Fft, Fir, Graph, OverlapSave, Src, Stream, channelizer_all_to_all, current_stream, synth_f32, synth_iq  # noqa: E402,F401
+from .plans import Chain, Channelizer, Comm, Fft, Fir, Graph, OverlapSave, Src, Stream, channelizer_all_to_all, current_stream, synth_f32, synth_iq  # noqa: E402,F401

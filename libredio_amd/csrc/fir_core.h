@@ -14,6 +14,9 @@
 // Host-compilable (tests/emu).
 #pragma once
 #include "redio_device.h"
+#ifndef REDIO_EXP_ABLATE
+#define REDIO_EXP_ABLATE 0
+#endif
 #include <type_traits>
 
 namespace redio {
@@ -106,6 +109,10 @@ RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH],
         RD_PIN_SV(hb[c & 1][T::NT - 1], q[c & 1][0]);
         fir_static_for<CH>([&](auto I) { // the next chunk's samples (LDS) ...
             constexpr int i = (c + 1) * CH + I.value;
+#if REDIO_EXP_ABLATE == 1 // timing-only experiment (tools/ablate.sh), never in the product build: half the window reads
+            if constexpr (i < NRD && (I.value & 1)) q[(c + 1) & 1][I.value] = q[(c + 1) & 1][I.value - 1];
+            else
+#endif
             if constexpr (i < NRD) q[(c + 1) & 1][I.value] = xs4[base4 + G::lds_index(2 * i) / 2];
         });
         fir_static_for<T::NT>([&](auto J) { // ... and taps (scalar cache)
@@ -119,6 +126,9 @@ RD_HD void fir_chunks_v(Lds4Ptr xs4, int base4, TapPtr h, Q (&q)[2][CH],
                 const float2 x0 = make_float2(v.x, v.y), x1 = make_float2(v.z, v.w);
                 fir_static_for<R>([&](auto RR) {
                     constexpr int r = RR.value;
+#if REDIO_EXP_ABLATE == 2 // timing-only experiment: half the multiply-adds (two of the four accumulators)
+                    if constexpr (r & 1) return;
+#endif
                     constexpr int j0 = m - r * D, j1 = m + 1 - r * D;
                     if constexpr (j0 >= 0 && j0 < K) acc[r] = mac<FUSED>(x0, hb[c & 1][j0 - T::lo(c)], acc[r]);
                     if constexpr (j1 >= 0 && j1 < K && m + 1 < G::SPAN) acc[r] = mac<FUSED>(x1, hb[c & 1][j1 - T::lo(c)], acc[r]);

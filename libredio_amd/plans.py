@@ -338,6 +338,81 @@ def channelizer_all_to_all(grouped, group=None):
     return torch.view_as_complex(recv.reshape(sum(rows), cpg, 2))
 
 
+class Comm:
+    """redio_comm_* / redio_pfb_exchange: the channelizer's regrouping step through the C ABI (RCCL ncclSend/ncclRecv
+    inside one group) -- what a Rust or C++ kpn host calls.  channelizer_all_to_all above is the torch.distributed
+    twin (and the only form the gloo CPU tests can run)."""
+
+    def __init__(self, handle, rank, size):
+        self._h, self.rank, self.size = handle, rank, size
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        """One rank per process under torch.distributed.run: rank 0 makes the RCCL id, the process group carries the
+        128 bytes to the others (any backend), every rank joins on its current device."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(lib().redio_comm_unique_id(buf), "comm_unique_id")
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=0, group=group)
+        h = C.c_void_p()
+        check(lib().redio_comm_init_rank(C.byref(h), world, rank, C.create_string_buffer(box[0], 128)), "comm_init_rank")
+        return cls(h, rank, world)
+
+    @classmethod
+    def single(cls):
+        """A communicator of one rank on the current device (1-GPU boxes; the exchange degenerates to a copy to self)."""
+        buf = C.create_string_buffer(128)
+        check(lib().redio_comm_unique_id(buf), "comm_unique_id")
+        h = C.c_void_p()
+        check(lib().redio_comm_init_rank(C.byref(h), 1, 0, buf), "comm_init_rank")
+        return cls(h, 0, 1)
+
+    @classmethod
+    def init_all(cls, devices=None):
+        """Every visible device (or `devices`) as ranks of ONE process: returns the list of communicators."""
+        import torch
+        devs = list(range(torch.cuda.device_count())) if devices is None else list(devices)
+        hs = (C.c_void_p * len(devs))()
+        check(lib().redio_comm_init_all(hs, len(devs), (C.c_int * len(devs))(*devs)), "comm_init_all")
+        return [cls(C.c_void_p(hs[i]), i, len(devs)) for i in range(len(devs))]
+
+    def exchange(self, grouped, rows_per_rank, out=None):
+        """grouped: [size][my rows][channels per rank] complex64 on this rank's device -> [sum(rows)][channels per rank]."""
+        import torch
+        assert grouped.dtype == torch.complex64 and grouped.dim() == 3 and grouped.shape[0] == self.size
+        rows = [int(r) for r in rows_per_rank]
+        assert len(rows) == self.size and rows[self.rank] == grouped.shape[1]
+        cpg = grouped.shape[2]
+        if out is None:
+            out = torch.empty((sum(rows), cpg), dtype=torch.complex64, device=grouped.device)
+        check(lib().redio_pfb_exchange(self._h, _dev_ptr(grouped), _dev_ptr(out), (C.c_size_t * self.size)(*rows), cpg, current_stream()),
+              "pfb_exchange")
+        return out
+
+    def __del__(self, _safe_destroy=_safe_destroy):
+        if getattr(self, "_h", None):
+            _safe_destroy("redio_comm_destroy", self._h)
+            self._h = None
+
+
+def exchange_all(comms, grouped, rows_per_rank, outs=None):
+    """redio_pfb_exchange_all: all ranks of one process (Comm.init_all) in one RCCL group.  grouped[g] lives on device g."""
+    import torch
+    n = len(comms)
+    rows = [int(r) for r in rows_per_rank]
+    cpg = grouped[0].shape[2]
+    if outs is None:
+        outs = [torch.empty((sum(rows), cpg), dtype=torch.complex64, device=grouped[g].device) for g in range(n)]
+    streams = [C.c_void_p(torch.cuda.current_stream(grouped[g].device).cuda_stream) for g in range(n)]
+    check(lib().redio_pfb_exchange_all((C.c_void_p * n)(*[c._h for c in comms]), n, (C.c_void_p * n)(*[_dev_ptr(t) for t in grouped]),
+                                       (C.c_void_p * n)(*[_dev_ptr(t) for t in outs]), (C.c_size_t * n)(*rows), cpg,
+                                       (C.c_void_p * n)(*streams)), "pfb_exchange_all")
+    return outs
+
+
 class OverlapSave:
     """redio_ovsave_*: overlap-save FFT convolution (BASELINE.json configs[4]) with the semantics of
     dsputils::convolve (valid-mode correlation, dsputils.rs:30-32) on complex64 streams."""

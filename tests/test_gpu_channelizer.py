@@ -103,3 +103,40 @@ def test_exchange_runs_on_rccl_with_device_tensors(gpu, redio, oracle):
         assert np.array_equal(mine.cpu().numpy().view(np.uint32), want.view(np.uint32))
     finally:
         dist.destroy_process_group()
+
+
+def test_exchange_through_the_c_abi_on_every_visible_device(gpu, redio, oracle):
+    """redio_pfb_exchange / redio_pfb_exchange_all (RCCL ncclSend/ncclRecv in one group, no torch.distributed): the
+    time-sharded channelizer regrouped across however many devices this box shows, all ranks driven from ONE process
+    as the reference's thread-per-block host would (src/ratpak.rs:60-185).  The result on every rank equals the
+    oracle's channelizer of the whole stream, restricted to that rank's channels."""
+    from libredio_amd import plans, sharding
+    M, P = 64, 16
+    ndev = gpu.cuda.device_count()
+    while M % ndev:
+        ndev -= 1
+    h = oracle.lpf_corrected(M * P, 0.45 / M)
+    total_rows = 1500 + 7 * ndev
+    x = oracle.synth_iq(0x5EED0004, 0, M * total_rows)
+    want = oracle.pfb_channelizer(x, h, M, P, True)
+    comms = redio.Comm.init_all(range(ndev))
+    assert [c.rank for c in comms] == list(range(ndev)) and all(c.size == ndev for c in comms)
+    cpg = sharding.channelizer_exchange_layout(ndev, M)
+    grouped, rows = [], []
+    for g in range(ndev):
+        first, nout, nin = sharding.channelizer_time_shard(g, ndev, total_rows, P)
+        with gpu.cuda.device(g):
+            xs = gpu.from_numpy(x[M * first: M * (first + nin)]).cuda(g)
+            grouped.append(redio.Channelizer(h)(xs, ngroups=ndev))
+            rows.append(nout)
+            assert grouped[-1].shape == (ndev, nout, cpg)
+    outs = plans.exchange_all(comms, grouped, rows)
+    for g in range(ndev):
+        gpu.cuda.synchronize(g)
+        assert np.array_equal(bits(outs[g].cpu().numpy()), bits(np.ascontiguousarray(want[:, g * cpg:(g + 1) * cpg]))), g
+    # the one-rank-per-call entry point on rank 0's communicator when this box has a single device
+    if ndev == 1:
+        one = comms[0].exchange(grouped[0], rows)
+        gpu.cuda.synchronize()
+        assert np.array_equal(bits(one.cpu().numpy()), bits(want))
+    gpu.cuda.set_device(0)

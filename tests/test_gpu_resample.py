@@ -231,7 +231,7 @@ def test_c3_256_channels_two_messages(gpu, redio, oracle):
     K = 2 * len(pos)
     sum_h = 2 * ratio * np.abs(np.interp(pos, np.arange(half + 2), tab.astype(np.float64))).sum()
     bound = (K + 1) * 2.0 ** -24 * max(sum_h, 1.0) * np.abs(x).max()
-    total = 0
+    total = wtotal = 0
     for lo, hi in ((0, 150001), (150001, n)):
         a, ua = exact.process(d[:, lo:hi].contiguous(), ratio)
         b, ub = fast.process(d[:, lo:hi].contiguous(), ratio)
@@ -242,5 +242,8 @@ def test_c3_256_channels_two_messages(gpu, redio, oracle):
             err, want, wused = refs[c].process(x[c, lo:hi], ratio, int(ratio * (hi - lo) + 1.0))
             assert err == 0 and wused == ua
             assert np.array_equal(bits(an[c]), bits(want)), (c, lo, hi)
+        wtotal += len(want)
         assert (a - b).abs().max().item() <= bound
-    assert abs(total - int(n * ratio)) <= 2      # the output count law over the whole stream
+    # the output count over the whole stream: the oracle's, i.e. ratio * frames less the converter's start-up delay
+    # (half the stretched filter: the first outputs wait for input that has not arrived)
+    assert total == wtotal and 0 <= int(n * ratio) - total <= 64

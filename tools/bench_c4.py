@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
+                    help="cabi = redio_pfb_exchange (RCCL send/recv group through the C ABI); torch = all_to_all_single")
+    ap.add_argument("--check", action="store_true", help="compare this rank's regrouped rows with the oracle on a short stream and exit")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -54,9 +57,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / a.steps
 
+    use_cabi = a.exchange == "cabi" and a.backend == "nccl"
+    comm = R.Comm.from_torch_distributed() if use_cabi else None
+    mine_buf = torch.empty((world * nrows, cpg), dtype=torch.complex64, device="cuda")
+    exchange = (lambda g: comm.exchange(g, [nrows] * world, out=mine_buf)) if use_cabi else R.channelizer_all_to_all
+    if a.check:   # correctness half: a short stream, every rank against the oracle's channelizer of the WHOLE stream
+        import numpy as np
+        import oracle as O
+        total_rows = 2000 + 5 * world
+        xs = O.synth_iq(0x5EED0004, 0, M * total_rows)
+        want = O.pfb_channelizer(xs, h, M, P, True)
+        first, nout, nin = sharding.channelizer_time_shard(rank, world, total_rows, P)
+        g = plan(torch.from_numpy(xs[M * first: M * (first + nin)]).cuda(), ngroups=world)
+        rows = [sharding.channelizer_time_shard(q, world, total_rows, P)[1] for q in range(world)]
+        got = (comm.exchange(g, rows) if use_cabi else R.channelizer_all_to_all(g)).cpu().numpy()
+        ok = np.array_equal(got.view(np.uint32), np.ascontiguousarray(want[:, rank * cpg:(rank + 1) * cpg]).view(np.uint32))
+        flag = torch.tensor([int(ok)], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            print(json.dumps({"check": "channelizer exchange vs oracle", "n_gpus": world, "exchange": a.exchange, "ok": bool(flag.item())}))
+        dist.destroy_process_group()
+        sys.exit(0 if flag.item() else 1)
     t_analysis = timed(lambda: plan(x, ngroups=world, out=grouped))
-    t_both = timed(lambda: R.channelizer_all_to_all(plan(x, ngroups=world, out=grouped)))
-    mine = R.channelizer_all_to_all(grouped)
+    t_both = timed(lambda: exchange(plan(x, ngroups=world, out=grouped)))
+    mine = exchange(grouped)
     assert mine.shape == (world * nrows, cpg)
     if rank == 0:
         egress = nrows * (M - cpg) * 8                  # bytes this GPU sends to its peers per step
@@ -65,7 +89,8 @@ def main():
                           "analysis_GSps": world * n / t_analysis / 1e9, "analysis_plus_exchange_GSps": world * n / t_both / 1e9,
                           "ms_analysis": t_analysis * 1e3, "ms_analysis_plus_exchange": t_both * 1e3,
                           "exchange_egress_GBps_per_gpu": (egress / max(t_both - t_analysis, 1e-9) / 1e9) if world > 1 else None,
-                          "scaling": "weak", "collective": "all_to_all_single (%s)" % a.backend}))
+                          "scaling": "weak",
+                          "collective": "redio_pfb_exchange: RCCL ncclSend/ncclRecv group (C ABI)" if use_cabi else "all_to_all_single (%s)" % a.backend}))
     dist.destroy_process_group()
 
 
