@@ -320,6 +320,9 @@ int redio_src_process(redio_src *h, const void *d_in, long input_frames, long in
 /* host buffers, mono, synchronous: the body of the src_process drop-in (include/samplerate.h) */
 int redio_src_process_host(redio_src *h, const float *data_in, long input_frames, float *data_out, long output_frames,
                            double src_ratio, int end_of_input, long *input_frames_used, long *output_frames_gen);
+/* diagnostics: buffer-refill epochs of this handle served by the periodic-phase kernel (constant rational ratios such as
+ * 48000/44100 or 2.0: P sets of coefficients, LDS tiles) and by the general per-tap kernel; both bit-identical */
+int redio_src_path_counts(const redio_src *h, long *periodic, long *general);
 /* the coefficient table of a converter (coeffs_out may be NULL; it holds half_len + 2 floats) */
 int redio_src_table(int converter, float *coeffs_out, int *half_len, int *increment);
 

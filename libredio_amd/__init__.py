@@ -117,6 +117,7 @@ def lib():
     _sig(L.redio_src_process, i, vp, vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_double, i, pl, pl, vp)
     _sig(L.redio_src_process_host, i, vp, pf, C.c_long, pf, C.c_long, C.c_double, i, pl, pl)
     _sig(L.redio_src_table, i, i, pf, C.POINTER(i), C.POINTER(i))
+    _sig(L.redio_src_path_counts, i, vp, pl, pl)
     _sig(L.redio_fft_enqueue_strided, i, vp, vp, vp, sz, C.c_long, vp)
     _sig(L.redio_ovsave_create, i, C.POINTER(vp), pf, sz, i)
     _sig(L.redio_ovsave_destroy, i, vp)

@@ -95,6 +95,13 @@ struct redio_src {
     double *d_cl, *d_cr;
     int ncl, ncr;
     float2 *d_T2; int nm; double fast_scale; // packed f32 tap pairs of the polyphase path
+    // periodic-phase path (rational ratios): per-epoch tables [tap][phase] on the device, host copies kept until the call ends
+    double *d_pL, *d_pR; size_t pL_cap, pR_cap;
+    int *d_pint; // dpos | skipL | skipR, 256 each
+    int period_hint;
+    std::vector<std::vector<double>> keep_d;
+    std::vector<std::vector<int>> keep_i;
+    long periodic_launches, general_launches; // diagnostics (redio_src_path_counts)
     int mode;                                // REDIO_SRC_EXACT / REDIO_SRC_FAST
     int window_ok;                           // single-launch path enabled (off: one launch per buffer refill)
     size_t stage_in_cap, stage_out_cap;
@@ -142,6 +149,8 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
     s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0; s->host_stream = nullptr;
     s->fast_inc = 0; s->d_cl = s->d_cr = nullptr; s->ncl = s->ncr = 0;
+    s->d_pL = s->d_pR = nullptr; s->pL_cap = s->pR_cap = 0; s->d_pint = nullptr; s->period_hint = 0;
+    s->periodic_launches = s->general_launches = 0;
     s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
     s->h_coeffs = coeffs;
     long bl = lrint(2.5 * half / (inc * 1.0) * SRC_MAX_RATIO);
@@ -167,6 +176,7 @@ extern "C" int redio_src_destroy(redio_src *s)
     hipFree(s->d_stage_in); hipFree(s->d_stage_out);
     if (s->host_stream) hipStreamDestroy(s->host_stream);
     hipFree(s->d_cl); hipFree(s->d_cr); hipFree(s->d_T2);
+    hipFree(s->d_pL); hipFree(s->d_pR); hipFree(s->d_pint);
     delete s;
     return REDIO_OK;
 }
@@ -325,6 +335,108 @@ static int prepare_fast_taps(redio_src *f, int S, double scale)
     return REDIO_OK;
 }
 
+// ---- periodic-phase epochs: a constant rational ratio makes (start index, position step) repeat every P outputs ----
+// Checks, on the per-output values the library's recurrence just produced, that outputs first .. first+count-1 are
+// exactly periodic; builds the P sets of interpolated coefficients with the expression of calc_output_single (in
+// double) as tables [tap][phase]; launches src_sinc_periodic_kernel.  Returns 1 when it handled the epoch, 0 when the
+// epoch is not eligible (the general kernel then runs), an error code otherwise.
+static int try_periodic_epoch(redio_src *f, long first, long count, float *d_out, long out_stride, hipStream_t st)
+{
+    if (count < 128) return 0;
+    const int inc = f->h_inc[(size_t)first];
+    const double scale = f->h_scale[(size_t)first];
+    const int *pos = f->h_pos.data() + first, *start = f->h_start.data() + first;
+    for (long k = 1; k < count; ++k)
+        if (f->h_inc[(size_t)(first + k)] != inc || f->h_scale[(size_t)(first + k)] != scale || pos[k] < pos[k - 1]) return 0;
+    auto is_period = [&](int P) {
+        if (P < 1 || P > 256 || 2L * P > count) return false;
+        const int Q = pos[P] - pos[0];
+        for (long k = 0; k + P < count; ++k)
+            if (start[k + P] != start[k] || pos[k + P] - pos[k] != Q) return false;
+        return true;
+    };
+    int P = 0;
+    if (is_period(f->period_hint)) P = f->period_hint;
+    for (int c = 1; !P && c <= 256 && 2L * c <= count; ++c)
+        if (start[c] == start[0] && is_period(c)) P = c;
+    if (!P) return 0;
+    f->period_hint = P;
+    const int Q = pos[P] - pos[0];
+    const int maxf = f->coeff_half_len << SRC_SHIFT;
+    auto icoeff = [&](int filter_index) {
+        const double fraction = (double)(filter_index & ((1 << SRC_SHIFT) - 1)) * (1.0 / (double)(1 << SRC_SHIFT));
+        const int indx = filter_index >> SRC_SHIFT;
+        const float c0 = f->h_coeffs[(size_t)indx];
+        const float dc = f->h_coeffs[(size_t)indx + 1] - c0;
+        return (double)c0 + fraction * (double)dc;
+    };
+    // the taps each wing loop visits, per phase (far end first), and where its nearest tap lands
+    std::vector<std::vector<int>> Lf((size_t)P), Rf((size_t)P);
+    int NL = 0, NR = 0;
+    for (int p = 0; p < P; ++p) {
+        int fi = start[p];
+        int cc = (maxf - fi) / inc;
+        fi += cc * inc;
+        int di = -cc;
+        do { Lf[(size_t)p].push_back(fi); fi -= inc; ++di; } while (fi >= 0);
+        if (di - 1 != 0) return 0; // the nearest left tap must multiply x[pos] (always, unless start == inc)
+        fi = inc - start[p];
+        cc = (maxf - fi) / inc;
+        fi += cc * inc;
+        di = 1 + cc;
+        do { Rf[(size_t)p].push_back(fi); fi -= inc; --di; } while (fi > 0);
+        if (di + 1 != 1) return 0; // the nearest right tap must multiply x[pos + 1]
+        NL = NL > (int)Lf[(size_t)p].size() ? NL : (int)Lf[(size_t)p].size();
+        NR = NR > (int)Rf[(size_t)p].size() ? NR : (int)Rf[(size_t)p].size();
+    }
+    const int dpos_max = pos[P - 1] - pos[0];
+    int NT = 0; size_t lds = 0;
+    if (!src_periodic_shape(P, Q, NL, NR, dpos_max, 1, &NT, &lds)) return 0;
+    f->keep_d.emplace_back((size_t)NL * P, 0.0);
+    f->keep_d.emplace_back((size_t)NR * P, 0.0);
+    f->keep_i.emplace_back((size_t)3 * 256, 0);
+    std::vector<double> &L = f->keep_d[f->keep_d.size() - 2], &R = f->keep_d.back();
+    std::vector<int> &I = f->keep_i.back();
+    int maxskipL = 0, maxskipR = 0;
+    for (int p = 0; p < P; ++p) {
+        const int sl = NL - (int)Lf[(size_t)p].size(), sr = NR - (int)Rf[(size_t)p].size();
+        for (size_t t = 0; t < Lf[(size_t)p].size(); ++t) L[(size_t)(sl + (int)t) * P + p] = icoeff(Lf[(size_t)p][t]);
+        for (size_t t = 0; t < Rf[(size_t)p].size(); ++t) R[(size_t)(sr + (int)t) * P + p] = icoeff(Rf[(size_t)p][t]);
+        I[(size_t)p] = pos[p] - pos[0]; I[256 + (size_t)p] = sl; I[512 + (size_t)p] = sr;
+        maxskipL = maxskipL > sl ? maxskipL : sl;
+        maxskipR = maxskipR > sr ? maxskipR : sr;
+    }
+    if (L.size() > f->pL_cap) {
+        hipFree(f->d_pL); f->d_pL = nullptr; f->pL_cap = 0;
+        SRC_TRY(hipMalloc((void **)&f->d_pL, 2 * L.size() * sizeof(double)));
+        f->pL_cap = 2 * L.size();
+    }
+    if (R.size() > f->pR_cap) {
+        hipFree(f->d_pR); f->d_pR = nullptr; f->pR_cap = 0;
+        SRC_TRY(hipMalloc((void **)&f->d_pR, 2 * R.size() * sizeof(double)));
+        f->pR_cap = 2 * R.size();
+    }
+    if (!f->d_pint) SRC_TRY(hipMalloc((void **)&f->d_pint, 3 * 256 * sizeof(int)));
+    SRC_TRY(hipMemcpyAsync(f->d_pL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_pR, R.data(), R.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_pint, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    hipError_t e = launch_src_periodic(f->d_buf[f->cur], f->buf_stride, f->d_pL, f->d_pR, f->d_pint, f->d_pint + 256, f->d_pint + 512, P, Q, NL, NR,
+                                       maxskipL, maxskipR, dpos_max, pos[0], scale, d_out + first, out_stride, count, f->nchan, st);
+    if (e == hipErrorNotSupported) return 0;
+    if (e != hipSuccess) return hip_rc(e);
+    ++f->periodic_launches;
+    return 1;
+}
+
+// how many epochs of this handle ran through the periodic-phase kernel / the general per-tap kernel (tests, tools)
+extern "C" int redio_src_path_counts(const redio_src *s, long *periodic, long *general)
+{
+    if (!s) return REDIO_SRC_ERR_BAD_STATE;
+    if (periodic) *periodic = s->periodic_launches;
+    if (general) *general = s->general_launches;
+    return REDIO_OK;
+}
+
 // flush the outputs decided since the last refill: they all read the current buffer image
 static int flush_epoch(redio_src *f, long first, long count, float *d_out, long out_stride, hipStream_t st)
 {
@@ -350,6 +462,12 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
             }
         }
     }
+    if (f->window_ok) { // rational ratios: P sets of coefficients instead of one interpolation per tap
+        const int handled = try_periodic_epoch(f, first, count, d_out, out_stride, st);
+        if (handled == 1) return REDIO_OK;
+        if (handled != 0) return handled;
+    }
+    ++f->general_launches;
     SRC_TRY(hipMemcpyAsync(f->d_pos + first, f->h_pos.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
     SRC_TRY(hipMemcpyAsync(f->d_start + first, f->h_start.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
     SRC_TRY(hipMemcpyAsync(f->d_inc + first, f->h_inc.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
@@ -465,6 +583,7 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
     }
     int rc = ensure_scratch(f, (size_t)out_count);
     if (rc) return rc;
+    f->keep_d.clear(); f->keep_i.clear(); // tables of the previous call: its uploads completed when that call synchronised
     // the scratch upload of an earlier call on another stream must not be overwritten while in
     // flight: calls on one handle are serialised by the caller (one block thread per handle)
 

@@ -9,6 +9,11 @@ hipError_t launch_src_exact(const float *win, long win_stride, const float *coef
 hipError_t launch_src_uniform(const float *win, long win_stride, const double *cl_rev, int ncl, const double *cr_rev, int ncr,
                               int pos0, int S, double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s);
 size_t src_uniform_lds(int nt, int S, int cl, int cr);
+// periodic-phase epochs (src_kernels.hip): per-phase coefficient tables [tap][phase], P phases per Q input samples
+bool src_periodic_shape(int P, int Q, int NL, int NR, int dpos_max, int G, int *NT_out, size_t *lds_bytes);
+hipError_t launch_src_periodic(const float *win, long win_stride, const double *Lc, const double *Rc, const int *dpos, const int *skipL,
+                               const int *skipR, int P, int Q, int NL, int NR, int maxskipL, int maxskipR, int dpos_max, int pos0,
+                               double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s);
 hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,
                              const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, bool fast,
                              long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,

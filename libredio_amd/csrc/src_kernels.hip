@@ -78,6 +78,117 @@ hipError_t launch_src_exact(const float *win, long win_stride, const float *coef
     return hipGetLastError();
 }
 
+// ---- periodic-phase path: rational ratios whose (start index, position step) sequence repeats --------------
+// With a constant ratio p/q the fractional input position of output k + P equals that of output k (P outputs per
+// Q input samples: 160 / 147 for 44.1 -> 48 kHz, 2 / 1 for ratio 2.0, 3 / 10 for 0.3 ...), so only P different sets of
+// interpolated coefficients exist.  The host (src_host.hip, flush_epoch) verifies on the library's own per-output
+// recurrence that the epoch IS periodic and builds, per phase, the coefficient of every tap the library's two wing
+// loops would visit -- in double, with the library's expression -- as two tables [tap][phase].  A thread then owns
+// ONE phase and G outputs that many periods apart: per tap it loads one coefficient (coalesced across the phases)
+// and feeds G strictly ordered double accumulators from an LDS tile of the buffer image.  Same products in the
+// same order as src_sinc_exact_kernel: bit-identical; no per-tap table interpolation, samples read from LDS.
+struct SrcPeriodic {
+    const double *Lc;  // [NL][P] left wing, far end first; row NL-1 multiplies x[pos]
+    const double *Rc;  // [NR][P] right wing, far end first; row t multiplies x[pos + 1 + (NR-1) - t]
+    const int *dpos;   // [P] buffer position of phase p relative to phase 0 of the same period (non-decreasing)
+    const int *skipL;  // [P] leading rows of Lc / Rc that do not exist for this phase (its wing is shorter)
+    const int *skipR;
+    int P, Q, NL, NR, maxskipL, maxskipR, dpos_max;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void src_sinc_periodic_kernel(const float *__restrict__ win, long win_stride, SrcPeriodic t, int pos0, int NT,
+                                                                double scale, float *__restrict__ out, long out_stride, long nout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const long k0 = (long)blockIdx.x * G * NT; // a whole number of periods
+    const int periods = G * NT / t.P;
+    const long tile_base = (long)pos0 + (k0 / t.P) * t.Q - (t.NL - 1); // buffer index of xs[0]
+    const int span = (periods - 1) * t.Q + t.dpos_max + t.NL + t.NR + 1;
+    const float *row = win + (long)ch * win_stride;
+    for (int n = tid; n < span; n += 256) {
+        long a = tile_base + n; // rows past the image belong to outputs that do not exist (or to skipped taps)
+        a = a < 0 ? 0 : (a < win_stride ? a : win_stride - 1);
+        xs[n] = row[a];
+    }
+    __syncthreads();
+    if (tid >= NT) return;
+    const int p = tid % t.P, mg = tid / t.P, per_g = NT / t.P;
+    int base[G]; // xs index of x[pos] of item g
+    double l[G], r[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        base[g] = (mg + g * per_g) * t.Q + t.dpos[p] + (t.NL - 1);
+        l[g] = 0.0; r[g] = 0.0;
+    }
+    const int sl = t.skipL[p], sr = t.skipR[p];
+    const double *lc = t.Lc + p, *rc = t.Rc + p;
+    int tt = 0;
+    for (; tt < t.maxskipL; ++tt) {
+        const double c = lc[(long)tt * t.P];
+        if (tt >= sl)
+#pragma unroll
+            for (int g = 0; g < G; ++g) l[g] += c * (double)xs[base[g] - (t.NL - 1) + tt];
+    }
+#pragma unroll 4
+    for (; tt < t.NL; ++tt) {
+        const double c = lc[(long)tt * t.P];
+#pragma unroll
+        for (int g = 0; g < G; ++g) l[g] += c * (double)xs[base[g] - (t.NL - 1) + tt];
+    }
+    for (tt = 0; tt < t.maxskipR; ++tt) {
+        const double c = rc[(long)tt * t.P];
+        if (tt >= sr)
+#pragma unroll
+            for (int g = 0; g < G; ++g) r[g] += c * (double)xs[base[g] + 1 + (t.NR - 1) - tt];
+    }
+#pragma unroll 4
+    for (; tt < t.NR; ++tt) {
+        const double c = rc[(long)tt * t.P];
+#pragma unroll
+        for (int g = 0; g < G; ++g) r[g] += c * (double)xs[base[g] + 1 + (t.NR - 1) - tt];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const long k = k0 + tid + (long)g * NT;
+        if (k < nout) out[(long)ch * out_stride + k] = (float)(scale * (l[g] + r[g]));
+    }
+}
+
+// P phases (<= 256), Q input samples per period; *lds_bytes / *NT_out describe the launch; false if a tile cannot fit
+bool src_periodic_shape(int P, int Q, int NL, int NR, int dpos_max, int G, int *NT_out, size_t *lds_bytes)
+{
+    if (P < 1 || P > 256) return false;
+    const int NT = P * (256 / P);
+    const long span = (long)(G * NT / P - 1) * Q + dpos_max + NL + NR + 1;
+    if (span * 4 > 60 * 1024) return false;
+    *NT_out = NT; *lds_bytes = (size_t)span * 4;
+    return true;
+}
+
+hipError_t launch_src_periodic(const float *win, long win_stride, const double *Lc, const double *Rc, const int *dpos, const int *skipL,
+                               const int *skipR, int P, int Q, int NL, int NR, int maxskipL, int maxskipR, int dpos_max, int pos0,
+                               double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s)
+{
+    if (nout <= 0 || nchan <= 0) return hipSuccess;
+    const SrcPeriodic t = {Lc, Rc, dpos, skipL, skipR, P, Q, NL, NR, maxskipL, maxskipR, dpos_max};
+    int NT = 0; size_t lds = 0;
+    const int Gs[3] = {8, 4, 1};
+    for (int i = 0; i < 3; ++i) {
+        const int G = Gs[i];
+        if (!src_periodic_shape(P, Q, NL, NR, dpos_max, G, &NT, &lds)) continue;
+        if (G > 1 && nout < (long)G * NT) continue; // short epochs: less work per thread, more workgroups
+        const dim3 grid((unsigned)((nout + (long)G * NT - 1) / ((long)G * NT)), (unsigned)nchan);
+        if (G == 8) hipLaunchKernelGGL(src_sinc_periodic_kernel<8>, grid, dim3(256), lds, s, win, win_stride, t, pos0, NT, scale, out, out_stride, nout);
+        else if (G == 4) hipLaunchKernelGGL(src_sinc_periodic_kernel<4>, grid, dim3(256), lds, s, win, win_stride, t, pos0, NT, scale, out, out_stride, nout);
+        else hipLaunchKernelGGL(src_sinc_periodic_kernel<1>, grid, dim3(256), lds, s, win, win_stride, t, pos0, NT, scale, out, out_stride, nout);
+        return hipGetLastError();
+    }
+    return hipErrorNotSupported;
+}
+
 // ---- the stream window of a single-launch call: [old buffer image | new input] by absolute index
 struct SrcWindow {
     const float *old_img; long old_stride; // [nchan][old_stride]

@@ -221,6 +221,12 @@ class Src:
     def reset(self):
         check(lib().redio_src_reset(self._h), "src_reset")
 
+    def path_counts(self):
+        """(epochs through the periodic-phase kernel, epochs through the general per-tap kernel) so far."""
+        a, b = C.c_long(0), C.c_long(0)
+        check(lib().redio_src_path_counts(self._h, C.byref(a), C.byref(b)), "src_path_counts")
+        return a.value, b.value
+
     def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_src_destroy", self._h)

@@ -247,3 +247,49 @@ def test_c3_256_channels_two_messages(gpu, redio, oracle):
     # the output count over the whole stream: the oracle's, i.e. ratio * frames less the converter's start-up delay
     # (half the stretched filter: the first outputs wait for input that has not arrived)
     assert total == wtotal and 0 <= int(n * ratio) - total <= 64
+
+
+@pytest.mark.parametrize("nch", [1, 5])
+@pytest.mark.parametrize("ratio,conv,periodic", [(48000 / 44100, 1, True), (2.0, 1, True), (1.5, 1, True), (0.3, 1, True), (4 / 3, 2, True),
+                                                 (44100 / 48000, 0, True), (0.75, 1, True), (0.0213, 1, False), (3.7, 1, None)])
+def test_rational_ratios_take_the_periodic_phase_kernel_bit_exactly(gpu, redio, oracle, ratio, conv, periodic, nch):
+    """samplerate::resample takes any ratio: f64 (samplerate.rs:59).  A constant rational ratio makes the per-output
+    (filter start index, position step) repeat every P outputs; those epochs run src_sinc_periodic_kernel (P sets of
+    coefficients, LDS tiles) instead of the per-tap interpolating kernel.  Same bits as the literal one-launch-per-refill
+    schedule (EPOCHS) and as the oracle, same counts, same carried state across messages of awkward lengths."""
+    n = 130000
+    x = np.stack([oracle.synth_f32(700 + c, 0, n) for c in range(nch)])
+    d = gpu.from_numpy(x).cuda()
+    new, lit = redio.Src(nch, conv), redio.Src(nch, conv, mode=redio.Src.EPOCHS)
+    refs = [oracle.Resampler(conv) for _ in range(nch)]
+    for lo, hi in ((0, 50000), (50000, 50001), (50001, 50120), (50120, n)):
+        cap = int(ratio * (hi - lo) + 1.0)
+        a, ua = new.process(d[:, lo:hi].contiguous(), ratio, output_frames=cap)
+        b, ub = lit.process(d[:, lo:hi].contiguous(), ratio, output_frames=cap)
+        assert ua == ub and a.shape == b.shape
+        an = a.cpu().numpy()
+        assert np.array_equal(bits(an), bits(b.cpu().numpy())), (ratio, lo, hi)
+        for c in range(nch):
+            err, want, wused = refs[c].process(x[c, lo:hi], ratio, cap)
+            assert err == 0 and wused == ua and np.array_equal(bits(an[c]), bits(want)), (ratio, c, lo, hi)
+    per, gen = new.path_counts()
+    if periodic is True:
+        assert per > 0 and per >= gen, (per, gen)     # the long epochs are periodic; only short leftovers may run per tap
+    elif periodic is False:
+        assert per == 0 and gen > 0
+    assert lit.path_counts()[0] == 0
+
+
+def test_periodic_path_then_ratio_change_and_flush(gpu, redio, oracle):
+    # a periodic message, then a varying-ratio one (general kernel), then end_of_input on a periodic ratio again
+    n = 120000
+    x = oracle.synth_f32(78, 0, n)
+    d = gpu.from_numpy(x[None, :]).cuda()
+    plan, ref = redio.Src(1, 1), oracle.Resampler(1)
+    for lo, hi, r, eoi in ((0, 50000, 1.25, 0), (50000, 80000, 1.6, 0), (80000, n, 1.6, 1)):
+        cap = int(r * (hi - lo) + 1.0) + 400
+        got, used = plan.process(d[:, lo:hi].contiguous(), r, output_frames=cap, end_of_input=bool(eoi))
+        err, want, wused = ref.process(x[lo:hi], r, cap, bool(eoi))
+        assert err == 0 and used == wused and got.shape[1] == len(want)
+        assert np.array_equal(bits(got.cpu().numpy()[0]), bits(want)), (lo, hi, r)
+    assert plan.path_counts()[0] > 0

@@ -77,7 +77,19 @@ if "c3" in which or "c3big" in which:
             out, used = plan.process(x, 0.02)
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         b = nch * frames * 4 * (1 + 0.02)
-        print(f"C3 resample 1/50 x{nch} ch, {frames} frames each ({name}): {best*1e3:.2f} ms  {nch*frames/best/1e9:.2f} GS/s  {b/best/1e9:.0f} GB/s algorithmic ({b/best/8e12:.1%} of 8 TB/s)")
+        # the binding roofline (report min(HBM, VALU)): EXACT does v_cvt_f64_f32 + v_mul_f64 + v_add_f64 per tap and
+        # lane, 3 instructions x 4 issue cycles per wave64 (f64 vector peak = half the f32 rate), on 1024 SIMDs at 2.4 GHz;
+        # FAST does one v_pk_fma_f32 per two taps (4 cycles).  Taps per output: both wings of the stretched filter.
+        tab_half, tab_inc = 22438 - 2, 491
+        taps_per_out = 2 * int(tab_half / (tab_inc * 0.02)) + 1
+        tap_waves = nch * frames * 0.02 * taps_per_out / 64
+        cyc = 12 if mode != R.Src.FAST else 2
+        t_valu = tap_waves * cyc / 1024 / 2.4e9
+        t_hbm = b / 8e12
+        bound = "VALU f64" if mode != R.Src.FAST else "VALU f32"
+        print(f"C3 resample 1/50 x{nch} ch, {frames} frames each ({name}): {best*1e3:.2f} ms  {nch*frames/best/1e9:.2f} GS/s  {b/best/1e9:.0f} GB/s algorithmic "
+              f"({b/best/8e12:.1%} of 8 TB/s) | rooflines: HBM {t_hbm*1e3:.3f} ms, {bound} {t_valu*1e3:.3f} ms ({taps_per_out} taps/output, {cyc} issue cycles per tap-wave) "
+              f"-> binding = {bound if t_valu > t_hbm else 'HBM'}, achieved {max(t_valu, t_hbm)/best:.1%} of it")
 if "c5" in which or "c5only" in which:
     for k in ((8193, 127) if "c5" in which else (8193,)):
         taps = R.dsputils.lpf_corrected(k, 0.08)
@@ -164,13 +176,18 @@ if "srcgen" in which:
     import time
     nch, frames = 64, 1 << 18
     x = torch.stack([R.synth_f32(100 + c, 0, frames) for c in range(nch)])
-    for ratio in (0.02, 0.0213, 0.5, 48000 / 44100, 2.0):
-        plan = R.Src(nch, 1)
-        plan.process(x, ratio)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        out, used = plan.process(x, ratio)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"resample ratio {ratio:.5f} x{nch} ch, {frames} frames: {dt*1e3:.2f} ms  {nch*used/dt/1e9:.3f} GS/s in, {out.shape[1]} out per channel")
+    for ratio in (0.02, 0.0213, 0.5, 48000 / 44100, 2.0, 1.5, 0.3):
+        for name, mode in (("default", R.Src.EXACT), ("per-refill general kernel", R.Src.EPOCHS)):
+            plan = R.Src(nch, 1, mode=mode)
+            plan.process(x, ratio)
+            best = 1e9
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                out, used = plan.process(x, ratio)
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            per, gen = plan.path_counts()
+            print(f"resample ratio {ratio:.5f} x{nch} ch, {frames} frames ({name}; epochs periodic/general {per}/{gen}): {best*1e3:.2f} ms  "
+                  f"{nch*used/best/1e9:.3f} GS/s in, {best*1e9/(nch*used):.3f} ns per input frame, {out.shape[1]} out per channel")
 if "c4gen" in which:
     for M, P in ((64, 16), (32, 16), (128, 16), (256, 8), (1024, 4), (64, 12)):
         h = R.dsputils.lpf_corrected(M * P, 0.45 / M)
