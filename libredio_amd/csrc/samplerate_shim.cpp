@@ -13,10 +13,9 @@ extern "C" SRC_STATE *src_new(int converter_type, int channels, int *error)
 {
     if (error) *error = 0;
     if (channels < 1) { if (error) *error = REDIO_SRC_ERR_BAD_CHANNEL_COUNT; return NULL; }
-    if (channels != 1) { if (error) *error = REDIO_SRC_ERR_BAD_CHANNEL_COUNT; return NULL; } // mono only (samplerate.rs:61)
     SRC_STATE *st = (SRC_STATE *)calloc(1, sizeof(SRC_STATE));
     if (!st) { if (error) *error = REDIO_SRC_ERR_MALLOC_FAILED; return NULL; }
-    int rc = redio_src_create(&st->h, converter_type, 1);
+    int rc = redio_src_create(&st->h, converter_type, channels); // the reference asks for (1, 1) (samplerate.rs:61)
     if (rc != REDIO_OK) {
         if (error) *error = rc > 0 ? rc : REDIO_SRC_ERR_MALLOC_FAILED; // a HIP failure has no libsamplerate code
         free(st);
@@ -55,6 +54,8 @@ extern "C" const char *src_get_name(int c)
     case 0: return "Best Sinc Interpolator";
     case 1: return "Medium Sinc Interpolator";
     case 2: return "Fastest Sinc Interpolator";
+    case 3: return "ZOH Interpolator";
+    case 4: return "Linear Interpolator";
     default: return NULL;
     }
 }
@@ -64,6 +65,8 @@ extern "C" const char *src_get_description(int c)
     case 0: return "Band limited sinc interpolation, best quality class (MI355X, libredio table).";
     case 1: return "Band limited sinc interpolation, medium quality class (MI355X, libredio table).";
     case 2: return "Band limited sinc interpolation, fastest class (MI355X, libredio table).";
+    case 3: return "Zero order hold interpolator, very fast, poor quality.";
+    case 4: return "Linear interpolator, very fast, poor quality.";
     default: return NULL;
     }
 }
@@ -79,7 +82,7 @@ extern "C" const char *src_strerror(int error)
     case REDIO_SRC_ERR_BAD_DATA_PTR: return "SRC_DATA->data_out or SRC_DATA->data_in is NULL.";
     case REDIO_SRC_ERR_BAD_SRC_RATIO: return "SRC ratio outside [1/256, 256] range.";
     case REDIO_SRC_ERR_BAD_CONVERTER: return "Bad converter number.";
-    case REDIO_SRC_ERR_BAD_CHANNEL_COUNT: return "Channel count must be >= 1 (this build: exactly 1).";
+    case REDIO_SRC_ERR_BAD_CHANNEL_COUNT: return "Channel count must be >= 1.";
     case REDIO_SRC_ERR_DATA_OVERLAP: return "Input and output data arrays overlap.";
     case REDIO_SRC_ERR_SINC_PREPARE_DATA_BAD_LEN: return "Internal error : Bad length in prepare_data ().";
     case REDIO_SRC_ERR_BAD_INTERNAL_STATE: return "Error : Someone is trampling on my internal state.";

@@ -102,6 +102,9 @@ struct redio_src {
     std::vector<std::vector<double>> keep_d;
     std::vector<std::vector<int>> keep_i;
     long periodic_launches, general_launches; // diagnostics (redio_src_path_counts)
+    // converters 3 / 4 (zero-order hold, linear): the value carried from the previous call, per channel, and the reset flag
+    float *d_last; int zl_reset;
+    float *d_rows_in, *d_rows_out; size_t rows_in_cap, rows_out_cap; // interleaved host form, nchan > 1: de-interleaved rows
     int mode;                                // REDIO_SRC_EXACT / REDIO_SRC_FAST
     int window_ok;                           // single-launch path enabled (off: one launch per buffer refill)
     size_t stage_in_cap, stage_out_cap;
@@ -122,6 +125,12 @@ extern "C" int redio_src_reset(redio_src *s)
     SRC_TRY(hipSetDevice(s->device));
     s->last_ratio = 0.0;
     s->last_position = 0.0;
+    if (s->converter >= 3) { // zoh_reset / linear_reset
+        s->zl_reset = 1;
+        SRC_TRY(hipMemset(s->d_last, 0, (size_t)s->nchan * sizeof(float)));
+        SRC_TRY(hipStreamSynchronize(nullptr));
+        return REDIO_OK;
+    }
     s->b_current = s->b_end = 0;
     s->b_real_end = -1;
     s->cur = 0;
@@ -138,12 +147,14 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     if (nchan < 1) return REDIO_SRC_ERR_BAD_CHANNEL_COUNT;
     std::vector<float> coeffs;
     int half = 0, inc = 0;
-    if (!src_make_table(converter, coeffs, half, inc)) return REDIO_SRC_ERR_BAD_CONVERTER; // ZOH / linear: not built
+    const bool zl = converter == 3 || converter == 4; // SRC_ZERO_ORDER_HOLD / SRC_LINEAR (samplerate.rs:29-30): no table
+    if (!zl && !src_make_table(converter, coeffs, half, inc)) return REDIO_SRC_ERR_BAD_CONVERTER;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return REDIO_ERR_NO_DEVICE;
     redio_src *s = new (std::nothrow) redio_src();
     if (!s) return REDIO_ERR_NOMEM;
     s->device = dev; s->converter = converter; s->nchan = nchan;
+    s->d_last = nullptr; s->zl_reset = 1; s->d_rows_in = s->d_rows_out = nullptr; s->rows_in_cap = s->rows_out_cap = 0;
     s->coeff_half_len = half; s->index_inc = inc;
     s->d_coeffs = nullptr; s->d_buf[0] = s->d_buf[1] = nullptr;
     s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
@@ -153,6 +164,15 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->periodic_launches = s->general_launches = 0;
     s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
     s->h_coeffs = coeffs;
+    if (zl) {
+        s->b_len = 0; s->buf_stride = 0;
+        hipError_t ez = hipMalloc((void **)&s->d_last, (size_t)nchan * sizeof(float));
+        if (ez != hipSuccess) { redio_src_destroy(s); return hip_rc(ez); }
+        const int rcz = redio_src_reset(s);
+        if (rcz) { redio_src_destroy(s); return rcz; }
+        *h = s;
+        return REDIO_OK;
+    }
     long bl = lrint(2.5 * half / (inc * 1.0) * SRC_MAX_RATIO);
     if (bl < 4096) bl = 4096;
     s->b_len = (int)bl;
@@ -177,6 +197,7 @@ extern "C" int redio_src_destroy(redio_src *s)
     if (s->host_stream) hipStreamDestroy(s->host_stream);
     hipFree(s->d_cl); hipFree(s->d_cr); hipFree(s->d_T2);
     hipFree(s->d_pL); hipFree(s->d_pR); hipFree(s->d_pint);
+    hipFree(s->d_last); hipFree(s->d_rows_in); hipFree(s->d_rows_out);
     delete s;
     return REDIO_OK;
 }
@@ -562,6 +583,62 @@ static int try_uniform_window(redio_src *f, const SrcInput &in, long in_count, f
     return 1;
 }
 
+// zoh_vari_process / linear_vari_process (src_zoh.c, src_linear.c) on device rows: the recurrence on the host in double,
+// the samples on the device.  All channels share the per-output (index, fraction); frame units throughout.
+static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long input_frames, float *d_out, long out_stride, long output_frames,
+                           double src_ratio_arg, long *in_used_out, long *out_gen_out, hipStream_t st)
+{
+    const bool lin = f->converter == 4;
+    if (input_frames <= 0) return REDIO_OK;
+    if (f->zl_reset) { // just reset: the value "before" the stream is its first frame
+        SRC_TRY(launch_src_copy_rows(d_in, in_stride, 0, f->d_last, 1, 0, 1, f->nchan, st));
+        f->zl_reset = 0;
+    }
+    int rc = ensure_scratch(f, (size_t)output_frames);
+    if (rc) return rc;
+    const long in_count = input_frames, out_count = output_frames;
+    long in_used = 0, out_gen = 0;
+    double src_ratio = f->last_ratio, input_index = f->last_position, rem;
+    while (input_index < 1.0 && out_gen < out_count) {
+        if (lin ? (in_used + (1.0 + input_index) >= in_count) : (in_used + input_index >= in_count)) break;
+        if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
+            src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
+        f->h_pos[(size_t)out_gen] = -1;
+        f->h_scale[(size_t)out_gen] = input_index;
+        ++out_gen;
+        input_index += 1.0 / src_ratio;
+    }
+    rem = fmod_one(input_index);
+    in_used += lrint(input_index - rem);
+    input_index = rem;
+    while (out_gen < out_count && (lin ? (in_used + input_index < in_count) : (in_used + input_index <= in_count))) {
+        if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
+            src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
+        f->h_pos[(size_t)out_gen] = (int)(in_used - 1);
+        f->h_scale[(size_t)out_gen] = input_index;
+        ++out_gen;
+        input_index += 1.0 / src_ratio;
+        rem = fmod_one(input_index);
+        in_used += lrint(input_index - rem);
+        input_index = rem;
+    }
+    if (in_used > in_count) {
+        input_index += (double)(in_used - in_count);
+        in_used = in_count;
+    }
+    if (out_gen > 0) {
+        SRC_TRY(hipMemcpyAsync(f->d_pos, f->h_pos.data(), (size_t)out_gen * sizeof(int), hipMemcpyHostToDevice, st));
+        SRC_TRY(hipMemcpyAsync(f->d_scale, f->h_scale.data(), (size_t)out_gen * sizeof(double), hipMemcpyHostToDevice, st));
+        SRC_TRY(launch_src_zoh_linear(d_in, in_stride, f->d_last, f->d_pos, f->d_scale, d_out, out_stride, out_gen, f->nchan, lin, st));
+    }
+    f->last_position = input_index;
+    if (in_used > 0) SRC_TRY(launch_src_copy_rows(d_in, in_stride, in_used - 1, f->d_last, 1, 0, 1, f->nchan, st));
+    f->last_ratio = src_ratio;
+    if (in_used_out) *in_used_out = in_used;
+    if (out_gen_out) *out_gen_out = out_gen;
+    return REDIO_OK;
+}
+
 // src_process + sinc_mono_vari_process; outputs land in d_out[nchan][out_stride]
 static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames, float *d_out, long out_stride, long output_frames,
                             double src_ratio_arg, int end_of_input, long *in_used_out, long *out_gen_out, hipStream_t st)
@@ -570,6 +647,10 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
     if (input_frames < 0) input_frames = 0;
     if (output_frames < 0) output_frames = 0;
     if (f->last_ratio < (1.0 / SRC_MAX_RATIO)) f->last_ratio = src_ratio_arg;
+    if (f->converter >= 3) {
+        if (!in.dev && input_frames > 0) return REDIO_SRC_ERR_BAD_DATA_PTR;
+        return zoh_linear_impl(f, in.dev, in.in_stride, input_frames, d_out, out_stride, output_frames, src_ratio_arg, in_used_out, out_gen_out, st);
+    }
 
     const long in_count = input_frames, out_count = output_frames;
     long in_used = 0, out_gen = 0;
@@ -599,32 +680,53 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
     const double terminate = 1.0 / src_ratio + 1e-20;
     const double fp_one = (double)(1 << SRC_SHIFT);
 
+    // The per-output recurrence below is the library's, value for value; it runs once for ALL channels.  Two things are
+    // rewritten without changing any result: x % b_len as a conditional subtraction (the operands are below 2 * b_len), and
+    // the quantities that only depend on the ratio are formed once when the ratio does not vary inside the call (the
+    // library recomputes the same expressions from the same operands for every output).
+    const bool vary = out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-10;
+    auto wrap = [&](int x) { while (x >= f->b_len) x -= f->b_len; return x; };
+    double float_increment = f->index_inc * (src_ratio < 1.0 ? src_ratio : 1.0);
+    int inc_fp = (int)lrint(float_increment * fp_one);
+    double scale = float_increment / f->index_inc;
+    double step = 1.0 / src_ratio;
     long epoch_first = 0;
     while (out_gen < out_count) {
-        int samples_in_hand = (f->b_end - f->b_current + f->b_len) % f->b_len;
+        int samples_in_hand = wrap(f->b_end - f->b_current + f->b_len);
         if (samples_in_hand <= half) {
             rc = flush_epoch(f, epoch_first, out_gen - epoch_first, d_out, out_stride, st); // before the image changes
             if (rc) return rc;
             epoch_first = out_gen;
             rc = prepare_data(f, in, in_count, in_used, end_of_input, half, st);
             if (rc) return rc;
-            samples_in_hand = (f->b_end - f->b_current + f->b_len) % f->b_len;
+            samples_in_hand = wrap(f->b_end - f->b_current + f->b_len);
             if (samples_in_hand <= half) break;
         }
         if (f->b_real_end >= 0) {
             if (f->b_current + input_index + terminate > f->b_real_end) break;
         }
-        if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-10)
+        if (vary) {
             src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
-        const double float_increment = f->index_inc * (src_ratio < 1.0 ? src_ratio : 1.0);
-        f->h_inc[(size_t)out_gen] = (int)lrint(float_increment * fp_one);
-        f->h_start[(size_t)out_gen] = (int)lrint(input_index * float_increment * fp_one);
-        f->h_scale[(size_t)out_gen] = float_increment / f->index_inc;
-        f->h_pos[(size_t)out_gen] = f->b_current;
+            float_increment = f->index_inc * (src_ratio < 1.0 ? src_ratio : 1.0);
+            inc_fp = (int)lrint(float_increment * fp_one);
+            scale = float_increment / f->index_inc;
+            step = 1.0 / src_ratio;
+        }
+        int start_fp = (int)lrint(input_index * float_increment * fp_one);
+        int at = f->b_current;
+        // a fractional position that rounds up to a whole increment is the next sample at phase zero: the two wing loops
+        // then visit the same taps and the same samples in the same order (left: indices inc*(cc+1) .. 0 over x[at-cc .. at+1],
+        // right: cc'*inc .. inc over x[at+1+cc' .. at+2]), so the output is the same bits; writing it that way keeps
+        // rational ratios (1.5, 48000/44100 ...) exactly periodic for the periodic-phase kernel
+        if (start_fp == inc_fp) { start_fp = 0; at += 1; }
+        f->h_inc[(size_t)out_gen] = inc_fp;
+        f->h_start[(size_t)out_gen] = start_fp;
+        f->h_scale[(size_t)out_gen] = scale;
+        f->h_pos[(size_t)out_gen] = at;
         ++out_gen;
-        input_index += 1.0 / src_ratio;
+        input_index += step;
         rem = fmod_one(input_index);
-        f->b_current = (f->b_current + (int)lrint(input_index - rem)) % f->b_len;
+        f->b_current = wrap(f->b_current + (int)lrint(input_index - rem));
         input_index = rem;
     }
     rc = flush_epoch(f, epoch_first, out_gen - epoch_first, d_out, out_stride, st);
@@ -655,48 +757,72 @@ extern "C" int redio_src_process(redio_src *s, const void *d_in, long input_fram
     return hip_rc(e);
 }
 
-// host-buffer, mono: the body of the src_process drop-in (samplerate_shim.cpp)
+// host buffers, interleaved frames (nchan >= 1), synchronous: the body of the src_process drop-in (samplerate_shim.cpp).
+// Channels are independent streams: the interleaved message is split into rows on the device, every row runs as
+// the mono converter does, and the outputs are interleaved again.
 extern "C" int redio_src_process_host(redio_src *s, const float *data_in, long input_frames, float *data_out, long output_frames,
                                       double src_ratio, int end_of_input, long *input_frames_used, long *output_frames_gen)
 {
     if (input_frames_used) *input_frames_used = 0;
     if (output_frames_gen) *output_frames_gen = 0;
     if (!s) return REDIO_SRC_ERR_BAD_STATE;
-    if (s->nchan != 1) return REDIO_SRC_ERR_BAD_CHANNEL_COUNT;
     if (!data_in || !data_out) return REDIO_SRC_ERR_BAD_DATA_PTR;
     if (is_bad_src_ratio(src_ratio)) return REDIO_SRC_ERR_BAD_SRC_RATIO;
     if (input_frames < 0) input_frames = 0;
     if (output_frames < 0) output_frames = 0;
+    const long nch = s->nchan;
     if (data_in < data_out) {
-        if (data_in + input_frames > data_out) return REDIO_SRC_ERR_DATA_OVERLAP;
-    } else if (data_out + output_frames > data_in) {
+        if (data_in + input_frames * nch > data_out) return REDIO_SRC_ERR_DATA_OVERLAP;
+    } else if (data_out + output_frames * nch > data_in) {
         return REDIO_SRC_ERR_DATA_OVERLAP;
     }
     SRC_TRY(hipSetDevice(s->device));
     if (!s->host_stream) SRC_TRY(hipStreamCreateWithFlags(&s->host_stream, hipStreamNonBlocking));
     hipStream_t st = s->host_stream;
-    if ((size_t)output_frames > s->stage_out_cap) {
+    const size_t out_elems = (size_t)output_frames * nch, in_elems = (size_t)input_frames * nch;
+    if (out_elems > s->stage_out_cap) {
         hipFree(s->d_stage_out);
         s->d_stage_out = nullptr; s->stage_out_cap = 0;
-        SRC_TRY(hipMalloc((void **)&s->d_stage_out, ((size_t)output_frames + 1024) * sizeof(float)));
-        s->stage_out_cap = (size_t)output_frames + 1024;
+        SRC_TRY(hipMalloc((void **)&s->d_stage_out, (out_elems + 1024) * sizeof(float)));
+        s->stage_out_cap = out_elems + 1024;
     }
-    SrcInput in = {data_in, nullptr, 0};
+    if (nch > 1 && out_elems > s->rows_out_cap) {
+        hipFree(s->d_rows_out);
+        s->d_rows_out = nullptr; s->rows_out_cap = 0;
+        SRC_TRY(hipMalloc((void **)&s->d_rows_out, (out_elems + 1024) * sizeof(float)));
+        s->rows_out_cap = out_elems + 1024;
+    }
+    SrcInput in = {nch == 1 ? data_in : nullptr, nullptr, 0};
     if (input_frames > 0) { // one upload of the whole message; the refills then copy on the device
-        if ((size_t)input_frames > s->stage_in_cap) {
+        if (in_elems > s->stage_in_cap) {
             hipFree(s->d_stage_in);
             s->d_stage_in = nullptr; s->stage_in_cap = 0;
-            SRC_TRY(hipMalloc((void **)&s->d_stage_in, ((size_t)input_frames + 1024) * sizeof(float)));
-            s->stage_in_cap = (size_t)input_frames + 1024;
+            SRC_TRY(hipMalloc((void **)&s->d_stage_in, (in_elems + 1024) * sizeof(float)));
+            s->stage_in_cap = in_elems + 1024;
         }
-        SRC_TRY(hipMemcpyAsync(s->d_stage_in, data_in, (size_t)input_frames * sizeof(float), hipMemcpyHostToDevice, st));
-        in = {nullptr, s->d_stage_in, (long)s->stage_in_cap};
+        SRC_TRY(hipMemcpyAsync(s->d_stage_in, data_in, in_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        if (nch == 1) {
+            in = {nullptr, s->d_stage_in, (long)s->stage_in_cap};
+        } else {
+            if (in_elems > s->rows_in_cap) {
+                hipFree(s->d_rows_in);
+                s->d_rows_in = nullptr; s->rows_in_cap = 0;
+                SRC_TRY(hipMalloc((void **)&s->d_rows_in, (in_elems + 1024) * sizeof(float)));
+                s->rows_in_cap = in_elems + 1024;
+            }
+            SRC_TRY(launch_src_interleave(s->d_stage_in, s->d_rows_in, input_frames, input_frames, (int)nch, true, st));
+            in = {nullptr, s->d_rows_in, input_frames};
+        }
     }
     long used = 0, gen = 0;
-    int rc = src_process_impl(s, in, input_frames, s->d_stage_out, (long)s->stage_out_cap, output_frames, src_ratio, end_of_input,
-                              &used, &gen, st);
+    float *d_rows = nch == 1 ? s->d_stage_out : s->d_rows_out;
+    const long row_stride = nch == 1 ? (long)s->stage_out_cap : (output_frames > 0 ? output_frames : 1);
+    int rc = src_process_impl(s, in, input_frames, d_rows, row_stride, output_frames, src_ratio, end_of_input, &used, &gen, st);
     hipError_t e = hipSuccess;
-    if (rc == REDIO_OK && gen > 0) e = hipMemcpyAsync(data_out, s->d_stage_out, (size_t)gen * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (rc == REDIO_OK && gen > 0) {
+        if (nch > 1) e = launch_src_interleave(s->d_stage_out, s->d_rows_out, row_stride, gen, (int)nch, false, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(data_out, s->d_stage_out, (size_t)gen * nch * sizeof(float), hipMemcpyDeviceToHost, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (rc) return rc;
     if (e != hipSuccess) return hip_rc(e);

@@ -21,4 +21,7 @@ hipError_t launch_src_window(const float *old_img, long old_stride, const float 
 hipError_t launch_src_copy_rows(const float *src, long src_stride, long src_off, float *dst, long dst_stride, long dst_off,
                                 long n, int nchan, hipStream_t s);
 hipError_t launch_src_fill_rows(float *dst, long dst_stride, long dst_off, long n, int nchan, float v, hipStream_t s);
+hipError_t launch_src_zoh_linear(const float *in, long in_stride, const float *last, const int *idx, const double *frac, float *out,
+                                 long out_stride, long nout, int nchan, bool linear, hipStream_t s);
+hipError_t launch_src_interleave(float *inter, float *rows, long stride, long frames, int nchan, bool to_rows, hipStream_t s);
 } // namespace redio

@@ -624,4 +624,51 @@ hipError_t launch_src_fill_rows(float *dst, long dst_stride, long dst_off, long 
     return hipGetLastError();
 }
 
+// ---- converters 3 / 4: zero-order hold and linear (src_zoh.c / src_linear.c of the published library) -----------
+// The host runs the library's double recurrence and hands over, per output, the index i of the sample before the
+// output instant (-1: the value carried from the previous call) and the fractional position; all channels share them.
+// out = a (hold) or (float)(a + frac * (b - a)) with the difference b - a formed in float, as the C expression does.
+__global__ __launch_bounds__(256) void src_zoh_linear_kernel(const float *__restrict__ in, long in_stride, const float *__restrict__ last,
+                                                             const int *__restrict__ idx, const double *__restrict__ frac,
+                                                             float *__restrict__ out, long out_stride, long nout, int linear)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nout) return;
+    const int ch = blockIdx.y, i = idx[k];
+    const float *row = in + (long)ch * in_stride;
+    const float a = i < 0 ? last[ch] : row[i];
+    float v = a;
+    if (linear) {
+        const float d = row[i + 1] - a;
+        v = (float)((double)a + frac[k] * (double)d);
+    }
+    out[(long)ch * out_stride + k] = v;
+}
+hipError_t launch_src_zoh_linear(const float *in, long in_stride, const float *last, const int *idx, const double *frac, float *out,
+                                 long out_stride, long nout, int nchan, bool linear, hipStream_t s)
+{
+    if (nout <= 0 || nchan <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nout + 255) / 256), (unsigned)nchan);
+    hipLaunchKernelGGL(src_zoh_linear_kernel, grid, dim3(256), 0, s, in, in_stride, last, idx, frac, out, out_stride, nout, linear ? 1 : 0);
+    return hipGetLastError();
+}
+
+// interleaved frames [frames][nchan] <-> rows [nchan][stride] (the multi-channel form of the src_process drop-in)
+__global__ __launch_bounds__(256) void src_deinterleave_kernel(const float *__restrict__ inter, float *__restrict__ rows, long stride, long frames, int nchan, int to_rows)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= frames * nchan) return;
+    const long fr = e / nchan;
+    const int ch = (int)(e - fr * nchan);
+    if (to_rows) rows[(long)ch * stride + fr] = inter[e];
+    else const_cast<float *>(inter)[e] = rows[(long)ch * stride + fr];
+}
+hipError_t launch_src_interleave(float *inter, float *rows, long stride, long frames, int nchan, bool to_rows, hipStream_t s)
+{
+    if (frames <= 0 || nchan <= 0) return hipSuccess;
+    const long total = frames * nchan;
+    hipLaunchKernelGGL(src_deinterleave_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, inter, rows, stride, frames, nchan, to_rows ? 1 : 0);
+    return hipGetLastError();
+}
+
 } // namespace redio

@@ -35,17 +35,20 @@ class State:
 
     def __init__(self, converter=SRC_SINC_MEDIUM_QUALITY, channels=1):
         err = C.c_int(0)
+        self.channels = int(channels)
         self._s = samplerate_lib().src_new(converter, channels, C.byref(err))
         if not self._s:
             raise SrcError(err.value)
 
     def process(self, vin, ratio, output_frames, end_of_input=0):
-        """src_process(state, &SRC_DATA): returns (error, output[:gen], input_frames_used)."""
+        """src_process(state, &SRC_DATA): vin holds interleaved frames (len = frames * channels);
+        returns (error, interleaved output[:gen * channels], input_frames_used)."""
+        ch = self.channels
         vin = np.ascontiguousarray(vin, dtype=np.float32)
-        vout = np.empty(max(int(output_frames), 1), np.float32)
-        d = SRC_DATA(vin.ctypes.data, vout.ctypes.data, len(vin), int(output_frames), 0, 0, int(end_of_input), float(ratio))
+        vout = np.empty(max(int(output_frames), 1) * ch, np.float32)
+        d = SRC_DATA(vin.ctypes.data, vout.ctypes.data, len(vin) // ch, int(output_frames), 0, 0, int(end_of_input), float(ratio))
         err = samplerate_lib().src_process(self._s, C.byref(d))
-        return err, vout[: d.output_frames_gen].copy(), d.input_frames_used
+        return err, vout[: d.output_frames_gen * ch].copy(), d.input_frames_used
 
     def block(self, vin, ratio):
         """One message of the resample block (samplerate.rs:63-85)."""

@@ -222,6 +222,7 @@ class Resampler:
 
     def __init__(self, converter=1, channels=1):
         err = C.c_int(0)
+        self.channels = int(channels)
         self._s = lib().orc_src_new(converter, channels, C.byref(err))
         if not self._s:
             raise ValueError(f"src_new failed with error {err.value}")
@@ -243,10 +244,12 @@ class Resampler:
         return out[:n].copy()
 
     def process(self, vin, ratio, out_frames, end_of_input=False):
-        vin = _f32(vin); out = np.empty(max(out_frames, 1), np.float32)
-        d = SrcData(vin.ctypes.data, out.ctypes.data, len(vin), out_frames, 0, 0, int(end_of_input), ratio)
+        """vin: interleaved frames (len = frames * channels); returns (error, interleaved output, input FRAMES used)."""
+        ch = self.channels
+        vin = _f32(vin); out = np.empty(max(out_frames, 1) * ch, np.float32)
+        d = SrcData(vin.ctypes.data, out.ctypes.data, len(vin) // ch, out_frames, 0, 0, int(end_of_input), ratio)
         err = lib().orc_src_process(self._s, C.byref(d))
-        return err, out[: d.output_frames_gen].copy(), d.input_frames_used
+        return err, out[: d.output_frames_gen * ch].copy(), d.input_frames_used
 
 
 def src_table(converter):

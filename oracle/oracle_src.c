@@ -101,6 +101,12 @@ struct orc_src_state {
     long in_count, in_used, out_count, out_gen;
     int b_current, b_end, b_real_end, b_len;
     float *buffer;
+    /* channels > 1, sinc: one mono state per channel (the library's multi-channel loops do the same arithmetic per
+     * channel on interleaved data; the end-of-input rule follows the mono loop).  Converters 3 / 4: src_zoh.c / src_linear.c. */
+    int channels;
+    struct orc_src_state **sub;
+    float *last_value;
+    int zl_reset;
 };
 
 int orc_src_reset(orc_src_state *s)
@@ -108,6 +114,8 @@ int orc_src_reset(orc_src_state *s)
     if (!s) return SRC_ERR_BAD_STATE;
     s->last_ratio = 0.0;
     s->last_position = 0.0;
+    if (s->sub) { for (int c = 0; c < s->channels; ++c) orc_src_reset(s->sub[c]); return 0; }
+    if (s->type >= 3) { s->zl_reset = 1; memset(s->last_value, 0, (size_t)s->channels * sizeof(float)); return 0; } /* zoh_reset / linear_reset */
     s->b_current = s->b_end = 0;
     s->b_real_end = -1;
     memset(s->buffer, 0, (size_t)(s->b_len + 1) * sizeof(float));
@@ -118,10 +126,26 @@ orc_src_state *orc_src_new(int converter_type, int channels, int *error)
 {
     if (error) *error = 0;
     if (channels < 1) { if (error) *error = SRC_ERR_BAD_CHANNEL_COUNT; return NULL; }
-    if (channels != 1) { if (error) *error = SRC_ERR_BAD_CHANNEL_COUNT; return NULL; } /* mono only here */
+    if (converter_type == 3 || converter_type == 4) { /* SRC_ZERO_ORDER_HOLD, SRC_LINEAR (samplerate.rs:29-30) */
+        orc_src_state *z = (orc_src_state *)calloc(1, sizeof(*z));
+        z->type = converter_type;
+        z->channels = channels;
+        z->last_value = (float *)calloc((size_t)channels, sizeof(float));
+        orc_src_reset(z);
+        return z;
+    }
     const src_table *t = get_table(converter_type);
-    if (!t) { if (error) *error = SRC_ERR_BAD_CONVERTER; return NULL; } /* ZOH/linear not restated */
+    if (!t) { if (error) *error = SRC_ERR_BAD_CONVERTER; return NULL; }
+    if (channels > 1) {
+        orc_src_state *m = (orc_src_state *)calloc(1, sizeof(*m));
+        m->type = converter_type;
+        m->channels = channels;
+        m->sub = (orc_src_state **)calloc((size_t)channels, sizeof(*m->sub));
+        for (int c = 0; c < channels; ++c) m->sub[c] = orc_src_new(converter_type, 1, NULL);
+        return m;
+    }
     orc_src_state *s = (orc_src_state *)calloc(1, sizeof(*s));
+    s->channels = 1;
     s->type = converter_type;
     s->coeffs = t->c;
     s->coeff_half_len = t->n - 2;
@@ -137,6 +161,8 @@ orc_src_state *orc_src_new(int converter_type, int channels, int *error)
 void orc_src_delete(orc_src_state *s)
 {
     if (!s) return;
+    if (s->sub) { for (int c = 0; c < s->channels; ++c) orc_src_delete(s->sub[c]); free(s->sub); }
+    free(s->last_value);
     free(s->buffer);
     free(s);
 }
@@ -230,6 +256,61 @@ static double calc_output(const orc_src_state *f, int32_t increment, int32_t sta
     return left + right;
 }
 
+/* zoh_vari_process (src_zoh.c) and linear_vari_process (src_linear.c) of the published libsamplerate 0.1.8, interleaved
+ * channels.  ZOH repeats the sample before the output instant; linear interpolates between the two samples around it:
+ * (float)(a + input_index * (b - a)) with a, b float (their difference is a float) and input_index double. */
+static int zoh_linear_process(orc_src_state *p, orc_src_data *d)
+{
+    const int ch_n = p->channels, lin = p->type == 4;
+    if (d->input_frames <= 0) return SRC_ERR_NO_ERROR;
+    if (p->zl_reset) { /* just reset: the value "before" the stream is its first frame */
+        for (int ch = 0; ch < ch_n; ++ch) p->last_value[ch] = d->data_in[ch];
+        p->zl_reset = 0;
+    }
+    const long in_count = d->input_frames * ch_n, out_count = d->output_frames * ch_n;
+    long in_used = 0, out_gen = 0;
+    double src_ratio = p->last_ratio, input_index = p->last_position, rem;
+    /* samples before the first sample of this input array */
+    while (input_index < 1.0 && out_gen < out_count) {
+        if (lin ? (in_used + ch_n * (1.0 + input_index) >= in_count) : (in_used + ch_n * input_index >= in_count)) break;
+        if (out_count > 0 && fabs(p->last_ratio - d->src_ratio) > 1e-20)
+            src_ratio = p->last_ratio + out_gen * (d->src_ratio - p->last_ratio) / out_count;
+        for (int ch = 0; ch < ch_n; ++ch) {
+            d->data_out[out_gen] = lin ? (float)(p->last_value[ch] + input_index * (d->data_in[ch] - p->last_value[ch])) : p->last_value[ch];
+            out_gen++;
+        }
+        input_index += 1.0 / src_ratio;
+    }
+    rem = fmod_one(input_index);
+    in_used += ch_n * lrint(input_index - rem);
+    input_index = rem;
+    /* main loop */
+    while (out_gen < out_count && (lin ? (in_used + ch_n * input_index < in_count) : (in_used + ch_n * input_index <= in_count))) {
+        if (out_count > 0 && fabs(p->last_ratio - d->src_ratio) > 1e-20)
+            src_ratio = p->last_ratio + out_gen * (d->src_ratio - p->last_ratio) / out_count;
+        for (int ch = 0; ch < ch_n; ++ch) {
+            const float a = d->data_in[in_used - ch_n + ch];
+            d->data_out[out_gen] = lin ? (float)(a + input_index * (d->data_in[in_used + ch] - a)) : a;
+            out_gen++;
+        }
+        input_index += 1.0 / src_ratio;
+        rem = fmod_one(input_index);
+        in_used += ch_n * lrint(input_index - rem);
+        input_index = rem;
+    }
+    if (in_used > in_count) {
+        input_index += (in_used - in_count) / ch_n;
+        in_used = in_count;
+    }
+    p->last_position = input_index;
+    if (in_used > 0)
+        for (int ch = 0; ch < ch_n; ++ch) p->last_value[ch] = d->data_in[in_used - ch_n + ch];
+    p->last_ratio = src_ratio;
+    d->input_frames_used = in_used / ch_n;
+    d->output_frames_gen = out_gen / ch_n;
+    return SRC_ERR_NO_ERROR;
+}
+
 /* src_process (samplerate.c) + sinc_mono_vari_process (src_sinc.c) */
 int orc_src_process(orc_src_state *f, orc_src_data *d)
 {
@@ -239,14 +320,33 @@ int orc_src_process(orc_src_state *f, orc_src_data *d)
     if (is_bad_src_ratio(d->src_ratio)) return SRC_ERR_BAD_SRC_RATIO;
     if (d->input_frames < 0) d->input_frames = 0;
     if (d->output_frames < 0) d->output_frames = 0;
+    const int nch = f->channels > 0 ? f->channels : 1;
     if (d->data_in < d->data_out) {
-        if (d->data_in + d->input_frames > d->data_out) return SRC_ERR_DATA_OVERLAP;
-    } else if (d->data_out + d->output_frames > d->data_in) {
+        if (d->data_in + d->input_frames * nch > d->data_out) return SRC_ERR_DATA_OVERLAP;
+    } else if (d->data_out + d->output_frames * nch > d->data_in) {
         return SRC_ERR_DATA_OVERLAP;
     }
     d->input_frames_used = 0;
     d->output_frames_gen = 0;
     if (f->last_ratio < (1.0 / SRC_MAX_RATIO)) f->last_ratio = d->src_ratio;
+    if (f->type >= 3) return zoh_linear_process(f, d);
+    if (f->sub) { /* interleaved channels: every channel through its own mono state, same arguments */
+        float *in = (float *)malloc((size_t)(d->input_frames + 1) * sizeof(float));
+        float *out = (float *)malloc((size_t)(d->output_frames + 1) * sizeof(float));
+        int err = 0;
+        for (int c = 0; c < nch && !err; ++c) {
+            for (long i = 0; i < d->input_frames; ++i) in[i] = d->data_in[i * nch + c];
+            orc_src_data m = *d;
+            m.data_in = in; m.data_out = out;
+            err = orc_src_process(f->sub[c], &m);
+            for (long i = 0; i < m.output_frames_gen; ++i) d->data_out[i * nch + c] = out[i];
+            d->input_frames_used = m.input_frames_used;
+            d->output_frames_gen = m.output_frames_gen;
+        }
+        free(in); free(out);
+        f->last_ratio = f->sub[0]->last_ratio;
+        return err;
+    }
 
     f->in_count = d->input_frames;
     f->out_count = d->output_frames;

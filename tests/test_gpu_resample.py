@@ -101,10 +101,10 @@ def test_errors_are_the_library_codes(gpu, redio):
     from libredio_amd import samplerate
     S = redio.samplerate_lib()
     with pytest.raises(samplerate.SrcError) as e:
-        samplerate.State(3, 1)          # zero-order hold: not built
+        samplerate.State(5, 1)          # there are five converters (samplerate.rs:26-30)
     assert e.value.code == 10
     with pytest.raises(samplerate.SrcError) as e:
-        samplerate.State(1, 2)          # channels > 1: not built
+        samplerate.State(1, 0)          # channel count must be >= 1
     assert e.value.code == 11
     st = samplerate.State()
     err, _, _ = st.process(tone(100), 1000.0, 10)
@@ -293,3 +293,61 @@ def test_periodic_path_then_ratio_change_and_flush(gpu, redio, oracle):
         assert err == 0 and used == wused and got.shape[1] == len(want)
         assert np.array_equal(bits(got.cpu().numpy()[0]), bits(want)), (lo, hi, r)
     assert plan.path_counts()[0] > 0
+
+
+@pytest.mark.parametrize("conv", [3, 4])
+@pytest.mark.parametrize("channels", [1, 2, 5])
+@pytest.mark.parametrize("ratio", [2.0, 0.5, 48000 / 44100, 0.0213, 1.0, 3.7])
+def test_zero_order_hold_and_linear_converters(gpu, redio, oracle, conv, channels, ratio):
+    """SRC_ZERO_ORDER_HOLD / SRC_LINEAR (samplerate.rs:29-30; the reference only ever asks for converter 1) through the
+    src_* drop-in, interleaved channels, state carried across messages, bit for bit against the oracle's restatement of
+    the published src_zoh.c / src_linear.c."""
+    from libredio_amd import samplerate
+    n = 30000
+    x = np.stack([oracle.synth_f32(40 + c, 0, n) for c in range(channels)], 1).reshape(-1)     # interleaved
+    st, ref = samplerate.State(conv, channels), oracle.Resampler(conv, channels)
+    pos = 0
+    for frames in (7000, 1, 2, 9997, 13000):
+        msg = x[pos * channels:(pos + frames) * channels]
+        cap = int(ratio * frames + 1.0) + 3
+        e1, o1, u1 = st.process(msg, ratio, cap, 0)
+        e2, o2, u2 = ref.process(msg, ratio, cap, False)
+        assert (e1, u1, len(o1)) == (e2, u2, len(o2)), (conv, channels, ratio, frames)
+        assert np.array_equal(bits(o1), bits(o2)), (conv, channels, ratio, frames)
+        pos += u1 if u1 else frames
+    # a ratio change inside a call (linear interpolation of the ratio) and a reset
+    msg = x[: 5000 * channels]
+    for r in (ratio, min(ratio * 1.3, 200.0)):
+        e1, o1, u1 = st.process(msg, r, int(r * 5000) + 10, 0)
+        e2, o2, u2 = ref.process(msg, r, int(r * 5000) + 10, False)
+        assert (e1, u1, len(o1)) == (e2, u2, len(o2)) and np.array_equal(bits(o1), bits(o2))
+    st.reset(); ref = oracle.Resampler(conv, channels)
+    e1, o1, u1 = st.process(msg, ratio, int(ratio * 5000) + 10, 0)
+    e2, o2, u2 = ref.process(msg, ratio, int(ratio * 5000) + 10, False)
+    assert (e1, u1, len(o1)) == (e2, u2, len(o2)) and np.array_equal(bits(o1), bits(o2))
+    st.close()
+
+
+@pytest.mark.parametrize("conv,channels,ratio", [(1, 2, 0.02), (1, 2, 48000 / 44100), (2, 3, 0.5), (0, 2, 2.0), (1, 4, 0.0213)])
+def test_interleaved_channels_through_the_drop_in(gpu, redio, oracle, conv, channels, ratio):
+    """src_new(converter, channels > 1): interleaved frames in and out; every channel is converted exactly as a mono
+    stream (the reference itself always passes 1, samplerate.rs:61)."""
+    from libredio_amd import samplerate
+    n = 40000
+    cols = [oracle.synth_f32(60 + c, 0, n) for c in range(channels)]
+    x = np.stack(cols, 1).reshape(-1)
+    st, ref = samplerate.State(conv, channels), oracle.Resampler(conv, channels)
+    monos = [oracle.Resampler(conv, 1) for _ in range(channels)]
+    pos = 0
+    for frames in (15000, 3, 24997):
+        msg = x[pos * channels:(pos + frames) * channels]
+        cap = int(ratio * frames + 1.0)
+        e1, o1, u1 = st.process(msg, ratio, cap, 0)
+        e2, o2, u2 = ref.process(msg, ratio, cap, False)
+        assert (e1, u1, len(o1)) == (e2, u2, len(o2))
+        assert np.array_equal(bits(o1), bits(o2)), (conv, channels, ratio, frames)
+        for c in range(channels):
+            _, oc, _ = monos[c].process(cols[c][pos:pos + frames], ratio, cap, False)
+            assert np.array_equal(bits(o1[c::channels]), bits(oc))
+        pos += frames
+    st.close()

@@ -53,7 +53,19 @@ def test_resampler_contract(oracle):
     err, y, used = oracle.Resampler(1).process(np.zeros(100, np.float32), 1000.0, 10)
     assert err == 6                                                       # SRC_ERR_BAD_SRC_RATIO
     with pytest.raises(ValueError):
-        oracle.Resampler(3)                                               # ZOH/linear are not restated
+        oracle.Resampler(5)                                               # five converters (samplerate.rs:26-30)
+    # converters 3 / 4 against closed forms: hold repeats the sample before the output instant, linear interpolates
+    ramp = np.arange(1000, dtype=np.float32)
+    e, z, u = oracle.Resampler(3).process(ramp, 0.25, 300)
+    assert e == 0 and u == 1000 and np.array_equal(z[1:5], np.float32([3, 7, 11, 15]))
+    e, l, u = oracle.Resampler(4).process(ramp, 4.0, 4100)
+    assert e == 0 and np.allclose(l[4:40], np.arange(36) * 0.25, atol=0)          # exact: dyadic steps on integers
+    # interleaved channels are independent mono streams
+    a2 = oracle.synth_f32(5, 0, 4000); b2 = oracle.synth_f32(6, 0, 4000)
+    e, y2, u2 = oracle.Resampler(1, 2).process(np.stack([a2, b2], 1).reshape(-1), 0.5, 2100)
+    _, ya, _ = oracle.Resampler(1).process(a2, 0.5, 2100)
+    _, yb, _ = oracle.Resampler(1).process(b2, 0.5, 2100)
+    assert e == 0 and np.array_equal(y2[0::2], ya) and np.array_equal(y2[1::2], yb)
     # streaming invariance to message segmentation
     x = oracle.synth_f32(3, 0, 9000)
     a = oracle.Resampler(1).block(x, 0.5)
