@@ -83,8 +83,10 @@ struct redio_src {
     int cur; // which image is live
     long buf_stride;
     // per-call scratch
-    std::vector<int> h_pos, h_start, h_inc;
-    std::vector<double> h_scale;
+    // per-output values of the host recurrence, in PINNED host memory so that their uploads are true asynchronous DMAs
+    // (a pageable hipMemcpyAsync is staged synchronously: tens of microseconds per refill epoch)
+    int *h_pos, *h_start, *h_inc;
+    double *h_scale;
     int *d_pos, *d_start, *d_inc;
     double *d_scale;
     size_t d_cap;
@@ -99,8 +101,7 @@ struct redio_src {
     double *d_pL, *d_pR; size_t pL_cap, pR_cap;
     int *d_pint; // dpos | skipL | skipR, 256 each
     int period_hint;
-    std::vector<std::vector<double>> keep_d;
-    std::vector<std::vector<int>> keep_i;
+    char *h_arena; size_t arena_cap, arena_used; // pinned: the periodic tables of one call, carved out epoch by epoch
     long periodic_launches, general_launches; // diagnostics (redio_src_path_counts)
     // converters 3 / 4 (zero-order hold, linear): the value carried from the previous call, per channel, and the reset flag
     float *d_last; int zl_reset;
@@ -161,6 +162,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0; s->host_stream = nullptr;
     s->fast_inc = 0; s->d_cl = s->d_cr = nullptr; s->ncl = s->ncr = 0;
     s->d_pL = s->d_pR = nullptr; s->pL_cap = s->pR_cap = 0; s->d_pint = nullptr; s->period_hint = 0;
+    s->h_pos = s->h_start = s->h_inc = nullptr; s->h_scale = nullptr; s->h_arena = nullptr; s->arena_cap = s->arena_used = 0;
     s->periodic_launches = s->general_launches = 0;
     s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
     s->h_coeffs = coeffs;
@@ -198,6 +200,11 @@ extern "C" int redio_src_destroy(redio_src *s)
     hipFree(s->d_cl); hipFree(s->d_cr); hipFree(s->d_T2);
     hipFree(s->d_pL); hipFree(s->d_pR); hipFree(s->d_pint);
     hipFree(s->d_last); hipFree(s->d_rows_in); hipFree(s->d_rows_out);
+    if (s->h_pos) hipHostFree(s->h_pos);
+    if (s->h_start) hipHostFree(s->h_start);
+    if (s->h_inc) hipHostFree(s->h_inc);
+    if (s->h_scale) hipHostFree(s->h_scale);
+    if (s->h_arena) hipHostFree(s->h_arena);
     delete s;
     return REDIO_OK;
 }
@@ -241,7 +248,15 @@ static int ensure_scratch(redio_src *s, size_t nout)
     SRC_TRY(hipMalloc((void **)&s->d_inc, cap * sizeof(int)));
     SRC_TRY(hipMalloc((void **)&s->d_scale, cap * sizeof(double)));
     s->d_cap = cap;
-    s->h_pos.resize(cap); s->h_start.resize(cap); s->h_inc.resize(cap); s->h_scale.resize(cap);
+    if (s->h_pos) hipHostFree(s->h_pos);
+    if (s->h_start) hipHostFree(s->h_start);
+    if (s->h_inc) hipHostFree(s->h_inc);
+    if (s->h_scale) hipHostFree(s->h_scale);
+    s->h_pos = s->h_start = s->h_inc = nullptr; s->h_scale = nullptr;
+    SRC_TRY(hipHostMalloc((void **)&s->h_pos, cap * sizeof(int), hipHostMallocDefault));
+    SRC_TRY(hipHostMalloc((void **)&s->h_start, cap * sizeof(int), hipHostMallocDefault));
+    SRC_TRY(hipHostMalloc((void **)&s->h_inc, cap * sizeof(int), hipHostMallocDefault));
+    SRC_TRY(hipHostMalloc((void **)&s->h_scale, cap * sizeof(double), hipHostMallocDefault));
     return REDIO_OK;
 }
 
@@ -366,7 +381,7 @@ static int try_periodic_epoch(redio_src *f, long first, long count, float *d_out
     if (count < 128) return 0;
     const int inc = f->h_inc[(size_t)first];
     const double scale = f->h_scale[(size_t)first];
-    const int *pos = f->h_pos.data() + first, *start = f->h_start.data() + first;
+    const int *pos = f->h_pos + first, *start = f->h_start + first;
     for (long k = 1; k < count; ++k)
         if (f->h_inc[(size_t)(first + k)] != inc || f->h_scale[(size_t)(first + k)] != scale || pos[k] < pos[k - 1]) return 0;
     auto is_period = [&](int P) {
@@ -413,11 +428,21 @@ static int try_periodic_epoch(redio_src *f, long first, long count, float *d_out
     const int dpos_max = pos[P - 1] - pos[0];
     int NT = 0; size_t lds = 0;
     if (!src_periodic_shape(P, Q, NL, NR, dpos_max, 1, &NT, &lds)) return 0;
-    f->keep_d.emplace_back((size_t)NL * P, 0.0);
-    f->keep_d.emplace_back((size_t)NR * P, 0.0);
-    f->keep_i.emplace_back((size_t)3 * 256, 0);
-    std::vector<double> &L = f->keep_d[f->keep_d.size() - 2], &R = f->keep_d.back();
-    std::vector<int> &I = f->keep_i.back();
+    // the tables are rebuilt for every epoch (its first output may sit at any phase): only worth it while they are small
+    // next to the epoch's own work (0.0213 = 213 / 10000 is periodic too, but 213 phases x 4300 taps is not a table)
+    if ((long)P * (NL + NR) > 65536 || (long)P * (NL + NR) > 8 * count) return 0;
+    // this epoch's tables in the pinned arena (kept until the call's final synchronisation: the uploads are asynchronous)
+    const size_t nLd = (size_t)NL * P, nRd = (size_t)NR * P, need = (nLd + nRd) * sizeof(double) + 3 * 256 * sizeof(int);
+    if (!f->h_arena) {
+        SRC_TRY(hipHostMalloc((void **)&f->h_arena, (size_t)16 << 20, hipHostMallocDefault));
+        f->arena_cap = (size_t)16 << 20; f->arena_used = 0;
+    }
+    if (f->arena_used + need > f->arena_cap) return 0; // a very long call: the remaining epochs take the general kernel
+    double *L = reinterpret_cast<double *>(f->h_arena + f->arena_used), *R = L + nLd;
+    int *I = reinterpret_cast<int *>(R + nRd);
+    f->arena_used += (need + 63) & ~(size_t)63;
+    memset(L, 0, (nLd + nRd) * sizeof(double));
+    memset(I, 0, 3 * 256 * sizeof(int));
     int maxskipL = 0, maxskipR = 0;
     for (int p = 0; p < P; ++p) {
         const int sl = NL - (int)Lf[(size_t)p].size(), sr = NR - (int)Rf[(size_t)p].size();
@@ -427,21 +452,16 @@ static int try_periodic_epoch(redio_src *f, long first, long count, float *d_out
         maxskipL = maxskipL > sl ? maxskipL : sl;
         maxskipR = maxskipR > sr ? maxskipR : sr;
     }
-    if (L.size() > f->pL_cap) {
+    // device side: one buffer [L | R | ints], same layout as the arena slice, one upload
+    if (need > f->pL_cap) {
         hipFree(f->d_pL); f->d_pL = nullptr; f->pL_cap = 0;
-        SRC_TRY(hipMalloc((void **)&f->d_pL, 2 * L.size() * sizeof(double)));
-        f->pL_cap = 2 * L.size();
+        SRC_TRY(hipMalloc((void **)&f->d_pL, 2 * need));
+        f->pL_cap = 2 * need;
     }
-    if (R.size() > f->pR_cap) {
-        hipFree(f->d_pR); f->d_pR = nullptr; f->pR_cap = 0;
-        SRC_TRY(hipMalloc((void **)&f->d_pR, 2 * R.size() * sizeof(double)));
-        f->pR_cap = 2 * R.size();
-    }
-    if (!f->d_pint) SRC_TRY(hipMalloc((void **)&f->d_pint, 3 * 256 * sizeof(int)));
-    SRC_TRY(hipMemcpyAsync(f->d_pL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    SRC_TRY(hipMemcpyAsync(f->d_pR, R.data(), R.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    SRC_TRY(hipMemcpyAsync(f->d_pint, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    hipError_t e = launch_src_periodic(f->d_buf[f->cur], f->buf_stride, f->d_pL, f->d_pR, f->d_pint, f->d_pint + 256, f->d_pint + 512, P, Q, NL, NR,
+    SRC_TRY(hipMemcpyAsync(f->d_pL, L, need, hipMemcpyHostToDevice, st));
+    const double *dL = f->d_pL, *dR = dL + nLd;
+    const int *dI = reinterpret_cast<const int *>(dR + nRd);
+    hipError_t e = launch_src_periodic(f->d_buf[f->cur], f->buf_stride, dL, dR, dI, dI + 256, dI + 512, P, Q, NL, NR,
                                        maxskipL, maxskipR, dpos_max, pos[0], scale, d_out + first, out_stride, count, f->nchan, st);
     if (e == hipErrorNotSupported) return 0;
     if (e != hipSuccess) return hip_rc(e);
@@ -489,10 +509,10 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
         if (handled != 0) return handled;
     }
     ++f->general_launches;
-    SRC_TRY(hipMemcpyAsync(f->d_pos + first, f->h_pos.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
-    SRC_TRY(hipMemcpyAsync(f->d_start + first, f->h_start.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
-    SRC_TRY(hipMemcpyAsync(f->d_inc + first, f->h_inc.data() + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
-    SRC_TRY(hipMemcpyAsync(f->d_scale + first, f->h_scale.data() + first, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_pos + first, f->h_pos + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_start + first, f->h_start + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_inc + first, f->h_inc + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    SRC_TRY(hipMemcpyAsync(f->d_scale + first, f->h_scale + first, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
     SRC_TRY(launch_src_exact(f->d_buf[f->cur], f->buf_stride, f->d_coeffs, f->coeff_half_len, f->d_pos + first, f->d_start + first,
                              f->d_inc + first, f->d_scale + first, d_out + first, out_stride, count, f->nchan, st));
     return REDIO_OK;
@@ -627,8 +647,8 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
         in_used = in_count;
     }
     if (out_gen > 0) {
-        SRC_TRY(hipMemcpyAsync(f->d_pos, f->h_pos.data(), (size_t)out_gen * sizeof(int), hipMemcpyHostToDevice, st));
-        SRC_TRY(hipMemcpyAsync(f->d_scale, f->h_scale.data(), (size_t)out_gen * sizeof(double), hipMemcpyHostToDevice, st));
+        SRC_TRY(hipMemcpyAsync(f->d_pos, f->h_pos, (size_t)out_gen * sizeof(int), hipMemcpyHostToDevice, st));
+        SRC_TRY(hipMemcpyAsync(f->d_scale, f->h_scale, (size_t)out_gen * sizeof(double), hipMemcpyHostToDevice, st));
         SRC_TRY(launch_src_zoh_linear(d_in, in_stride, f->d_last, f->d_pos, f->d_scale, d_out, out_stride, out_gen, f->nchan, lin, st));
     }
     f->last_position = input_index;
@@ -664,7 +684,7 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
     }
     int rc = ensure_scratch(f, (size_t)out_count);
     if (rc) return rc;
-    f->keep_d.clear(); f->keep_i.clear(); // tables of the previous call: its uploads completed when that call synchronised
+    f->arena_used = 0; // tables of the previous call: its uploads completed when that call synchronised
     // the scratch upload of an earlier call on another stream must not be overwritten while in
     // flight: calls on one handle are serialised by the caller (one block thread per handle)
 
