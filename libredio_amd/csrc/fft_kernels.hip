@@ -868,19 +868,12 @@ __device__ __forceinline__ void f64w_exchange(float2 (&a)[4][16], float2 (&b)[4]
 // overlap-save middle pass: forward pass 1, spectrum product, inverse pass 0 on the same tile.  After the forward
 // stages lane (col, q) holds rows s + 16 j, s = q + 4 x: in the inverse transform's digit-reversed order that IS
 // group 4 q + x with rows in rev2 order, so the inverse starts from registers without another exchange.
-__global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out,
-                                                                 const float2 *__restrict__ Tf, const float2 *__restrict__ tw_i,
-                                                                 const float2 *__restrict__ Hc, long ntiles)
+__device__ __forceinline__ void ovsave64k_mid_tile(const float2 *__restrict__ a_blk, float2 *__restrict__ b_blk, const float2 *__restrict__ Tf,
+                                                   const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc, int c, int lane, float2 *Lw)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long tile = f64w_first_tile() + w;
-    if (tile >= ntiles) return;
-    float2 *Lw = Ls + w * F64W_REGION;
-    const long xf = tile >> 4;
-    const int c = (int)(tile & 15), col = lane & 15, q = lane >> 4;
-    const float2 *src = a_in + xf * F64K_N + F64K_COLS * c;
-    float2 *dst = b_out + xf * F64K_N;
+    const int col = lane & 15, q = lane >> 4;
+    const float2 *src = a_blk + F64K_COLS * c;
+    float2 *dst = b_blk;
     const unsigned lo_q1 = col + 256u * q, lo_q16 = col + 4096u * q;
     float2 a[4][16], b[4][16];
 #pragma unroll
@@ -915,18 +908,24 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
         for (int j = 0; j < 16; ++j) (dst + 256 * (64 * x + rc) + 16 * j)[lo_q16] = b[x][j];
 }
 
-__global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
-                                                                  const float2 *__restrict__ Ti, long hop, float scale, long ntiles)
+__global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out,
+                                                                 const float2 *__restrict__ Tf, const float2 *__restrict__ tw_i,
+                                                                 const float2 *__restrict__ Hc, long ntiles)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile() + w;
     if (tile >= ntiles) return;
-    float2 *Lw = Ls + w * F64W_REGION;
     const long xf = tile >> 4;
-    const int c = (int)(tile & 15), col = lane & 15, q = lane >> 4;
-    const float2 *src = b_in + xf * F64K_N + F64K_COLS * c;
-    float2 *dst = out + xf * hop + F64K_COLS * c;
+    ovsave64k_mid_tile(a_in + xf * F64K_N, b_out + xf * F64K_N, Tf, tw_i, Hc, (int)(tile & 15), lane, Ls + w * F64W_REGION);
+}
+
+__device__ __forceinline__ void ovsave64k_last_tile(const float2 *__restrict__ b_blk, float2 *__restrict__ out_blk, const float2 *__restrict__ Ti,
+                                                    long hop, float scale, int c, int lane, float2 *Lw)
+{
+    const int col = lane & 15, q = lane >> 4;
+    const float2 *src = b_blk + F64K_COLS * c;
+    float2 *dst = out_blk + F64K_COLS * c;
     const unsigned lo_q1 = col + 256u * q, lo_q16 = col + 4096u * q;
     float2 a[4][16], b[4][16];
 #pragma unroll
@@ -944,6 +943,17 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float
 #pragma unroll
         for (int j = 0; j < 16; ++j)
             if (256 * (4 * x + 16 * j) < lim) (dst + 256 * (4 * x + 16 * j))[lo_q1] = make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale));
+}
+
+__global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
+                                                                  const float2 *__restrict__ Ti, long hop, float scale, long ntiles)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    const long xf = tile >> 4;
+    ovsave64k_last_tile(b_in + xf * F64K_N, out + xf * hop, Ti, hop, scale, (int)(tile & 15), lane, Ls + w * F64W_REGION);
 }
 
 // ---- N = 4096, one wavefront per transform ---------------------------------------------------------
@@ -1362,21 +1372,15 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
 // neighbouring positions; the last one to three stages (rows 65536 apart) need no regrouping at all: a lane keeps whole
 // columns in registers and every load and store is 512 contiguous bytes.  16 B/sample per pass.  Twiddle index of the stage
 // with sub-length m: (e mod m) * N / (4 m), exactly kissfft's k * fstride.
+// one 256 x 16 tile of the gather pass: block at in_blk (source columns 16c .. 16c + 15) -> working order at out_blk
 template <bool INV>
-__global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
-                                                           long ntiles, int L, const float2 *__restrict__ mulH = nullptr)
+__device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *out_blk, const float2 *__restrict__ tw, int L, unsigned c,
+                                                  int lane, float2 *Lw, const float2 *__restrict__ mulH)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long tile = f64w_first_tile() + w;
-    if (tile >= ntiles) return;
-    float2 *Lw = Ls + w * F64W_REGION;
     const unsigned N = 1u << (2 * L), S = N >> 8; // S: source row stride
-    const long xf = tile >> (2 * (L - 6));
-    const unsigned c = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)); // source columns 16c .. 16c + 15
     const int col = lane & 15, q = lane >> 4;
-    const float2 *src = in + xf * in_stride + 16 * c;
-    float2 *dst = out + xf * (long)N;
+    const float2 *src = in_blk + 16 * c;
+    float2 *dst = out_blk;
     float2 a[4][16], b[4][16];
     const unsigned lo_src = col + 4u * S * q;
 #pragma unroll
@@ -1410,6 +1414,19 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int j = 0; j < 16; ++j) (dst + 256l * (hx * x + rc) + 16 * j)[lo_dst] = b[x][j];
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
+                                                           long ntiles, int L, const float2 *__restrict__ mulH = nullptr)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    const long xf = tile >> (2 * (L - 6));
+    const unsigned c = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)); // source columns 16c .. 16c + 15
+    fftbig_first_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), tw, L, c, lane, Ls + w * F64W_REGION, mulH);
 }
 
 template <bool INV>
@@ -1865,6 +1882,139 @@ hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const f
     hipError_t e = launch_fftbig<false>(x, a, fw.tw, fw.tw_pass, nblk, hop, lgN, s);
     if (e != hipSuccess) return e;
     return launch_fftbig<true>(a, b, bw.tw, bw.tw_pass, nblk, (long)fw.nfft, lgN, s, Hc, out, hop, scale);
+}
+
+// ---- overlap-save at 65536 points with the intermediate kept inside the XCD's L2 ---------------------------------
+// The three passes above stream the 512 KiB intermediate of every block through the fabric twice each: 3.1 x the
+// algorithmic bytes.  A 65536-point block cannot stay inside one CU (512 KiB against 160 KiB of LDS), but it does fit
+// an XCD's 4 MiB L2.  This persistent kernel therefore forms, per XCD, "slots" of sixteen wavefronts that own ONE block
+// at a time and run its three passes back to back -- tile t of pass A (gather + four stages), a slot barrier, tile t of
+// pass B (four stages, spectrum product, four inverse stages), a slot barrier, tile t of pass C (four stages, scale,
+// store) -- on a scratch pair of 2 x 512 KiB that belongs to the slot and is re-used for every block, so with the four
+// slots per XCD used here the scratch an XCD touches is 4 MiB and its lines are overwritten in L2 instead of travelling.
+// Same tile programs as the three kernels (fftbig_first_tile, ovsave64k_mid_tile, ovsave64k_last_tile): same bits.
+//
+// Placement is never ASSUMED (HIP promises none): a workgroup reads the XCD it actually runs on (HW_REG_XCC_ID) and
+// registers there; the teams are whatever landed on each XCD.  All hand-offs of a slot stay inside one XCD, whose L2 is
+// shared by its CUs: a producer's plain stores are in that L2 once its s_waitcnt vmcnt(0) returns (the vector L1 is
+// write-through), the slot barrier is one monotonic counter (agent-scope atomic add, polled with L1-bypassing loads),
+// and a consumer invalidates its own L1 (agent-scope acquire fence) before it reads.  No L2 write-back is needed or
+// issued.  Every spin is bounded: on a time-out the error word is set and the wave leaves (wrong results, never a hang).
+constexpr int OV64T_MAX_WAVES = 8;   // wavefronts per workgroup (one workgroup per CU: the LDS request keeps a second one out); 32 CUs x w
+                                     // waves = 2 w slots per XCD, (512 + 512) KiB of scratch each: w = 2 keeps an XCD's scratch at its 4 MiB L2
+struct Ov64TeamCtrl {
+    unsigned team[8];        // workgroups registered per XCD
+    unsigned registered;     // workgroups registered in all
+    unsigned error;          // set on a spin time-out
+    unsigned pad[6];
+    unsigned cnt[64 * 32];   // slot barrier counters, one per 128-byte line (global slot g at cnt[32 g])
+};
+static_assert(sizeof(Ov64TeamCtrl) == 64 + 64 * 128, "layout");
+
+// the three tile programs as real calls: inlined into one loop body the register allocator merges their live ranges and
+// spills (624 VGPRs); each keeps the allocation it has in its own kernel (226) when it is compiled on its own
+__device__ __noinline__ void ov64_call_first(const float2 *in_blk, float2 *out_blk, const float2 *tw, unsigned c, int lane, float2 *Lw)
+{
+    fftbig_first_tile<false>(in_blk, out_blk, tw, 8, c, lane, Lw, nullptr);
+}
+__device__ __noinline__ void ov64_call_mid(const float2 *a_blk, float2 *b_blk, const float2 *Tf, const float2 *tw_i, const float2 *Hc, int c, int lane, float2 *Lw)
+{
+    ovsave64k_mid_tile(a_blk, b_blk, Tf, tw_i, Hc, c, lane, Lw);
+}
+__device__ __noinline__ void ov64_call_last(const float2 *b_blk, float2 *out_blk, const float2 *Ti, long hop, float scale, int c, int lane, float2 *Lw)
+{
+    ovsave64k_last_tile(b_blk, out_blk, Ti, hop, scale, c, lane, Lw);
+}
+
+__device__ __forceinline__ unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool ov64_wait(const unsigned *p, unsigned target, unsigned *err)
+{
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (ld_sc1(p) >= target) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+__global__ __launch_bounds__(64 * OV64T_MAX_WAVES) void ovsave64k_team_kernel(const float2 *__restrict__ x, long hop, float2 *scratch_a, float2 *scratch_b,
+                                                                       const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
+                                                                       const float2 *__restrict__ Tf, const float2 *__restrict__ Ti,
+                                                                       const float2 *__restrict__ Hc, float2 *__restrict__ out, long nblk, float scale,
+                                                                       Ov64TeamCtrl *ctrl, unsigned max_slots)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *Ls = reinterpret_cast<float2 *>(smem);
+    __shared__ unsigned sh_rank, sh_ok;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7;
+    if (threadIdx.x == 0) {
+        sh_rank = __hip_atomic_fetch_add(&ctrl->team[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctrl->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_ok = ov64_wait(&ctrl->registered, gridDim.x, &ctrl->error) ? 1u : 0u; // the teams are final once everybody has registered
+    }
+    __syncthreads();
+    if (!sh_ok) return;
+    // slots of this XCD and of the XCDs before it (every wave computes the same numbers from the final team sizes)
+    unsigned slot_base = 0, my_slots = 0, total_slots = 0;
+    for (unsigned k = 0; k < 8; ++k) {
+        unsigned n = (ld_sc1(&ctrl->team[k]) * (blockDim.x / 64)) / 16;
+        n = n < max_slots ? n : max_slots;
+        if (k < xcc) slot_base += n;
+        if (k == xcc) my_slots = n;
+        total_slots += n;
+    }
+    const unsigned R = sh_rank * (blockDim.x / 64) + w; // rank of this wave in its XCD team
+    if (R >= 16 * my_slots || total_slots == 0) return;
+    const unsigned g = slot_base + R / 16;                 // global slot
+    const int t = (int)(R % 16);                           // the tile this wave runs in every pass
+    float2 *Lw = Ls + w * F64W_REGION;
+    float2 *a_blk = scratch_a + (size_t)g * F64K_N, *b_blk = scratch_b + (size_t)g * F64K_N;
+    unsigned *cnt = &ctrl->cnt[32 * g];
+    unsigned phase = 0;
+    for (long blk = g; blk < nblk; blk += total_slots) {
+        ov64_call_first(x + blk * hop, a_blk, tw_f, (unsigned)t, lane, Lw);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's tile is in the XCD's L2
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++phase;
+        if (!ov64_wait(cnt, 16 * phase, &ctrl->error)) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's L1 copies of the scratch (the previous block's)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ov64_call_mid(a_blk, b_blk, Tf, tw_i, Hc, t, lane, Lw);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++phase;
+        if (!ov64_wait(cnt, 16 * phase, &ctrl->error)) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ov64_call_last(b_blk, out + blk * hop, Ti, hop, scale, t, lane, Lw);
+        // no barrier here: a wave that runs ahead writes `a` of the next block, which nobody reads any more (every wave
+        // passed the second barrier), and `b` is only written after the next first barrier, which needs all sixteen
+        // waves to have finished this pass
+    }
+}
+
+size_t ovsave64k_team_ctrl_bytes() { return sizeof(Ov64TeamCtrl); }
+// scratch_a / scratch_b: one block of 65536 cf32 per slot (8 XCDs x 2 waves_per_cu slots); ctrl: ovsave64k_team_ctrl_bytes(), zeroed here
+hipError_t launch_ovsave64k_team(const float2 *x, long hop, float2 *scratch_a, float2 *scratch_b, const float2 *tw_f, const float2 *tw_i,
+                                 const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, void *ctrl,
+                                 int ncu, int waves_per_cu, hipStream_t s)
+{
+    if (!Tf || !Ti || !ctrl || waves_per_cu < 1 || waves_per_cu > OV64T_MAX_WAVES) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(Ov64TeamCtrl), s);
+    if (e != hipSuccess) return e;
+    // more than half a CU's LDS per workgroup: never two on one CU, so a grid of one workgroup per CU is resident at once
+    const size_t lds = 84 * 1024;
+    static_assert(OV64T_MAX_WAVES * F64W_REGION * sizeof(float2) <= 84 * 1024, "wave regions");
+    auto kern = ovsave64k_team_kernel;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned max_slots = (unsigned)(2 * waves_per_cu); // per XCD (32 CUs x waves / 16); fewer where a team is smaller
+    hipLaunchKernelGGL(kern, dim3((unsigned)ncu), dim3(64 * waves_per_cu), lds, s, x, hop, scratch_a, scratch_b, tw_f, tw_i, Tf, Ti, Hc, out, nblk, scale,
+                       (Ov64TeamCtrl *)ctrl, max_slots);
+    return hipGetLastError();
 }
 
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
