@@ -1884,139 +1884,6 @@ hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const f
     return launch_fftbig<true>(a, b, bw.tw, bw.tw_pass, nblk, (long)fw.nfft, lgN, s, Hc, out, hop, scale);
 }
 
-// ---- overlap-save at 65536 points with the intermediate kept inside the XCD's L2 ---------------------------------
-// The three passes above stream the 512 KiB intermediate of every block through the fabric twice each: 3.1 x the
-// algorithmic bytes.  A 65536-point block cannot stay inside one CU (512 KiB against 160 KiB of LDS), but it does fit
-// an XCD's 4 MiB L2.  This persistent kernel therefore forms, per XCD, "slots" of sixteen wavefronts that own ONE block
-// at a time and run its three passes back to back -- tile t of pass A (gather + four stages), a slot barrier, tile t of
-// pass B (four stages, spectrum product, four inverse stages), a slot barrier, tile t of pass C (four stages, scale,
-// store) -- on a scratch pair of 2 x 512 KiB that belongs to the slot and is re-used for every block, so with the four
-// slots per XCD used here the scratch an XCD touches is 4 MiB and its lines are overwritten in L2 instead of travelling.
-// Same tile programs as the three kernels (fftbig_first_tile, ovsave64k_mid_tile, ovsave64k_last_tile): same bits.
-//
-// Placement is never ASSUMED (HIP promises none): a workgroup reads the XCD it actually runs on (HW_REG_XCC_ID) and
-// registers there; the teams are whatever landed on each XCD.  All hand-offs of a slot stay inside one XCD, whose L2 is
-// shared by its CUs: a producer's plain stores are in that L2 once its s_waitcnt vmcnt(0) returns (the vector L1 is
-// write-through), the slot barrier is one monotonic counter (agent-scope atomic add, polled with L1-bypassing loads),
-// and a consumer invalidates its own L1 (agent-scope acquire fence) before it reads.  No L2 write-back is needed or
-// issued.  Every spin is bounded: on a time-out the error word is set and the wave leaves (wrong results, never a hang).
-constexpr int OV64T_MAX_WAVES = 8;   // wavefronts per workgroup (one workgroup per CU: the LDS request keeps a second one out); 32 CUs x w
-                                     // waves = 2 w slots per XCD, (512 + 512) KiB of scratch each: w = 2 keeps an XCD's scratch at its 4 MiB L2
-struct Ov64TeamCtrl {
-    unsigned team[8];        // workgroups registered per XCD
-    unsigned registered;     // workgroups registered in all
-    unsigned error;          // set on a spin time-out
-    unsigned pad[6];
-    unsigned cnt[64 * 32];   // slot barrier counters, one per 128-byte line (global slot g at cnt[32 g])
-};
-static_assert(sizeof(Ov64TeamCtrl) == 64 + 64 * 128, "layout");
-
-// the three tile programs as real calls: inlined into one loop body the register allocator merges their live ranges and
-// spills (624 VGPRs); each keeps the allocation it has in its own kernel (226) when it is compiled on its own
-__device__ __noinline__ void ov64_call_first(const float2 *in_blk, float2 *out_blk, const float2 *tw, unsigned c, int lane, float2 *Lw)
-{
-    fftbig_first_tile<false>(in_blk, out_blk, tw, 8, c, lane, Lw, nullptr);
-}
-__device__ __noinline__ void ov64_call_mid(const float2 *a_blk, float2 *b_blk, const float2 *Tf, const float2 *tw_i, const float2 *Hc, int c, int lane, float2 *Lw)
-{
-    ovsave64k_mid_tile(a_blk, b_blk, Tf, tw_i, Hc, c, lane, Lw);
-}
-__device__ __noinline__ void ov64_call_last(const float2 *b_blk, float2 *out_blk, const float2 *Ti, long hop, float scale, int c, int lane, float2 *Lw)
-{
-    ovsave64k_last_tile(b_blk, out_blk, Ti, hop, scale, c, lane, Lw);
-}
-
-__device__ __forceinline__ unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool ov64_wait(const unsigned *p, unsigned target, unsigned *err)
-{
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (ld_sc1(p) >= target) return true;
-        __builtin_amdgcn_s_sleep(4);
-    }
-    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
-}
-
-__global__ __launch_bounds__(64 * OV64T_MAX_WAVES) void ovsave64k_team_kernel(const float2 *__restrict__ x, long hop, float2 *scratch_a, float2 *scratch_b,
-                                                                       const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
-                                                                       const float2 *__restrict__ Tf, const float2 *__restrict__ Ti,
-                                                                       const float2 *__restrict__ Hc, float2 *__restrict__ out, long nblk, float scale,
-                                                                       Ov64TeamCtrl *ctrl, unsigned max_slots)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *Ls = reinterpret_cast<float2 *>(smem);
-    __shared__ unsigned sh_rank, sh_ok;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned xcc = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7;
-    if (threadIdx.x == 0) {
-        sh_rank = __hip_atomic_fetch_add(&ctrl->team[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&ctrl->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_ok = ov64_wait(&ctrl->registered, gridDim.x, &ctrl->error) ? 1u : 0u; // the teams are final once everybody has registered
-    }
-    __syncthreads();
-    if (!sh_ok) return;
-    // slots of this XCD and of the XCDs before it (every wave computes the same numbers from the final team sizes)
-    unsigned slot_base = 0, my_slots = 0, total_slots = 0;
-    for (unsigned k = 0; k < 8; ++k) {
-        unsigned n = (ld_sc1(&ctrl->team[k]) * (blockDim.x / 64)) / 16;
-        n = n < max_slots ? n : max_slots;
-        if (k < xcc) slot_base += n;
-        if (k == xcc) my_slots = n;
-        total_slots += n;
-    }
-    const unsigned R = sh_rank * (blockDim.x / 64) + w; // rank of this wave in its XCD team
-    if (R >= 16 * my_slots || total_slots == 0) return;
-    const unsigned g = slot_base + R / 16;                 // global slot
-    const int t = (int)(R % 16);                           // the tile this wave runs in every pass
-    float2 *Lw = Ls + w * F64W_REGION;
-    float2 *a_blk = scratch_a + (size_t)g * F64K_N, *b_blk = scratch_b + (size_t)g * F64K_N;
-    unsigned *cnt = &ctrl->cnt[32 * g];
-    unsigned phase = 0;
-    for (long blk = g; blk < nblk; blk += total_slots) {
-        ov64_call_first(x + blk * hop, a_blk, tw_f, (unsigned)t, lane, Lw);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's tile is in the XCD's L2
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ++phase;
-        if (!ov64_wait(cnt, 16 * phase, &ctrl->error)) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's L1 copies of the scratch (the previous block's)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ov64_call_mid(a_blk, b_blk, Tf, tw_i, Hc, t, lane, Lw);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ++phase;
-        if (!ov64_wait(cnt, 16 * phase, &ctrl->error)) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ov64_call_last(b_blk, out + blk * hop, Ti, hop, scale, t, lane, Lw);
-        // no barrier here: a wave that runs ahead writes `a` of the next block, which nobody reads any more (every wave
-        // passed the second barrier), and `b` is only written after the next first barrier, which needs all sixteen
-        // waves to have finished this pass
-    }
-}
-
-size_t ovsave64k_team_ctrl_bytes() { return sizeof(Ov64TeamCtrl); }
-// scratch_a / scratch_b: one block of 65536 cf32 per slot (8 XCDs x 2 waves_per_cu slots); ctrl: ovsave64k_team_ctrl_bytes(), zeroed here
-hipError_t launch_ovsave64k_team(const float2 *x, long hop, float2 *scratch_a, float2 *scratch_b, const float2 *tw_f, const float2 *tw_i,
-                                 const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, void *ctrl,
-                                 int ncu, int waves_per_cu, hipStream_t s)
-{
-    if (!Tf || !Ti || !ctrl || waves_per_cu < 1 || waves_per_cu > OV64T_MAX_WAVES) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(Ov64TeamCtrl), s);
-    if (e != hipSuccess) return e;
-    // more than half a CU's LDS per workgroup: never two on one CU, so a grid of one workgroup per CU is resident at once
-    const size_t lds = 84 * 1024;
-    static_assert(OV64T_MAX_WAVES * F64W_REGION * sizeof(float2) <= 84 * 1024, "wave regions");
-    auto kern = ovsave64k_team_kernel;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const unsigned max_slots = (unsigned)(2 * waves_per_cu); // per XCD (32 CUs x waves / 16); fewer where a team is smaller
-    hipLaunchKernelGGL(kern, dim3((unsigned)ncu), dim3(64 * waves_per_cu), lds, s, x, hop, scratch_a, scratch_b, tw_f, tw_i, Tf, Ti, Hc, out, nblk, scale,
-                       (Ov64TeamCtrl *)ctrl, max_slots);
-    return hipGetLastError();
-}
-
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
                             const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, hipStream_t s)
 {

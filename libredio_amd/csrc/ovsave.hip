@@ -8,7 +8,6 @@
 #include "../../include/redio.h"
 #include "redio_internal.h"
 #include <new>
-#include <stdlib.h>
 #include <vector>
 
 namespace redio {
@@ -49,8 +48,6 @@ struct redio_ovsave {
     float2 *d_Hc;
     float2 *d_a, *d_b; // work buffers, chunk_blocks * nfft each
     size_t chunk_blocks;
-    void *d_team;      // 65536 points: control block of the L2-resident team kernel (fft_kernels.hip), else null
-    int team_path, ncu, team_waves;
 };
 
 // the plan structs live in redio_api.hip; reach the device plan through the public enqueue only
@@ -66,7 +63,7 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     redio_ovsave *p = new (std::nothrow) redio_ovsave();
     if (!p) return REDIO_ERR_NOMEM;
     p->device = dev; p->nfft = nfft; p->ntaps = ntaps; p->hop = (size_t)nfft - ntaps + 1;
-    p->fw = p->bw = nullptr; p->d_Hc = p->d_a = p->d_b = nullptr; p->d_team = nullptr; p->team_path = 0; p->ncu = 0;
+    p->fw = p->bw = nullptr; p->d_Hc = p->d_a = p->d_b = nullptr;
     // work buffers, only for the block sizes whose passes go through memory (the one-kernel sizes keep a block in
     // registers / LDS): about 64 MiB each, at least one block
     const bool one_kernel = nfft == 1024 || nfft == 2048 || nfft == 4096 || nfft == 8192 || nfft == 16384;
@@ -98,17 +95,6 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
         }
         if (one_kernel && d_pad) hipFree(d_pad);
     }
-    if (rc == REDIO_OK && e == hipSuccess && nfft == F64K_N) {
-        // measurement switch (tools, tests): REDIO_OVSAVE64K_PATH=passes keeps the three-launch form, =team forces the team kernel
-        const char *env = getenv("REDIO_OVSAVE64K_PATH");
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) p->ncu = prop.multiProcessorCount;
-        p->team_path = !(env && env[0] == 'p') && p->ncu >= 8 && p->chunk_blocks >= 128;
-        const char *wv = getenv("REDIO_OVSAVE64K_WAVES"); // tuning switch: wavefronts per CU of the team kernel (2 x that = slots per XCD)
-        p->team_waves = wv ? atoi(wv) : 2;
-        if (p->team_waves < 1 || p->team_waves > 8) p->team_waves = 2;
-        if (p->team_path) e = hipMalloc(&p->d_team, ovsave64k_team_ctrl_bytes());
-    }
     if (rc != REDIO_OK || e != hipSuccess) {
         redio_ovsave_destroy(p);
         return rc != REDIO_OK ? rc : hip_rc(e);
@@ -124,7 +110,6 @@ extern "C" int redio_ovsave_destroy(redio_ovsave *h)
     hipFree(h->d_Hc);
     if (h->d_a) hipFree(h->d_a);
     if (h->d_b) hipFree(h->d_b);
-    if (h->d_team) hipFree(h->d_team);
     delete h;
     return REDIO_OK;
 }
@@ -171,12 +156,6 @@ extern "C" int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_
         OV_TRY(launch_ovsave16k((const float2 *)d_in, (long)h->hop, redio_fft_twiddles_dev(h->fw), redio_fft_twiddles_dev(h->bw),
                                 redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc,
                                 (float2 *)d_out, (long)nblk, scale, st));
-        return REDIO_OK;
-    }
-    if (h->nfft == F64K_N && h->team_path && nblk >= 64) { // one persistent launch; short inputs keep the three-launch form
-        OV_TRY(launch_ovsave64k_team((const float2 *)d_in, (long)h->hop, h->d_a, h->d_b, redio_fft_twiddles_dev(h->fw), redio_fft_twiddles_dev(h->bw),
-                                     redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc, (float2 *)d_out, (long)nblk,
-                                     scale, h->d_team, h->ncu, h->team_waves, st));
         return REDIO_OK;
     }
     for (size_t b0 = 0; b0 < nblk; b0 += h->chunk_blocks) {

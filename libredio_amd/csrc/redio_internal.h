@@ -49,12 +49,6 @@ hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
                             const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, hipStream_t s);
 
-// the same with every block's three passes run back to back by sixteen wavefronts of ONE XCD, intermediate kept in that XCD's L2
-size_t ovsave64k_team_ctrl_bytes();
-hipError_t launch_ovsave64k_team(const float2 *x, long hop, float2 *scratch_a, float2 *scratch_b, const float2 *tw_f, const float2 *tw_i,
-                                 const float2 *Tf, const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, void *ctrl,
-                                 int ncu, int waves_per_cu, hipStream_t s);
-
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,

@@ -90,23 +90,16 @@ if "c3" in which or "c3big" in which:
         print(f"C3 resample 1/50 x{nch} ch, {frames} frames each ({name}): {best*1e3:.2f} ms  {nch*frames/best/1e9:.2f} GS/s  {b/best/1e9:.0f} GB/s algorithmic "
               f"({b/best/8e12:.1%} of 8 TB/s) | rooflines: HBM {t_hbm*1e3:.3f} ms, {bound} {t_valu*1e3:.3f} ms ({taps_per_out} taps/output, {cyc} issue cycles per tap-wave) "
               f"-> binding = {bound if t_valu > t_hbm else 'HBM'}, achieved {max(t_valu, t_hbm)/best:.1%} of it")
-if "c5" in which or "c5only" in which or "c5team" in which or "c5passes" in which:
-    import os
+if "c5" in which or "c5only" in which:
     for k in ((8193, 127) if "c5" in which else (8193,)):
-        for path in (("team", "passes") if ("c5" in which or "c5only" in which) else (("team",) if "c5team" in which else ("passes",))):
-            for wv in ((1, 2, 4, 8) if path == "team" and "c5only" in which else (None,)):
-                os.environ["REDIO_OVSAVE64K_PATH"] = path     # read at plan creation (measurement switch)
-                if wv: os.environ["REDIO_OVSAVE64K_WAVES"] = str(wv)
-                taps = R.dsputils.lpf_corrected(k, 0.08)
-                x = R.synth_iq(0x5EED0005, 0, n)
-                plan = R.OverlapSave(taps, 65536)
-                out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
-                ms = timeit(lambda: plan(x, out=out), n=10, warm=3)
-                hop = 65536 - k + 1
-                b = 8 * 65536 / hop + 8
-                print(f"C5 overlap-save N=65536 K={k} ({path}{', %d waves per CU' % wv if wv else ''}): {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  {b*out.numel()/ms/1e6:.0f} GB/s algorithmic ({b*out.numel()/ms/1e6/8000:.1%})")
-                os.environ.pop("REDIO_OVSAVE64K_WAVES", None)
-    os.environ.pop("REDIO_OVSAVE64K_PATH", None)
+        taps = R.dsputils.lpf_corrected(k, 0.08)
+        x = R.synth_iq(0x5EED0005, 0, n)
+        plan = R.OverlapSave(taps, 65536)
+        out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan(x, out=out), n=10, warm=3)
+        hop = 65536 - k + 1
+        b = 8 * 65536 / hop + 8
+        print(f"C5 overlap-save N=65536 K={k}: {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  {b*out.numel()/ms/1e6:.0f} GB/s algorithmic ({b*out.numel()/ms/1e6/8000:.1%})")
     for nfft, k in (((1024, 127), (1024, 63), (2048, 127), (2048, 513), (8192, 127), (32768, 127), (4096, 127), (4096, 1025), (16384, 127), (16384, 4097)) if "c5" in which else ()):
         taps = R.dsputils.lpf_corrected(k, 0.08)
         x = R.synth_iq(0x5EED0005, 0, n)
