@@ -261,5 +261,92 @@ inline void overlap_save(Receiver<View<std::complex<float>>> u, Sender<View<std:
     }
 }
 
+// ---- the windowed blocks as STREAMS: history carried across messages on the device (redio_*_stream_*, include/redio.h) ----
+// The blocks above keep the reference's per-message semantics (dsputils::convolve is stateless, dsputils.rs:30-32: a
+// message seam costs ntaps - 1 outputs).  These carry the stream's unconsumed tail in HBM, so the concatenation of their
+// output messages does not depend on how the input was cut into messages; a message that completes no
+// output unit sends nothing.
+inline void fir_stream(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, size_t decim, bool fused)
+{
+    BlockStream st;
+    redio_fir *h = nullptr;
+    check(redio_fir_create(&h, taps.data(), taps.size(), decim, REDIO_FIR_COMPLEX | (fused ? REDIO_FIR_FUSED : 0)));
+    redio_fir_stream *s = nullptr;
+    const int rc = redio_fir_stream_create(&s, h);
+    struct G { redio_fir *h; redio_fir_stream *s; ~G() { redio_fir_stream_destroy(s); redio_fir_destroy(h); } } g{h, s};
+    check(rc);
+    for (;;) {
+        auto d = u.recv();
+        const size_t n = redio_fir_stream_nout(s, d.len);
+        auto o = make<std::complex<float>>(n);
+        size_t got = 0;
+        check(redio_fir_stream_enqueue(s, d.data(), d.len, o.data(), &got, st));
+        check(redio_stream_sync(st)); // the input view may be released once the seam has been staged
+        if (n) v.send_unwrap(std::move(o));
+    }
+}
+
+inline void fir_fft_chain_stream(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps,
+                                 size_t decim, int nfft, bool fused)
+{
+    BlockStream st;
+    redio_chain *h = nullptr;
+    check(redio_chain_create(&h, taps.data(), taps.size(), decim, nfft, fused ? REDIO_FIR_FUSED : 0));
+    redio_chain_stream *s = nullptr;
+    const int rc = redio_chain_stream_create(&s, h);
+    struct G { redio_chain *h; redio_chain_stream *s; ~G() { redio_chain_stream_destroy(s); redio_chain_destroy(h); } } g{h, s};
+    check(rc);
+    for (;;) {
+        auto d = u.recv();
+        const size_t n = redio_chain_stream_nout(s, d.len);
+        auto o = make<std::complex<float>>(n);
+        size_t got = 0;
+        check(redio_chain_stream_enqueue(s, d.data(), d.len, o.data(), &got, st));
+        check(redio_stream_sync(st));
+        if (n) v.send_unwrap(std::move(o));
+    }
+}
+
+inline void channelizer_stream(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> proto, int nchan,
+                               int taps_per_branch, bool fused)
+{
+    BlockStream st;
+    redio_pfb *h = nullptr;
+    check(redio_pfb_create(&h, proto.data(), nchan, taps_per_branch, fused ? REDIO_FIR_FUSED : 0));
+    redio_pfb_stream *s = nullptr;
+    const int rc = redio_pfb_stream_create(&s, h);
+    struct G { redio_pfb *h; redio_pfb_stream *s; ~G() { redio_pfb_stream_destroy(s); redio_pfb_destroy(h); } } g{h, s};
+    check(rc);
+    for (;;) {
+        auto d = u.recv();
+        const size_t n = redio_pfb_stream_nout(s, d.len);
+        auto o = make<std::complex<float>>(n);
+        size_t got = 0;
+        check(redio_pfb_stream_enqueue(s, d.data(), d.len, o.data(), &got, st));
+        check(redio_stream_sync(st));
+        if (n) v.send_unwrap(std::move(o));
+    }
+}
+
+inline void overlap_save_stream(Receiver<View<std::complex<float>>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, int nfft)
+{
+    BlockStream st;
+    redio_ovsave *h = nullptr;
+    check(redio_ovsave_create(&h, taps.data(), taps.size(), nfft));
+    redio_ovsave_stream *s = nullptr;
+    const int rc = redio_ovsave_stream_create(&s, h);
+    struct G { redio_ovsave *h; redio_ovsave_stream *s; ~G() { redio_ovsave_stream_destroy(s); redio_ovsave_destroy(h); } } g{h, s};
+    check(rc);
+    for (;;) {
+        auto d = u.recv();
+        const size_t n = redio_ovsave_stream_nout(s, d.len);
+        auto o = make<std::complex<float>>(n);
+        size_t got = 0;
+        check(redio_ovsave_stream_enqueue(s, d.data(), d.len, o.data(), &got, st));
+        check(redio_stream_sync(st));
+        if (n) v.send_unwrap(std::move(o));
+    }
+}
+
 } // namespace dev
 } // namespace kpn

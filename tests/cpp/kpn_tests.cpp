@@ -431,6 +431,55 @@ static int dev_bank_graph(const char *in, const char *out_pfb, const char *out_o
     return 0;
 }
 
+// a stream cut into messages of awkward, varying lengths through the carried-history blocks: the concatenated outputs are those
+// of ONE stateless call on the whole stream
+static int dev_stream_graph(const char *in, const char *out_chain, const char *out_fir, const char *out_ovs, size_t seed)
+{
+    using cf = std::complex<float>;
+    auto x = read_bin<cf>(in);
+    const std::vector<float> taps = dsputils::lpf_corrected(127, 0.08f);
+    auto [s0, r0] = channel<std::vector<cf>>();
+    auto [s1, r1] = channel<dev::View<cf>>();
+    std::vector<Sender<dev::View<cf>>> outs;
+    std::vector<Receiver<dev::View<cf>>> ins;
+    for (int i = 0; i < 3; ++i) { auto [a, b] = channel<dev::View<cf>>(); outs.push_back(std::move(a)); ins.push_back(std::move(b)); }
+    auto [c0, d0] = channel<dev::View<cf>>();
+    auto [c1, d1] = channel<dev::View<cf>>();
+    auto [c2, d2] = channel<dev::View<cf>>();
+    auto [e0, f0] = channel<std::vector<cf>>();
+    auto [e1, f1] = channel<std::vector<cf>>();
+    auto [e2, f2] = channel<std::vector<cf>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &x, seed]() mutable {
+        uint64_t r = seed * 6364136223846793005ull + 1442695040888963407ull;
+        for (size_t o = 0; o < x.size();) {
+            r = r * 6364136223846793005ull + 1442695040888963407ull;
+            const size_t pick[6] = {1, 125, 126, 5119, 20001, 70000};
+            size_t m = pick[(r >> 33) % 6];
+            if (o + m > x.size()) m = x.size() - o;
+            s.send(std::vector<cf>(x.begin() + (long)o, x.begin() + (long)(o + m)));
+            o += m;
+        }
+    }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { dev::to_device<cf>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r1), o = std::move(outs)]() mutable { fork<dev::View<cf>>(std::move(r), std::move(o)); }));
+    th.push_back(spawn([r = std::move(ins[0]), s = std::move(c0), taps]() mutable { dev::fir_fft_chain_stream(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    th.push_back(spawn([r = std::move(ins[1]), s = std::move(c1), taps]() mutable { dev::fir_stream(std::move(r), std::move(s), taps, 5, false); }));
+    th.push_back(spawn([r = std::move(ins[2]), s = std::move(c2), taps]() mutable { dev::overlap_save_stream(std::move(r), std::move(s), taps, 4096); }));
+    th.push_back(spawn([r = std::move(d0), s = std::move(e0)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(d1), s = std::move(e1)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(d2), s = std::move(e2)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    std::vector<cf> a, b, c;
+    while (auto v = f0.try_recv_blocking()) a.insert(a.end(), v->begin(), v->end());
+    while (auto v = f1.try_recv_blocking()) b.insert(b.end(), v->begin(), v->end());
+    while (auto v = f2.try_recv_blocking()) c.insert(c.end(), v->begin(), v->end());
+    for (auto &t : th) t.join();
+    write_bin(out_chain, a);
+    write_bin(out_fir, b);
+    write_bin(out_ovs, c);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -439,6 +488,7 @@ int main(int argc, char **argv)
         if (mode == "c1" && argc == 4) return c1(argv[2], argv[3]);
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
         if (mode == "devchain" && argc == 6) return dev_chain_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
+        if (mode == "devstream" && argc == 7) return dev_stream_graph(argv[2], argv[3], argv[4], argv[5], (size_t)std::atol(argv[6]));
         if (mode == "devshaper" && argc == 6) return dev_shaper_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]));
         if (mode == "devmix" && argc == 6) return dev_mix_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), std::atof(argv[5]));
         if (mode == "devbank" && argc == 6) return dev_bank_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));

@@ -140,3 +140,19 @@ def test_exchange_through_the_c_abi_on_every_visible_device(gpu, redio, oracle):
         gpu.cuda.synchronize()
         assert np.array_equal(bits(one.cpu().numpy()), bits(want))
     gpu.cuda.set_device(0)
+
+
+def test_bench_c4_launcher_correctness_half(gpu, redio):
+    """tools/bench_c4.py --check under torch.distributed.run, one rank per visible device (the launcher the 8-GPU node will use:
+    `python -m torch.distributed.run --nproc-per-node 8 tools/bench_c4.py --gpus 8`), exchange through the C ABI (RCCL)."""
+    import os, subprocess, sys
+    ndev = gpu.cuda.device_count()
+    while 64 % ndev:
+        ndev -= 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ndev}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "tools", "bench_c4.py"), "--gpus", str(ndev), "--check"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert '"ok": true' in out.stdout

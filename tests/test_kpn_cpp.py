@@ -110,6 +110,26 @@ def test_device_resident_graph_fork_chain_and_fir(exe, gpu, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tmp_path, seed):
+    """include/kpn_dev.hpp stream blocks (redio_*_stream_*): a stream cut into messages of 1 ... 70000 samples gives, message
+    seams or not, exactly the outputs of one stateless call on the whole stream (SURVEY.md 8d C2 "history carried")."""
+    n = 300000 + 7
+    x = oracle.synth_iq(0x5EED0002, 0, n)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "devstream", str(tmp_path / "in.bin"), str(tmp_path / "spec.bin"), str(tmp_path / "fir.bin"),
+                          str(tmp_path / "ovs.bin"), str(seed)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    taps = oracle.lpf_corrected(127, 0.08)
+    spec = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
+    fir = np.fromfile(tmp_path / "fir.bin", dtype=np.complex64)
+    ovs = np.fromfile(tmp_path / "ovs.bin", dtype=np.complex64)
+    assert np.array_equal(bits(spec), bits(oracle.chain_fir_fft(x, taps, 5, 1024, True).reshape(-1)))
+    assert np.array_equal(bits(fir), bits(oracle.fir(x, taps, 5, False)))
+    assert np.array_equal(bits(ovs), bits(oracle.overlap_save(x, taps, 4096)))
+
+
+@pytest.mark.gpu
 def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
     x = oracle.synth_f32(3, 0, 10000)
     x.tofile(tmp_path / "in.bin")
