@@ -127,7 +127,7 @@ def test_exchange_through_the_c_abi_on_every_visible_device(gpu, redio, oracle):
         first, nout, nin = sharding.channelizer_time_shard(g, ndev, total_rows, P)
         with gpu.cuda.device(g):
             xs = gpu.from_numpy(x[M * first: M * (first + nin)]).cuda(g)
-            grouped.append(redio.Channelizer(h)(xs, ngroups=ndev))
+            grouped.append(redio.Channelizer(h)(xs, ngroups=ndev).reshape(ndev, -1, cpg))   # ngroups == 1 comes back as [row][channel]
             rows.append(nout)
             assert grouped[-1].shape == (ndev, nout, cpg)
     outs = plans.exchange_all(comms, grouped, rows)

@@ -68,7 +68,7 @@ def main():
         xs = O.synth_iq(0x5EED0004, 0, M * total_rows)
         want = O.pfb_channelizer(xs, h, M, P, True)
         first, nout, nin = sharding.channelizer_time_shard(rank, world, total_rows, P)
-        g = plan(torch.from_numpy(xs[M * first: M * (first + nin)]).cuda(), ngroups=world)
+        g = plan(torch.from_numpy(xs[M * first: M * (first + nin)]).cuda(), ngroups=world).reshape(world, nout, cpg)
         rows = [sharding.channelizer_time_shard(q, world, total_rows, P)[1] for q in range(world)]
         got = (comm.exchange(g, rows) if use_cabi else R.channelizer_all_to_all(g)).cpu().numpy()
         ok = np.array_equal(got.view(np.uint32), np.ascontiguousarray(want[:, rank * cpg:(rank + 1) * cpg]).view(np.uint32))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Host-resident input end to end: pinned host buffers -> H2D copy on one HIP stream while the previous chunk
-runs data_to_samples -> FIR/5 -> FFT-1024 on another (double buffered).  Reports the PCIe-inclusive rate, which
-is what a host that hands over host buffers gets; never bench.py's `value`.
+runs data_to_samples -> FIR/5 -> FFT-1024 on another (double buffered).  The chain runs as a STREAM
+(redio_chain_stream_*): the 126-sample FIR seam and the partial block at the end of every chunk are carried on the
+device, so the spectra are those of the uninterrupted stream -- nothing is lost at chunk boundaries.  Reports the
+PCIe-inclusive rate, which is what a host that hands over host buffers gets; never bench.py's `value`.
 
     python tools/stream_pipeline.py [u8|cf32] [chunks] [log2 samples per chunk]"""
 import sys, os, time
@@ -15,7 +17,8 @@ nchunks = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n = 1 << (int(sys.argv[3]) if len(sys.argv) > 3 else 26)
 taps = R.dsputils.lpf_corrected(127, 0.08)
 chain = R.Chain(taps, 5, 1024, fused=True)
-nblk = chain.nblocks(n)
+stream = R.Stream(chain)
+nblk = chain.nblocks(n) + 1          # a chunk can complete one block more than it holds (the carried partial block)
 bytes_per_sample = 2 if fmt == "u8" else 8
 host = [torch.randint(0, 256, (n * bytes_per_sample,), dtype=torch.uint8).pin_memory() for _ in range(2)]
 dev_raw = [torch.empty(n * bytes_per_sample, dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -35,7 +38,7 @@ def run(chunks):
         with torch.cuda.stream(comp_s):
             comp_s.wait_event(copied[b])
             x = B.data_to_samples(dev_raw[b]) if fmt == "u8" else dev_raw[b].view(torch.complex64)
-            chain(x, dev_out[b])
+            stream(x, out=dev_out[b].view(-1))   # history carried: [tail | chunk] without copying the chunk
             done[b].record(comp_s)
     torch.cuda.synchronize()
 
