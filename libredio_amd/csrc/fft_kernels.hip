@@ -1884,15 +1884,49 @@ hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const f
     return launch_fftbig<true>(a, b, bw.tw, bw.tw_pass, nblk, (long)fw.nfft, lgN, s, Hc, out, hop, scale);
 }
 
-hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
-                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, float scale, hipStream_t s)
+// the last pass of one chunk and the first pass of the NEXT chunk in one launch: the two are independent (b -> out, x -> a; the
+// middle pass of the earlier chunk has finished with a), so their load and store phases overlap and a chunk costs two launches
+// instead of three.  Workgroups alternate between the two tile programs.
+__global__ __launch_bounds__(256, 2) void ovsave64k_last_first_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
+                                                                   const float2 *__restrict__ Ti, long hop, float scale, long ntiles_last,
+                                                                   const float2 *__restrict__ x_next, float2 *__restrict__ a_out,
+                                                                   const float2 *__restrict__ tw_f, long ntiles_first)
 {
-    if (!Tf || !Ti) return hipErrorInvalidValue; // the plans' pass-ordered twiddle copies (fftbig_tables_build)
-    const long ntiles = nblk * 16;
-    const unsigned grid = (unsigned)((ntiles + 3) / 4);
-    hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3(grid), dim3(256), 0, s, x, a, tw_f, hop, ntiles, 8);
-    hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3(grid), dim3(256), 0, s, a, b, Tf, tw_i, Hc, ntiles);
-    hipLaunchKernelGGL(ovsave64k_last_wave_kernel, dim3(grid), dim3(256), 0, s, b, out, Ti, hop, scale, ntiles);
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *Lw = Ls + w * F64W_REGION;
+    // workgroup b: kind = b & 1 while both kinds have work left, the longer kind takes the rest
+    const long nb_last = (ntiles_last + 3) / 4, nb_first = (ntiles_first + 3) / 4, both = 2 * (nb_last < nb_first ? nb_last : nb_first);
+    const long b = blockIdx.x;
+    bool first;
+    long wg;
+    if (b < both) { first = (b & 1) != 0; wg = b >> 1; }
+    else { first = nb_first > nb_last; wg = (both >> 1) + (b - both); }
+    const long tile = wg * 4 + w;
+    if (first) {
+        if (tile >= ntiles_first) return;
+        fftbig_first_tile<false>(x_next + (tile >> 4) * hop, a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr);
+    } else {
+        if (tile >= ntiles_last) return;
+        ovsave64k_last_tile(b_in + (tile >> 4) * (long)F64K_N, out + (tile >> 4) * hop, Ti, hop, scale, (int)(tile & 15), lane, Lw);
+    }
+}
+
+// nblk blocks in chunks of `chunk` blocks (the work buffers a, b hold one chunk each)
+hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
+                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, long chunk, float scale, hipStream_t s)
+{
+    if (!Tf || !Ti || chunk < 1) return hipErrorInvalidValue; // the plans' pass-ordered twiddle copies (fftbig_tables_build)
+    auto tiles = [&](long b0) { const long nb = nblk - b0 < chunk ? nblk - b0 : chunk; return nb * 16; };
+    hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8);
+    for (long b0 = 0; b0 < nblk; b0 += chunk) {
+        const long nt = tiles(b0), next = b0 + chunk;
+        hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, a, b, Tf, tw_i, Hc, nt);
+        const long ntn = next < nblk ? tiles(next) : 0;
+        const unsigned grid = (unsigned)((nt + 3) / 4 + (ntn + 3) / 4);
+        hipLaunchKernelGGL(ovsave64k_last_first_kernel, dim3(grid), dim3(256), 0, s, b, out + b0 * hop, Ti, hop, scale, nt,
+                           x + next * hop, a, tw_f, ntn);
+    }
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #include "../../include/redio.h"
 #include "redio_internal.h"
 #include <new>
+#include <stdlib.h>
 #include <vector>
 
 namespace redio {
@@ -67,7 +68,9 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     // work buffers, only for the block sizes whose passes go through memory (the one-kernel sizes keep a block in
     // registers / LDS): about 64 MiB each, at least one block
     const bool one_kernel = nfft == 1024 || nfft == 2048 || nfft == 4096 || nfft == 8192 || nfft == 16384;
-    p->chunk_blocks = (size_t)(64u << 20) / ((size_t)nfft * sizeof(float2)); // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
+    size_t chunk_mib = 64;
+    if (const char *env = getenv("REDIO_OVSAVE_CHUNK_MIB")) { const int v = atoi(env); if (v >= 1 && v <= 1024) chunk_mib = (size_t)v; } // tuning switch (tools)
+    p->chunk_blocks = (chunk_mib << 20) / ((size_t)nfft * sizeof(float2)); // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
     if (p->chunk_blocks < 1) p->chunk_blocks = 1;
     int rc = redio_fft_create(&p->fw, nfft, 0);
     if (rc == REDIO_OK) rc = redio_fft_create(&p->bw, nfft, 1);
@@ -158,14 +161,15 @@ extern "C" int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_
                                 (float2 *)d_out, (long)nblk, scale, st));
         return REDIO_OK;
     }
+    if (h->nfft == F64K_N) { // three fused passes per chunk, the last of a chunk sharing a launch with the first of the next (fft_kernels.hip)
+        OV_TRY(launch_ovsave64k((const float2 *)d_in, (long)h->hop, h->d_a, h->d_b, redio_fft_twiddles_dev(h->fw), redio_fft_twiddles_dev(h->bw),
+                                redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc, (float2 *)d_out, (long)nblk,
+                                (long)h->chunk_blocks, scale, st));
+        return REDIO_OK;
+    }
     for (size_t b0 = 0; b0 < nblk; b0 += h->chunk_blocks) {
         const size_t nb = (nblk - b0 < h->chunk_blocks) ? nblk - b0 : h->chunk_blocks;
         const long total = (long)(nb * (size_t)h->nfft);
-        if (h->nfft == F64K_N) { // three fused passes (fft_kernels.hip), bit-identical to the generic sequence below
-            OV_TRY(launch_ovsave64k((const float2 *)d_in + b0 * h->hop, (long)h->hop, h->d_a, h->d_b, redio_fft_twiddles_dev(h->fw),
-                                    redio_fft_twiddles_dev(h->bw), redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc, (float2 *)d_out + b0 * h->hop, (long)nb, scale, st));
-            continue;
-        }
         if (ovsave_big_size(h->nfft)) { // the product and the scaled copy ride on the inverse transform's first and last pass
             OV_TRY(launch_ovsave_big(*redio_fft_plan_dev(h->fw), *redio_fft_plan_dev(h->bw), (const float2 *)d_in + b0 * h->hop, (long)h->hop, h->d_a,
                                      h->d_b, h->d_Hc, (float2 *)d_out + b0 * h->hop, (long)nb, scale, st));
