@@ -205,8 +205,8 @@ __device__ __forceinline__ float win_load(const SrcWindow &w, int ch, long a)
 // them is stored, the source select (old image / new input) is a pointer select so the loads carry no
 // branch, and samples at or past `need` (they belong to no valid output and may not exist) read a
 // clamped address and store zero.
-template <int NT, int U>
-__device__ __forceinline__ void src_tile_load(float *xs, const SrcWindow &w, int ch, long tile_base, int span, int need, int B, int P)
+template <int NT, int U, typename XT = float>
+__device__ __forceinline__ void src_tile_load(XT *xs, const SrcWindow &w, int ch, long tile_base, int span, int need, int B, int P)
 {
     const int tid = threadIdx.x;
     const float *old_row = w.old_img + (long)ch * w.old_stride;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void src_tile_load(float *xs, const SrcWindow &w, int
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int n = n0 + u * NT;
-            if (n < span) xs[n + P * q] = n < need ? v[u] : 0.0f;
+            if (n < span) xs[n + P * q] = n < need ? (XT)v[u] : (XT)0;
             if (P) { q += dq; r += dr; if (r >= B) { r -= B; ++q; } }
         }
     }
@@ -242,12 +242,12 @@ __device__ __forceinline__ void src_tile_load(float *xs, const SrcWindow &w, int
 // coefficient stream and the double-buffered taps fit the SGPR file.
 struct WingCursor { int lrem, lquo, rrem, rquo; };
 
-template <int U, bool PAD>
-__device__ __forceinline__ void wings_fetch(const float *xs, int lbase, int c, int S, const double *__restrict__ tab, int t,
-                                            WingCursor &w, float (&xl)[U], float (&xr)[U], double (&k)[U])
+template <int U, bool PAD, typename XT>
+__device__ __forceinline__ void wings_fetch(const XT *xs, int lbase, int c, int S, const double *__restrict__ tab, int t,
+                                            WingCursor &w, XT (&xl)[U], XT (&xr)[U], double (&k)[U])
 {
     if (!PAD) { // plain layout: one base address per wing, the U reads differ by immediate offsets
-        const float *pl = xs + lbase + t, *pr = xs + lbase + (c - t - (U - 1));
+        const XT *pl = xs + lbase + t, *pr = xs + lbase + (c - t - (U - 1));
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             xl[j] = pl[j];
@@ -266,12 +266,13 @@ __device__ __forceinline__ void wings_fetch(const float *xs, int lbase, int c, i
     }
 }
 
-// one pad float per S samples only when the lane stride S would put 8 or more lanes on a bank
-// (S % 8 == 0); a 2- or 4-way ds_read_b32 conflict costs less than the f64 arithmetic it feeds
-__host__ __device__ __forceinline__ int src_tile_pad(int S) { return (S % 8 == 0) ? 1 : 0; }
+// float tiles: one pad float per S samples only when the lane stride S would put 8 or more lanes on a bank
+// (S % 8 == 0); a 2- or 4-way ds_read_b32 conflict costs less than the f64 arithmetic it feeds.
+// double tiles (ds_read_b64): an odd lane stride is conflict-free, so an even S gets one pad double per S samples.
+__host__ __device__ __forceinline__ int src_tile_pad(int S, bool f64_tile = false) { return f64_tile ? ((S % 2 == 0) ? 1 : 0) : ((S % 8 == 0) ? 1 : 0); }
 
-template <int U, bool PAD>
-__device__ __forceinline__ void sinc_wings(const float *xs, int lbase, int S, const double *__restrict__ cl_rev,
+template <int U, bool PAD, typename XT = float>
+__device__ __forceinline__ void sinc_wings(const XT *xs, int lbase, int S, const double *__restrict__ cl_rev,
                                            const double *__restrict__ cr_rev, int cl, int cr, double &left, double &right)
 {
     constexpr int pad = PAD ? 1 : 0;
@@ -283,39 +284,46 @@ __device__ __forceinline__ void sinc_wings(const float *xs, int lbase, int S, co
     int t = 0;
     if (cr == cl - 1) {
         const int nsteps = (both + 1) / U;
-        float xl[U], xr[U];
-        double k[U];
-        if (nsteps > 0) wings_fetch<U, PAD>(xs, lbase, c, S, cl_rev, 0, w, xl, xr, k);
+        // two register sets used alternately (the loop body is the pipeline step written twice): the fetch of step i + 1 goes
+        // into the set that step i - 1 has finished with, so nothing is copied between steps (a rotating single set costs
+        // 32 v_mov_b32 per step: 5.1 vector instructions per tap instead of the 3 that do arithmetic)
+        XT xlA[U], xrA[U], xlB[U], xrB[U];
+        double kA[U], kB[U];
+        auto land = [&](XT (&xl)[U], XT (&xr)[U], double (&k)[U]) { // the one lgkmcnt(0) of a step lands here, not after the next issue
 #pragma unroll
-        for (int j = 0; j < U; ++j) { // land the first fetch before the loop so the loop header carries no pending load
-            asm volatile("" : "+v"(xl[j]), "+v"(xr[j]));
-            asm volatile("" : "+s"(k[j]));
-        }
-        for (int i = 0; i < nsteps; ++i) {
-            float nxl[U], nxr[U];
-            double nk[U];
-            if (i + 1 < nsteps) wings_fetch<U, PAD>(xs, lbase, c, S, cl_rev, (i + 1) * U, w, nxl, nxr, nk);
-            RD_SCHED_BARRIER();
+            for (int j = 0; j < U; ++j) {
+                asm volatile("" : "+v"(xl[j]), "+v"(xr[j]));
+                asm volatile("" : "+s"(k[j]));
+            }
+        };
+        auto compute = [&](const XT (&xl)[U], const XT (&xr)[U], const double (&k)[U]) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 left += k[j] * (double)xl[j];
                 right += k[j] * (double)xr[j];
             }
+        };
+        if (nsteps > 0) { wings_fetch<U, PAD, XT>(xs, lbase, c, S, cl_rev, 0, w, xlA, xrA, kA); land(xlA, xrA, kA); }
+        int i = 0;
+        for (; i + 1 < nsteps; i += 2) {
+            wings_fetch<U, PAD, XT>(xs, lbase, c, S, cl_rev, (i + 1) * U, w, xlB, xrB, kB);
             RD_SCHED_BARRIER();
-            // land the prefetch here (the one lgkmcnt(0) of the step), not after the next issue
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                asm volatile("" : "+v"(nxl[j]), "+v"(nxr[j]));
-                asm volatile("" : "+s"(nk[j]));
-                xl[j] = nxl[j]; xr[j] = nxr[j]; k[j] = nk[j];
-            }
+            compute(xlA, xrA, kA);
+            RD_SCHED_BARRIER();
+            land(xlB, xrB, kB);
+            if (i + 2 < nsteps) wings_fetch<U, PAD, XT>(xs, lbase, c, S, cl_rev, (i + 2) * U, w, xlA, xrA, kA);
+            RD_SCHED_BARRIER();
+            compute(xlB, xrB, kB);
+            RD_SCHED_BARRIER();
+            if (i + 2 < nsteps) land(xlA, xrA, kA);
         }
+        if (i < nsteps) compute(xlA, xrA, kA); // an odd number of steps: the last one is already fetched
         t = nsteps * U;
     }
     const double *__restrict__ kr_tab = (cr == cl - 1) ? cl_rev : cr_rev;
     for (; t <= both; ++t) {
-        const float xl = xs[lbase + t + (pad ? w.lquo : 0)];
-        const float xr = xs[lbase + (c - t) + (pad ? w.rquo : 0)];
+        const XT xl = xs[lbase + t + (pad ? w.lquo : 0)];
+        const XT xr = xs[lbase + (c - t) + (pad ? w.rquo : 0)];
         left += cl_rev[t] * (double)xl;
         right += kr_tab[t] * (double)xr;
         if (++w.lrem == S) { w.lrem = 0; ++w.lquo; }
@@ -419,28 +427,32 @@ hipError_t launch_src_uniform(const float *win, long win_stride, const double *c
 // The whole call as ONE launch: the stream window is [old buffer image | new input] addressed by an
 // absolute index a (a < a_in0 -> old image, else input), output k sits at a0 + S*k.  Same arithmetic
 // as src_sinc_uniform_kernel (bit-identical), no per-refill launches.
-template <int NT>
+// XT is the element type of the LDS tile.  XT = double (each sample converted once while the tile is staged, no v_cvt_f64_f32 per
+// tap) is bit-identical but was measured SLOWER at 1/50 -- the double tile of 256 outputs fills a CU's LDS: 12.9 ms with one
+// thread per output (four waves per CU), 8.3 ms with the two wings of an output on two threads (eight waves), against 3.6 ms
+// for the float tile at two workgroups per CU -- so every launch uses XT = float (profiles/r02_c3_experiments.txt).
+template <int NT, typename XT = float>
 __global__ __launch_bounds__(NT) void src_window_exact_kernel(SrcWindow w, const double *__restrict__ cl_rev, int ncl,
                                                               const double *__restrict__ cr_rev, int ncr, long a0, int S, double scale,
                                                               float *__restrict__ out, long out_stride, long nout)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *xs = reinterpret_cast<float *>(smem);
+    XT *xs = reinterpret_cast<XT *>(smem);
     const int tid = threadIdx.x, ch = blockIdx.y;
     const long k0 = (long)blockIdx.x * NT;
-    const int pad = src_tile_pad(S);
+    const int pad = src_tile_pad(S, sizeof(XT) == 8);
     const int cl = ncl - 1, cr = ncr - 1;
     const long tile_base = a0 + (long)S * k0 - cl;
     const int span = (NT - 1) * S + cl + cr + 2;
     const long nvalid = (nout - k0 < NT) ? nout - k0 : NT;
     const int need = (int)((nvalid - 1) * S) + cl + cr + 2;
-    src_tile_load<NT, 8>(xs, w, ch, tile_base, span, need, S, pad);
+    src_tile_load<NT, 8, XT>(xs, w, ch, tile_base, span, need, S, pad);
     __syncthreads();
     if (k0 + tid >= nout) return;
     const int lbase = (S + pad) * tid;
     double left = 0.0, right = 0.0;
-    if (pad) sinc_wings<8, true>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
-    else sinc_wings<8, false>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
+    if (pad) sinc_wings<8, true, XT>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
+    else sinc_wings<8, false, XT>(xs, lbase, S, cl_rev, cr_rev, cl, cr, left, right);
     out[(long)ch * out_stride + k0 + tid] = (float)(scale * (left + right));
 }
 

@@ -78,12 +78,13 @@ if "c3" in which or "c3big" in which:
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         b = nch * frames * 4 * (1 + 0.02)
         # the binding roofline (report min(HBM, VALU)): EXACT does v_cvt_f64_f32 + v_mul_f64 + v_add_f64 per tap and
-        # lane, 3 instructions x 4 issue cycles per wave64 (f64 vector peak = half the f32 rate), on 1024 SIMDs at 2.4 GHz;
-        # FAST does one v_pk_fma_f32 per two taps (4 cycles).  Taps per output: both wings of the stretched filter.
+        # lane on 1024 SIMDs at 2.4 GHz; FAST does one v_pk_fma_f32 per two taps.  Taps per output: both wings of the stretched filter.
         tab_half, tab_inc = 22438 - 2, 491
         taps_per_out = 2 * int(tab_half / (tab_inc * 0.02)) + 1
         tap_waves = nch * frames * 0.02 * taps_per_out / 64
-        cyc = 12 if mode != R.Src.FAST else 2
+        # EXACT: 13.3 cycle-equivalents per tap-wave measured for cvt + mul + add back to back (tools/valu_rate_f64.hip,
+        # profiles/r02_c3_experiments.txt; the three instructions issue in 4.3-5.7 cycles each); FAST: one 4-cycle v_pk_fma_f32 per two taps
+        cyc = 13.3 if mode != R.Src.FAST else 2
         t_valu = tap_waves * cyc / 1024 / 2.4e9
         t_hbm = b / 8e12
         bound = "VALU f64" if mode != R.Src.FAST else "VALU f32"
