@@ -53,3 +53,29 @@ def test_graph_errors(gpu, redio):
     assert L.redio_graph_begin(None) == -1            # the default stream cannot be captured
     assert L.redio_graph_launch(None, None) == -1
     assert L.redio_graph_destroy(None) == 0
+
+
+def test_plan_scratch_is_reserved_not_grown_inside_a_capture(gpu, redio, oracle):
+    """include/redio.h: *_enqueue only launches kernels.  The few paths with a plan-owned intermediate (here the two-kernel
+    chain of a shape without a fused kernel) size it with *_reserve(); an un-reserved plan refuses to allocate while its
+    stream is being captured (REDIO_ERR_NOT_RESERVED = -6) instead of breaking the capture with a hipMalloc."""
+    taps = oracle.lpf_corrected(31, 0.1)
+    n = 4 * 64 * 4 + 27 + 5
+    x = oracle.synth_iq(9, 0, n)
+    d = gpu.from_numpy(x).cuda()
+    want = oracle.chain_fir_fft(x, taps, 4, 64, fused=False)
+    chain = redio.Chain(taps, 4, 64, fused=False)
+    assert not chain.is_fused
+    out = gpu.zeros((chain.nblocks(n), 64), dtype=gpu.complex64, device="cuda")
+    g = redio.Graph()
+    with pytest.raises(redio.RedioError) as e:
+        with g:
+            chain(d, out)
+    assert e.value.code == -6
+    chain.reserve(n)
+    g2 = redio.Graph()
+    with g2:
+        chain(d, out)
+    g2.launch()
+    gpu.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
