@@ -23,7 +23,7 @@ def check(name, ok, detail):
 
 t_end = time.time() + budget
 while time.time() < t_end:
-    which = rng.integers(0, 10)
+    which = rng.integers(0, 12)
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000)), int(rng.integers(2000, 20000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
@@ -127,21 +127,59 @@ while time.time() < t_end:
         got, want = dsputils.convolve(u, v), O.convolve(u, v)
         ok = ok and got.shape == want.shape and np.array_equal(bits(got), bits(want))
         check("dropin", ok, (n, inv, nu, nv))
+    elif which in (10, 11):   # carried-history streams: any plan, any cut of the stream == one stateless call on the whole stream
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            k = int(rng.choice([1, 2, 17, 63, 127, 128, int(rng.integers(1, 600))])); d = int(rng.choice([1, 2, 3, 5, 8, 13, int(rng.integers(1, 300))]))
+            cplx, fused = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
+            plan = R.Fir(taps, d, complex_input=cplx, fused=fused)
+            one = lambda v: O.fir(v, taps, d, fused)
+            n = int(rng.integers(0, 60000)); desc = ("fir", k, d, cplx, fused)
+        elif kind == 1:
+            k, d = [(127, 5), (63, 5), (127, 3), (63, 1), (31, 4), (100, 2)][int(rng.integers(0, 6))]
+            nfc = int(rng.choice([1024, 1024, 256, 64])); fused = bool(rng.integers(0, 2)); cplx = True
+            taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
+            plan = R.Chain(taps, d, nfc, fused=fused)
+            one = lambda v: O.chain_fir_fft(v, taps, d, nfc, fused=fused).reshape(-1)
+            n = int(rng.integers(0, 12 * nfc * d)); desc = ("chain", k, d, nfc, fused)
+        elif kind == 2:
+            M = int(rng.choice([64, 32, 100, 7])); P = int(rng.choice([4, 8, 16, 5])); fused = bool(rng.integers(0, 2)); cplx = True
+            h = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, M * P)
+            plan = R.Channelizer(h, M, P, fused=fused)
+            one = lambda v: O.pfb_channelizer(v, h, M, P, fused).reshape(-1)
+            n = int(rng.integers(0, M * 400)); desc = ("pfb", M, P, fused)
+        else:
+            nfft = int(rng.choice([64, 256, 1024, 4096, 1000, 2048])); k = int(rng.integers(1, nfft + 1)); cplx = True
+            taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
+            plan = R.OverlapSave(taps, nfft)
+            one = lambda v: O.overlap_save(v, taps, nfft)
+            n = int(rng.integers(0, nfft + 8 * (nfft - k + 1))); desc = ("ovsave", nfft, k)
+        x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, max(n, 1))[:n]
+        want = one(x) if n else np.zeros(0, x.dtype)
+        st = R.Stream(plan)
+        dx = torch.from_numpy(x).cuda() if n else torch.zeros(0, dtype=torch.complex64 if cplx else torch.float32, device="cuda")
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 12)))]))
+        outs = [st(dx[lo:hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
+        got = torch.cat(outs).cpu().numpy() if outs else np.zeros(0, x.dtype)
+        check("stream", got.shape == np.asarray(want).reshape(-1).shape and np.array_equal(bits(got), bits(np.asarray(want).reshape(-1))), desc + (n, cuts))
     elif which == 9:    # src_process drop-in (host buffers, one state, random messages)
         from libredio_amd import samplerate
-        conv = int(rng.integers(0, 3))
-        ratio = float(rng.choice([0.02, 0.5, 1.0, 2.0, 0.25, 1.0884, float(rng.uniform(0.01, 3.0))]))
-        st, ref, ok = samplerate.State(conv, 1), O.Resampler(conv), True
+        conv = int(rng.integers(0, 5)); ch = int(rng.choice([1, 1, 2, 3]))
+        ratio = float(rng.choice([0.02, 0.5, 1.0, 2.0, 0.25, 1.0884, 48000 / 44100, 1.5, 0.3, float(rng.uniform(0.01, 3.0))]))
+        st, ref, ok = samplerate.State(conv, ch), O.Resampler(conv, ch), True
         for _ in range(int(rng.integers(1, 5))):
             m = int(rng.integers(1, 20000))
-            x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m)
-            a, b = st.block(x, ratio), ref.block(x, ratio)
-            ok = ok and len(a) == len(b) and np.array_equal(bits(a), bits(b))
+            x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m * ch)
+            cap = int(ratio * m + 1.0)
+            e1, a, u1 = st.process(x, ratio, cap, 0)
+            e2, b, u2 = ref.process(x, ratio, cap, False)
+            ok = ok and (e1, u1, len(a)) == (e2, u2, len(b)) and np.array_equal(bits(a), bits(b))
         st.close()
-        check("srcdrop", ok, (conv, ratio))
+        check("srcdrop", ok, (conv, ch, ratio))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 3))
-        ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
+        ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 48000 / 44100, 1.5, 0.3, 4 / 3, 0.75, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
         n = int(rng.integers(1, 40000 if ratio < 10 else 400))
         x = np.stack([O.synth_f32(int(rng.integers(1, 1 << 30)), 0, n) for _ in range(nch)])
         plan = R.Src(nch, conv, mode=int(rng.choice([0, 2])))
