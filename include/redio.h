@@ -233,7 +233,7 @@ int redio_comm_init_all(redio_comm **comms, int ndev, const int *devices /* NULL
 int redio_comm_destroy(redio_comm *c);
 int redio_comm_rank(const redio_comm *c);
 int redio_comm_size(const redio_comm *c);
-const char *redio_comm_last_error(void);
+const char *redio_comm_last_error(void); /* text of the calling thread's last REDIO_ERR_COMM */
 int redio_pfb_exchange(redio_comm *c, const void *d_grouped, void *d_out, const size_t *rows_per_rank, size_t chans_per_rank, void *stream);
 int redio_pfb_exchange_all(redio_comm *const *comms, int ndev, const void *const *d_grouped, void *const *d_out,
                            const size_t *rows_per_rank, size_t chans_per_rank, void *const *streams);

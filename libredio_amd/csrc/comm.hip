@@ -35,7 +35,7 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_once;
-char g_last_error[256] = "";
+thread_local char g_last_error[256] = ""; // per calling thread: one block thread per GPU may fail independently
 
 void load_rccl()
 {
