@@ -156,3 +156,19 @@ def test_bench_c4_launcher_correctness_half(gpu, redio):
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert '"ok": true' in out.stdout
+
+
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_bench_shards_launcher_correctness_half(gpu, redio, config):
+    """tools/bench_shards.py --check under torch.distributed.run, one rank per visible device: the independent-shard configs
+    (BASELINE configs[2] resampler channels, configs[4] overlap-save blocks; no collective) against the oracle."""
+    import os, subprocess, sys
+    ndev = gpu.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ndev}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90 + (7 if config == "c3" else 0)), os.path.join(root, "tools", "bench_shards.py"), config,
+           "--gpus", str(ndev), "--check"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert '"ok": true' in out.stdout
