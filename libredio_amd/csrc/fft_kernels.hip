@@ -1372,10 +1372,22 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
 // neighbouring positions; the last one to three stages (rows 65536 apart) need no regrouping at all: a lane keeps whole
 // columns in registers and every load and store is 512 contiguous bytes.  16 B/sample per pass.  Twiddle index of the stage
 // with sub-length m: (e mod m) * N / (4 m), exactly kissfft's k * fstride.
+// T1: the gather pass's own ordered twiddle copy (sub-lengths 1 ... 256: 1023 entries, fftbig_tables_build) -- in the table
+// order a wave's loads of one stage touch 16 different cache lines
+template <bool INV, typename TA, typename TB, typename TC, typename TD>
+__device__ __forceinline__ void fftbig_first_stages(float2 (&a)[4][16], float2 (&b)[4][16], TA t0, TB t1, TC t2, TD t3, int col, int lane, float2 *Lw)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], t0, t1, 0u, 1u, 0u, 1u);
+    f64w_exchange<false, true>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], t2, t3, 0u, 1u, (unsigned)col, 16u);
+}
+
 // one 256 x 16 tile of the gather pass: block at in_blk (source columns 16c .. 16c + 15) -> working order at out_blk
 template <bool INV>
 __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *out_blk, const float2 *__restrict__ tw, int L, unsigned c,
-                                                  int lane, float2 *Lw, const float2 *__restrict__ mulH)
+                                                  int lane, float2 *Lw, const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
 {
     const unsigned N = 1u << (2 * L), S = N >> 8; // S: source row stride
     const int col = lane & 15, q = lane >> 4;
@@ -1400,11 +1412,8 @@ __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *
         }
     }
     RD_SCHED_BARRIER();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], TwGather{tw, N >> 2}, TwGather{tw, N >> 4}, 0u, 1u, 0u, 1u);
-    f64w_exchange<false, true>(a, b, Lw, lane);
-#pragma unroll
-    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], TwGather{tw, N >> 6}, TwGather{tw, N >> 8}, 0u, 1u, (unsigned)col, 16u);
+    (void)tw;
+    fftbig_first_stages<INV>(a, b, tw_ordered_stage(T1, 1u, 0), tw_ordered_stage(T1, 1u, 1), tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), col, lane, Lw);
     // column r = 16c + 4q + x of the source is column h = digit reversal of r (L - 4 digits) of the working array
     unsigned rc = 0;
     for (int d = 0, cc = c; d < L - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
@@ -1418,7 +1427,7 @@ __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *
 
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
-                                                           long ntiles, int L, const float2 *__restrict__ mulH = nullptr)
+                                                           long ntiles, int L, const float2 *__restrict__ mulH = nullptr, const float2 *__restrict__ T1 = nullptr)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1426,7 +1435,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
     if (tile >= ntiles) return;
     const long xf = tile >> (2 * (L - 6));
     const unsigned c = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)); // source columns 16c .. 16c + 15
-    fftbig_first_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), tw, L, c, lane, Ls + w * F64W_REGION, mulH);
+    fftbig_first_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), tw, L, c, lane, Ls + w * F64W_REGION, mulH, T1);
 }
 
 template <bool INV>
@@ -1466,6 +1475,129 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
                 if (e < hop) vout[xf * hop + e] = make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale));
             } else (base + (long)m_lo * (4 * x + 16 * j))[lo_st] = b[x][j]; // row q + 4x + 16j
         }
+}
+
+// ---- five-stage passes: 4^9 and 4^10 points in TWO passes instead of three -------------------------------------------------
+// A tile of 1024 rows x 16 columns belongs to one workgroup: wave w runs the four-stage wave program above on the quarter of
+// the rows that forms one 256-row sub-transform (mid pass: rows 256 w .. 256 w + 255; gather pass: source rows 4 rho + w), then
+// the fifth stage combines position r of the four quarters.  It runs in four rounds through a 34 KiB LDS image: in round x
+// every wave parks its register group b[x][.] (64 rows x 16 columns), and wave w' takes slots 4 w' .. 4 w' + 3 of every
+// quarter -- the four inputs of a butterfly -- multiplies by the stage's twiddles and stores the four results (rows r,
+// r + 256, r + 512, r + 768 of the tile) straight from registers.  Same butterflies in the same order as the four-stage
+// passes followed by a one-stage pass: bit-identical.
+constexpr int F5_LD = 17;
+struct F5Image { float2 v[4][64][F5_LD]; }; // [quarter][slot 16 q + j][lane & 15]
+
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const float2 *__restrict__ T, long ngroups, int lgN, int lm)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ F5Image X;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long group = f64w_first_tile() >> 2;
+    if (group >= ngroups) return; // whole workgroup
+    float2 *Lw = Ls + w * F64W_REGION;
+    const unsigned N = 1u << lgN, m_lo = 1u << lm; // rows m_lo = 2^lm apart, 1024 of them per tile
+    const long xf = group >> (lgN - 14);
+    const unsigned gg = (unsigned)(group & ((1u << (lgN - 14)) - 1));
+    const unsigned c = gg & ((m_lo >> 4) - 1), H = gg >> (lm - 4); // positions l = 16c + col of 1024-row block H
+    const int col = lane & 15, q = lane >> 4;
+    float2 *tile = data + xf * (long)N + (long)H * 1024 * m_lo + 16 * c;
+    float2 *base = tile + (long)256 * m_lo * w; // this wave's quarter
+    const unsigned l = 16 * c + col;
+    float2 a[4][16], b[4][16];
+    const unsigned lo_ld = col + 16u * m_lo * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (base + (long)m_lo * (64 * i + j))[lo_ld]; // row 16 (4i + q) + j
+    RD_SCHED_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw_ordered_stage(T, m_lo, 0), tw_ordered_stage(T, m_lo, 1), l, m_lo, 0u, 1u);
+    f64w_exchange<false, false>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw_ordered_stage(T, m_lo, 2), tw_ordered_stage(T, m_lo, 3), l, m_lo, (unsigned)(q + 4 * x), 16u);
+    // b[x][j] = row q + 4x + 16j of this quarter, column col.  Fifth stage: sub-length 256 m_lo, twiddle index l + m_lo * row
+    const TwOrdered t4 = tw_ordered_stage(T, m_lo, 4);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X.v[w][16 * q + j][col] = b[x][j];
+        __syncthreads();
+        float2 v[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) v[jj][n] = X.v[n][16 * q + 4 * w + jj][col];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+            const unsigned row = (unsigned)(q + 4 * x + 16 * (4 * w + jj)), k = l + m_lo * row, kb = k + 16 * m_lo;
+            bfly4x2<INV>(v[jj][0], v[jj][1], v[jj][2], v[jj][3], t4.get(1, k), t4.get(2, k), t4.get(3, k),
+                         v[jj + 1][0], v[jj + 1][1], v[jj + 1][2], v[jj + 1][3], t4.get(1, kb), t4.get(2, kb), t4.get(3, kb));
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) (tile + (long)m_lo * (256 * n + q + 4 * x + 16 * (4 * w + jj)))[col] = v[jj][n];
+        __syncthreads();
+    }
+}
+
+// gather pass with five stages (4^L points, L >= 9): 1024 source rows N / 1024 apart x 16 source columns per workgroup
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_first5_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T1,
+                                                            long in_stride, long ngroups, int L)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ F5Image X;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long group = f64w_first_tile() >> 2;
+    if (group >= ngroups) return;
+    float2 *Lw = Ls + w * F64W_REGION;
+    const unsigned N = 1u << (2 * L), S = N >> 8, S5 = N >> 10; // source row strides of the four-stage program and of the tile
+    const long xf = group >> (2 * (L - 7));
+    const unsigned c = (unsigned)(group & ((1u << (2 * (L - 7))) - 1)); // source columns 16c .. 16c + 15 (of N / 1024)
+    const int col = lane & 15, q = lane >> 4;
+    const float2 *src = in + xf * in_stride + 16 * c + (long)S5 * w; // source rows 4 rho + w: the sub-transform of quarter w
+    float2 *dst = out + xf * (long)N;
+    float2 a[4][16], b[4][16];
+    const unsigned lo_src = col + 4u * S * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[i][j] = (src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src]; // source row rev4(16 (4i + q) + j)
+    RD_SCHED_BARRIER();
+    fftbig_first_stages<INV>(a, b, tw_ordered_stage(T1, 1u, 0), tw_ordered_stage(T1, 1u, 1), tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), col, lane, Lw);
+    // b[x][j] = position col + 16 j of the quarter's 256-point sub-transform, source column 16c + 4q + x.  Fifth stage: sub-length
+    // 256, twiddle tw[n * position * N / 1024]; column r of the source is column rev(r) (L - 5 digits) of the working array
+    unsigned rc = 0;
+    for (int d = 0, cc = c; d < L - 7; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
+    const unsigned hq = 1u << (2 * (L - 7)), hx = hq << 2;
+    const TwOrdered t4 = tw_ordered_stage(T1, 1u, 4); // tw[n * position * N / 1024], neighbouring positions in neighbouring entries
+    (void)tw;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X.v[w][16 * q + j][col] = b[x][j];
+        __syncthreads();
+        float2 v[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) v[jj][n] = X.v[n][16 * q + 4 * w + jj][col];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+            const unsigned k = (unsigned)(col + 16 * (4 * w + jj)), kb = k + 16;
+            bfly4x2<INV>(v[jj][0], v[jj][1], v[jj][2], v[jj][3], t4.get(1, k), t4.get(2, k), t4.get(3, k),
+                         v[jj + 1][0], v[jj + 1][1], v[jj + 1][2], v[jj + 1][3], t4.get(1, kb), t4.get(2, kb), t4.get(3, kb));
+        }
+        float2 *colbase = dst + 1024l * (hx * x + hq * q + rc); // the 1024 working positions of source column 16c + 4q + x
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) (colbase + 256 * n + 16 * (4 * w + jj))[col] = v[jj][n];
+        __syncthreads();
+    }
 }
 
 // the last LG = 1, 2 or 3 stages: G = 4^LG rows, m_lo = N / G apart; a wave takes 4096 / G neighbouring columns
@@ -1793,6 +1925,12 @@ static hipError_t launch_fft_tile_passes(const FftPlanDev &p, const float2 *in, 
     return hipGetLastError();
 }
 
+// 4^9 and 4^10 points run as two passes (four + five, five + five stages): the five-stage in-place pass reads its own ordered
+// twiddle copy (sub-lengths m_lo ... 256 m_lo), stored behind the tables of the four-stage plan (which the overlap-save path keeps using)
+static int fftbig_five_lm(int lgN) { return lgN == 18 ? 8 : lgN == 20 ? 10 : 0; }
+static size_t fftbig_five_elems(int lgN) { const int lm = fftbig_five_lm(lgN); return lm ? (size_t)1023 << lm : 0; }
+// every 4^L size: the gather pass's ordered copy (sub-lengths 1, 4, 16, 64, 256), at the very end of the tables
+static size_t fftbig_first_elems(int lgN) { return (lgN & 1) ? 0 : 1023; }
 static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384; }
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
@@ -1813,7 +1951,7 @@ size_t fftbig_tables_elems(int nfft)
     size_t total = 0;
     for (; left >= 4; lm += 8, left -= 4) total += (size_t)255 << lm;
     if (left == 3) total += (size_t)15 << (lgN - 6);
-    return total;
+    return total + fftbig_five_elems(lgN) + fftbig_first_elems(lgN);
 }
 hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s)
 {
@@ -1835,7 +1973,9 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
         hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm, 4, (unsigned)nfft);
         T += (size_t)255 << lm;
     }
-    if (left == 3) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft);
+    if (left == 3) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft); T += (size_t)15 << (lgN - 6); }
+    if (const int lm5 = fftbig_five_lm(lgN)) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm5, 5, (unsigned)nfft); T += fftbig_five_elems(lgN); }
+    if (fftbig_first_elems(lgN)) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(4), dim3(256), 0, s, tw, T, 1u, 5, (unsigned)nfft);
     return hipGetLastError();
 }
 
@@ -1847,11 +1987,20 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
 {
     const long ntiles = nbatch << (lgN - 12);
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
+    const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_first_elems(lgN)) : nullptr;
+    if (fftbig_five_lm(lgN) && !mulH && !vout) { // two passes: (four or five stages gathered) + five stages in place
+        const float2 *T5 = T1 - fftbig_five_elems(lgN);
+        const long ngroups = nbatch << (lgN - 14);
+        if (lgN == 18) hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, nullptr, T1);
+        else hipLaunchKernelGGL(fftbig_first5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, in, out, tw, T1, in_stride, ngroups, lgN / 2);
+        hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, out, T5, ngroups, lgN, fftbig_five_lm(lgN));
+        return hipGetLastError();
+    }
     if (lgN & 1) {
         const long nt2 = nbatch << (lgN - 11);
         hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN, mulH);
     } else {
-        hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH);
+        hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1);
     }
     int lm, left;
     fftbig_after_first(lgN, lm, left);
@@ -1890,7 +2039,7 @@ hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const f
 __global__ __launch_bounds__(256, 2) void ovsave64k_last_first_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
                                                                    const float2 *__restrict__ Ti, long hop, float scale, long ntiles_last,
                                                                    const float2 *__restrict__ x_next, float2 *__restrict__ a_out,
-                                                                   const float2 *__restrict__ tw_f, long ntiles_first)
+                                                                   const float2 *__restrict__ tw_f, long ntiles_first, const float2 *__restrict__ T1)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1905,7 +2054,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_first_kernel(const floa
     const long tile = wg * 4 + w;
     if (first) {
         if (tile >= ntiles_first) return;
-        fftbig_first_tile<false>(x_next + (tile >> 4) * hop, a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr);
+        fftbig_first_tile<false>(x_next + (tile >> 4) * hop, a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr, T1);
     } else {
         if (tile >= ntiles_last) return;
         ovsave64k_last_tile(b_in + (tile >> 4) * (long)F64K_N, out + (tile >> 4) * hop, Ti, hop, scale, (int)(tile & 15), lane, Lw);
@@ -1918,14 +2067,15 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
 {
     if (!Tf || !Ti || chunk < 1) return hipErrorInvalidValue; // the plans' pass-ordered twiddle copies (fftbig_tables_build)
     auto tiles = [&](long b0) { const long nb = nblk - b0 < chunk ? nblk - b0 : chunk; return nb * 16; };
-    hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8);
+    const float2 *T1 = Tf + (fftbig_tables_elems(F64K_N) - fftbig_first_elems(16)); // the forward plan's gather-pass copy
+    hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8, nullptr, T1);
     for (long b0 = 0; b0 < nblk; b0 += chunk) {
         const long nt = tiles(b0), next = b0 + chunk;
         hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, a, b, Tf, tw_i, Hc, nt);
         const long ntn = next < nblk ? tiles(next) : 0;
         const unsigned grid = (unsigned)((nt + 3) / 4 + (ntn + 3) / 4);
         hipLaunchKernelGGL(ovsave64k_last_first_kernel, dim3(grid), dim3(256), 0, s, b, out + b0 * hop, Ti, hop, scale, nt,
-                           x + next * hop, a, tw_f, ntn);
+                           x + next * hop, a, tw_f, ntn, T1);
     }
     return hipGetLastError();
 }

@@ -182,6 +182,24 @@ def test_fft_large_mixed_radix_tile_passes(gpu, redio, oracle, n):
         assert same_bits(got, np.concatenate([oracle.fft(xs[b * (n - 7): b * (n - 7) + n], n, False) for b in range(3)]))
 
 
+@pytest.mark.parametrize("n", [1 << 18, 1 << 20])
+def test_fft_two_pass_five_stage_tiles(gpu, redio, oracle, n):
+    # 4^9 and 4^10 points: (four or five stages gathered) + five stages in place (fftbig_first5_kernel / fftbig_mid5_kernel):
+    # both directions, several transforms per call, strided (overlapping) blocks, and the same plan size through the
+    # overlap-save path, which keeps the four-stage passes and their tables
+    nb = 3
+    x = oracle.synth_iq(n & 0xFFFF, 0, n * nb)
+    d = gpu.from_numpy(x).cuda()
+    for inverse in (False, True):
+        assert same_bits(redio.Fft(n, inverse)(d).cpu().numpy(), oracle.fft(x, n, inverse)), (n, inverse)
+    xs = oracle.synth_iq(n + 1, 0, n + 2 * (n - 5))
+    got = redio.Fft(n, False).strided(gpu.from_numpy(xs).cuda(), 3, n - 5).cpu().numpy()
+    assert same_bits(got, np.concatenate([oracle.fft(xs[b * (n - 5): b * (n - 5) + n], n, False) for b in range(3)]))
+    taps = oracle.lpf_corrected(1001, 0.02)
+    xo = oracle.synth_iq(9, 0, n + (n - 1000) + 33)
+    assert same_bits(redio.OverlapSave(taps, n)(gpu.from_numpy(xo).cuda()).cpu().numpy(), oracle.overlap_save(xo, taps, n))
+
+
 @pytest.mark.parametrize("n", [1 << 21, 1 << 22, 1 << 23, 1 << 24])
 def test_fft_multi_pass_powers_of_four(gpu, redio, oracle, n):
     # 2 * 4^10, 4^11, 2 * 4^11, 4^12: gather pass, in-place four-stage passes, register-only last stages (fft_kernels.hip, fftbig_*)
