@@ -1489,7 +1489,8 @@ constexpr int F5_LD = 17;
 struct F5Image { float2 v[4][64][F5_LD]; }; // [quarter][slot 16 q + j][lane & 15]
 
 template <bool INV>
-__global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const float2 *__restrict__ T, long ngroups, int lgN, int lm)
+__global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const float2 *__restrict__ T, long ngroups, int lgN, int lm,
+                                                          float2 *__restrict__ vout = nullptr, long hop = 0, float scale = 1.0f)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     __shared__ F5Image X;
@@ -1538,7 +1539,13 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) (tile + (long)m_lo * (256 * n + q + 4 * x + 16 * (4 * w + jj)))[col] = v[jj][n];
+            for (int n = 0; n < 4; ++n) {
+                const long r = 256 * n + q + 4 * x + 16 * (4 * w + jj);
+                if (vout) { // overlap-save: this was the last pass; 1/N and only the hop valid outputs, packed
+                    const long e = (long)H * 1024 * m_lo + (long)m_lo * r + l;
+                    if (e < hop) vout[xf * hop + e] = make_float2(mul_rn(v[jj][n].x, scale), mul_rn(v[jj][n].y, scale));
+                } else (tile + (long)m_lo * r)[col] = v[jj][n];
+            }
         __syncthreads();
     }
 }
@@ -1546,7 +1553,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const
 // gather pass with five stages (4^L points, L >= 9): 1024 source rows N / 1024 apart x 16 source columns per workgroup
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first5_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T1,
-                                                            long in_stride, long ngroups, int L)
+                                                            long in_stride, long ngroups, int L, const float2 *__restrict__ mulH = nullptr)
 {
     __shared__ float2 Ls[4 * F64W_REGION];
     __shared__ F5Image X;
@@ -1566,6 +1573,18 @@ __global__ __launch_bounds__(256, 2) void fftbig_first5_kernel(const float2 *in,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src]; // source row rev4(16 (4i + q) + j)
+    if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
+        const float2 *hsrc = mulH + 16 * c + (long)S5 * w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 hv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hv[j] = (hsrc + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src];
+            RD_SCHED_BARRIER();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[i][j] = cmul_rn(a[i][j], hv[j]);
+        }
+    }
     RD_SCHED_BARRIER();
     fftbig_first_stages<INV>(a, b, tw_ordered_stage(T1, 1u, 0), tw_ordered_stage(T1, 1u, 1), tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), col, lane, Lw);
     // b[x][j] = position col + 16 j of the quarter's 256-point sub-transform, source column 16c + 4q + x.  Fifth stage: sub-length
@@ -1925,10 +1944,34 @@ static hipError_t launch_fft_tile_passes(const FftPlanDev &p, const float2 *in, 
     return hipGetLastError();
 }
 
-// 4^9 and 4^10 points run as two passes (four + five, five + five stages): the five-stage in-place pass reads its own ordered
-// twiddle copy (sub-lengths m_lo ... 256 m_lo), stored behind the tables of the four-stage plan (which the overlap-save path keeps using)
-static int fftbig_five_lm(int lgN) { return lgN == 18 ? 8 : lgN == 20 ? 10 : 0; }
-static size_t fftbig_five_elems(int lgN) { const int lm = fftbig_five_lm(lgN); return lm ? (size_t)1023 << lm : 0; }
+// Plan B: sizes for which five-stage passes save a pass or end on a cheaper last pass.  first = stages of the gather pass (2: the
+// radix-2 stage + two radix-4 stages of 2 * 4^L), mid = stages of each in-place pass, last = trailing register-only stages.
+//   2^15: 3 + 5            (two passes instead of three)      2^18: 4 + 5, 2^20: 5 + 5   (two instead of three)
+//   2^19: 3 + 5 + 2, 2^22: 5 + 5 + 1  (three either way; shorter last pass; 2^24 measured slower as 5 + 5 + 2)     2^23: 3 + 5 + 4   (three instead of four)
+// Its in-place passes read their own ordered twiddle copies, stored behind plan A's tables.
+struct BigPlanB { int first, nmid, mid[2], last; };
+static bool fftbig_plan_b(int lgN, BigPlanB &p)
+{
+    switch (lgN) {
+    case 15: p = {2, 1, {5, 0}, 0}; return true;
+    case 18: p = {4, 1, {5, 0}, 0}; return true;
+    case 19: p = {2, 1, {5, 0}, 2}; return true;
+    case 20: p = {5, 1, {5, 0}, 0}; return true;
+    case 22: p = {5, 1, {5, 0}, 1}; return true;
+    case 23: p = {2, 2, {5, 4}, 0}; return true;
+    default: return false;
+    }
+}
+static int fftbig_plan_b_lm0(const BigPlanB &p) { return p.first == 2 ? 5 : p.first == 4 ? 8 : 10; }
+static size_t fftbig_five_elems(int lgN)
+{
+    BigPlanB p;
+    if (!fftbig_plan_b(lgN, p)) return 0;
+    size_t total = 0;
+    int lm = fftbig_plan_b_lm0(p);
+    for (int i = 0; i < p.nmid; ++i) { total += (size_t)(p.mid[i] == 5 ? 1023 : 255) << lm; lm += 2 * p.mid[i]; }
+    return total;
+}
 // every 4^L size: the gather pass's ordered copy (sub-lengths 1, 4, 16, 64, 256), at the very end of the tables
 static size_t fftbig_first_elems(int lgN) { return (lgN & 1) ? 0 : 1023; }
 static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384; }
@@ -1974,7 +2017,15 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
         T += (size_t)255 << lm;
     }
     if (left == 3) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft); T += (size_t)15 << (lgN - 6); }
-    if (const int lm5 = fftbig_five_lm(lgN)) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm5, 5, (unsigned)nfft); T += fftbig_five_elems(lgN); }
+    BigPlanB pb;
+    if (fftbig_plan_b(lgN, pb)) {
+        int lmb = fftbig_plan_b_lm0(pb);
+        for (int i = 0; i < pb.nmid; ++i) {
+            hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, pb.mid[i], (unsigned)nfft);
+            T += (size_t)(pb.mid[i] == 5 ? 1023 : 255) << lmb;
+            lmb += 2 * pb.mid[i];
+        }
+    }
     if (fftbig_first_elems(lgN)) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(4), dim3(256), 0, s, tw, T, 1u, 5, (unsigned)nfft);
     return hipGetLastError();
 }
@@ -1988,12 +2039,32 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     const long ntiles = nbatch << (lgN - 12);
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
     const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_first_elems(lgN)) : nullptr;
-    if (fftbig_five_lm(lgN) && !mulH && !vout) { // two passes: (four or five stages gathered) + five stages in place
-        const float2 *T5 = T1 - fftbig_five_elems(lgN);
+    BigPlanB pb;
+    if (fftbig_plan_b(lgN, pb)) {
+        const float2 *T = tables + (fftbig_tables_elems(1 << lgN) - fftbig_first_elems(lgN) - fftbig_five_elems(lgN));
         const long ngroups = nbatch << (lgN - 14);
-        if (lgN == 18) hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, nullptr, T1);
-        else hipLaunchKernelGGL(fftbig_first5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, in, out, tw, T1, in_stride, ngroups, lgN / 2);
-        hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, out, T5, ngroups, lgN, fftbig_five_lm(lgN));
+        if (pb.first == 2) {
+            const long nt2 = nbatch << (lgN - 11);
+            hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN, mulH);
+        } else if (pb.first == 4) {
+            hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1);
+        } else {
+            hipLaunchKernelGGL(fftbig_first5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, in, out, tw, T1, in_stride, ngroups, lgN / 2, mulH);
+        }
+        int lm = fftbig_plan_b_lm0(pb);
+        for (int i = 0; i < pb.nmid; ++i) {
+            float2 *vo = (i + 1 == pb.nmid && pb.last == 0) ? vout : nullptr; // the last pass of all
+            if (pb.mid[i] == 5) {
+                hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, out, T, ngroups, lgN, lm, vo, hop, scale);
+                T += (size_t)1023 << lm;
+            } else {
+                hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T, ntiles, lgN, lm, vo, hop, scale);
+                T += (size_t)255 << lm;
+            }
+            lm += 2 * pb.mid[i];
+        }
+        if (pb.last == 1) hipLaunchKernelGGL((fftbig_last_kernel<INV, 1>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN, vout, hop, scale);
+        else if (pb.last == 2) hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, T, ntiles, lgN, vout, hop, scale);
         return hipGetLastError();
     }
     if (lgN & 1) {

@@ -182,13 +182,14 @@ def test_fft_large_mixed_radix_tile_passes(gpu, redio, oracle, n):
         assert same_bits(got, np.concatenate([oracle.fft(xs[b * (n - 7): b * (n - 7) + n], n, False) for b in range(3)]))
 
 
-@pytest.mark.parametrize("n", [1 << 18, 1 << 20])
+@pytest.mark.parametrize("n", [1 << 15, 1 << 18, 1 << 19, 1 << 20, 1 << 22])
 def test_fft_two_pass_five_stage_tiles(gpu, redio, oracle, n):
-    # 4^9 and 4^10 points: (four or five stages gathered) + five stages in place (fftbig_first5_kernel / fftbig_mid5_kernel):
+    # plan B of the multi-pass transforms (fft_kernels.hip, fftbig_plan_b): 2^15 = 3 + 5 stages, 4^9 = 4 + 5, 2^19 = 3 + 5 + 2,
+    # 4^10 = 5 + 5, 4^11 = 5 + 5 + 1 (fftbig_first5_kernel / fftbig_mid5_kernel; 2^23 and 2^24 are in the test below):
     # both directions, several transforms per call, strided (overlapping) blocks, and the same plan size through the
     # overlap-save path, which keeps the four-stage passes and their tables
-    nb = 3
-    x = oracle.synth_iq(n & 0xFFFF, 0, n * nb)
+    nb = 3 if n <= (1 << 20) else 1
+    x = oracle.synth_iq((n & 0xFFFF) + 5, 0, n * nb)
     d = gpu.from_numpy(x).cuda()
     for inverse in (False, True):
         assert same_bits(redio.Fft(n, inverse)(d).cpu().numpy(), oracle.fft(x, n, inverse)), (n, inverse)
