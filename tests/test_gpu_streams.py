@@ -120,3 +120,43 @@ def test_chain_stream_large_pieces_at_full_rate_path(gpu, redio, oracle):
     st = redio.Stream(chain)
     got = gpu.cat([st(x[i:i + (1 << 24)]).clone() for i in range(0, n, 1 << 24)])
     assert got.numel() == one.numel() and gpu.equal(got, one)
+
+
+def test_stream_handle_edge_cases(gpu, redio, oracle):
+    """Empty messages, reset in mid-stream, two streams on one plan, messages shorter than anything the kernels take."""
+    import ctypes as C
+    taps = oracle.lpf_corrected(127, 0.08)
+    x = oracle.synth_iq(3, 0, 40000)
+    d = gpu.from_numpy(x).cuda()
+    plan = redio.Fir(taps, 5, complex_input=True, fused=True)
+    a, b = redio.Stream(plan), redio.Stream(plan)          # independent histories on one plan
+    assert a(d[:0]).numel() == 0 and a.pending == 0 and a.nout(0) == 0
+    ya = gpu.cat([a(d[:100]), a(d[100:100]), a(d[100:20000]), a(d[20000:])])
+    yb = gpu.cat([b(d[:33333]), b(d[33333:])])
+    want = oracle.fir(x, taps, 5, True)
+    assert np.array_equal(bits(ya.cpu().numpy()), bits(want)) and np.array_equal(bits(yb.cpu().numpy()), bits(want))
+    # reset drops the carried tail: the next message starts a new stream (decimation phase 0 again)
+    a.reset()
+    assert a.pending == 0
+    y2 = a(d[7:5007])
+    assert np.array_equal(bits(y2.cpu().numpy()), bits(oracle.fir(x[7:5007], taps, 5, True)))
+    # C ABI argument checks
+    L = redio.lib()
+    h = C.c_void_p()
+    assert L.redio_fir_stream_create(C.byref(h), None) == -1
+    assert L.redio_fir_stream_enqueue(None, None, 0, None, None, None) == -1
+    assert L.redio_fir_stream_nout(None, 10) == 0 and L.redio_fir_stream_destroy(None) == 0
+    got = C.c_size_t(7)
+    assert L.redio_fir_stream_enqueue(a._h, None, 5, None, C.byref(got), None) == -1 and got.value == 0   # NULL data with n > 0
+
+
+def test_exchange_argument_checks(gpu, redio):
+    import ctypes as C
+    L = redio.lib()
+    assert L.redio_pfb_exchange(None, None, None, None, 8, None) == -1
+    assert L.redio_comm_init_rank(C.byref(C.c_void_p()), 2, 5, C.create_string_buffer(128)) == -1        # rank outside the communicator
+    assert L.redio_comm_rank(None) == -1 and L.redio_comm_size(None) == 0 and L.redio_comm_destroy(None) == 0
+    comm = redio.Comm.single()
+    rows = (C.c_size_t * 1)(4)
+    assert L.redio_pfb_exchange(comm._h, None, None, rows, 8, None) == -1                                # rows announced, no buffers
+    assert L.redio_pfb_exchange(comm._h, None, None, rows, 0, None) == -1
