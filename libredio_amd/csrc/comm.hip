@@ -123,7 +123,10 @@ extern "C" int redio_comm_init_all(redio_comm **comms, int ndev, const int *devi
     std::vector<int> devs((size_t)ndev);
     for (int i = 0; i < ndev; ++i) devs[(size_t)i] = devices ? devices[i] : i;
     std::vector<ncclComm_t> cs((size_t)ndev);
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     const int rc = nccl_rc(r, r->CommInitAll(cs.data(), ndev, devs.data()), "ncclCommInitAll");
+    if (have_cur) hipSetDevice(cur); // the caller's current device is left as it was
     if (rc) return rc;
     for (int i = 0; i < ndev; ++i) {
         redio_comm *p = new (std::nothrow) redio_comm();

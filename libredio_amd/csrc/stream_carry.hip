@@ -96,14 +96,14 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     SC_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const char *src = (const char *)d_new;
-    c->total_in += n;
-    if (c->skip) { // a hop longer than the window: the samples between two windows are never read
-        const size_t drop = c->skip < n ? c->skip : n;
-        src += drop * c->in_elem; n -= drop; c->skip -= drop;
-        if (n == 0) return REDIO_OK;
-    }
-    const StreamSplit s = split(*c, n);
-    if ((s.nh || s.nb) && !d_out) return REDIO_ERR_ARG;
+    const size_t n_call = n;
+    const size_t drop = c->skip < n ? c->skip : n; // a hop longer than the window: the samples between two windows are never read
+    src += drop * c->in_elem; n -= drop;
+    const StreamSplit s = n ? split(*c, n) : StreamSplit{0, 0, 0, 0, 0};
+    if ((s.nh || s.nb) && !d_out) return REDIO_ERR_ARG; // nothing has been consumed yet: the call can be repeated
+    c->skip -= drop;
+    c->total_in += n_call;
+    if (n == 0) return REDIO_OK;
     char *S = c->d_s[c->cur], *T = c->d_s[c->cur ^ 1];
     const size_t m = n < c->W - 1 ? n : c->W - 1;
     if (c->hist > 0 && m > 0) SC_TRY(hipMemcpyAsync(S + c->hist * c->in_elem, src, m * c->in_elem, hipMemcpyDeviceToDevice, st));
