@@ -148,7 +148,38 @@ def pfb_generic_cases():
     return out
 
 
-CASES = {"ovsave": ovsave_cases, "front_end": front_end_cases, "pfb_generic": pfb_generic_cases, "fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
+def converter_cases():
+    """Converters 3 / 4 (zero-order hold, linear) and interleaved channels (samplerate.rs:26-30 declares them; the reference
+    only uses converter 1, mono).  Cross-checked at generation time against closed forms: a hold of an integer ramp at ratio
+    1/4 returns every fourth sample, a linear interpolation of it at ratio 4 returns exact quarter steps."""
+    out = {}
+    ramp = np.arange(1000, dtype=np.float32)
+    e, z, u = O.Resampler(3).process(ramp, 0.25, 300)
+    assert e == 0 and np.array_equal(z[1:9], np.float32([3, 7, 11, 15, 19, 23, 27, 31]))
+    e, l, u = O.Resampler(4).process(ramp, 4.0, 4100)
+    assert e == 0 and np.array_equal(l[4:44], (np.arange(40) * 0.25).astype(np.float32))
+    x2 = np.stack([O.synth_f32(0x5EED0C, 0, 3000), O.synth_f32(0x5EED0D, 0, 3000)], 1).reshape(-1)   # two interleaved channels
+    out["x2"] = x2
+    for conv in (1, 3, 4):
+        for name, ratio in (("r0p3", 0.3), ("r1p5", 1.5)):
+            r = O.Resampler(conv, 2)
+            ys, counts, used = [], [], []
+            for lo, hi in ((0, 1000), (1000, 1001), (1001, 3000)):
+                cap = int(ratio * (hi - lo) + 1.0) + 2
+                e, y, u = r.process(x2[2 * lo:2 * hi], ratio, cap, False)
+                assert e == 0
+                ys.append(y); counts.append(len(y) // 2); used.append(u)
+            out[f"c{conv}_{name}_y"] = np.concatenate(ys)
+            out[f"c{conv}_{name}_counts"] = np.array(counts, np.int64)
+            out[f"c{conv}_{name}_used"] = np.array(used, np.int64)
+    # channels are independent mono streams
+    m = O.Resampler(1, 1)
+    ym = np.concatenate([m.process(np.ascontiguousarray(x2[0::2][lo:hi]), 0.3, int(0.3 * (hi - lo) + 1.0) + 2, False)[1] for lo, hi in ((0, 1000), (1000, 1001), (1001, 3000))])
+    assert np.array_equal(out["c1_r0p3_y"][0::2], ym)
+    return out
+
+
+CASES = {"converters": converter_cases, "ovsave": ovsave_cases, "front_end": front_end_cases, "pfb_generic": pfb_generic_cases, "fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
 
 
 def generate(outdir=HERE):
