@@ -235,6 +235,10 @@ int redio_comm_rank(const redio_comm *c);
 int redio_comm_size(const redio_comm *c);
 const char *redio_comm_last_error(void); /* text of the calling thread's last REDIO_ERR_COMM */
 int redio_pfb_exchange(redio_comm *c, const void *d_grouped, void *d_out, const size_t *rows_per_rank, size_t chans_per_rank, void *stream);
+/* the same with rank q's rows placed at row out_row_offset[q] of d_out: lets a slice be analysed in pieces whose exchanges run beside
+ * the analysis of the next piece on another HIP stream and still build the time-ordered result in place */
+int redio_pfb_exchange_at(redio_comm *c, const void *d_grouped, void *d_out, const size_t *rows_per_rank, const size_t *out_row_offset,
+                          size_t chans_per_rank, void *stream);
 int redio_pfb_exchange_all(redio_comm *const *comms, int ndev, const void *const *d_grouped, void *const *d_out,
                            const size_t *rows_per_rank, size_t chans_per_rank, void *const *streams);
 

@@ -153,6 +153,7 @@ def lib():
     _sig(L.redio_comm_size, i, vp)
     _sig(L.redio_comm_last_error, C.c_char_p)
     _sig(L.redio_pfb_exchange, i, vp, vp, vp, psz, sz, vp)
+    _sig(L.redio_pfb_exchange_at, i, vp, vp, vp, psz, psz, sz, vp)
     _sig(L.redio_pfb_exchange_all, i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), psz, sz, C.POINTER(vp))
     _sig(L.redio_synth_iq, i, vp, C.c_uint32, C.c_uint64, sz, vp)
     _sig(L.redio_synth_f32, i, vp, C.c_uint32, C.c_uint64, sz, vp)

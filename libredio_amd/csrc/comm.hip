@@ -152,6 +152,54 @@ extern "C" int redio_comm_destroy(redio_comm *c)
 extern "C" int redio_comm_rank(const redio_comm *c) { return c ? c->rank : -1; }
 extern "C" int redio_comm_size(const redio_comm *c) { return c ? c->nranks : 0; }
 
+// One rank's transfers of an exchange: to every peer q `sendn[q]` floats from `sendp[q]`, from every peer `recvn[q]` floats into
+// `recvp[q]`.  Messages are cut into pieces of at most 2^27 floats (512 MiB), one RCCL group per piece index: a single
+// ncclSend / ncclRecv pair above 1 GiB was measured to deliver only its first gigabyte (RCCL 2.26.6, send to self on one MI355X;
+// tools/exp has the probe), and smaller pieces also let the fabric interleave the peers.
+constexpr size_t COMM_PIECE = (size_t)1 << 27;
+struct PeerXfer { const float *sendp; size_t sendn; float *recvp; size_t recvn; };
+static int xfer_group(const Rccl *r, redio_comm *c, const PeerXfer *x, size_t piece, hipStream_t st, bool &any)
+{
+    int rc = REDIO_OK;
+    for (int q = 0; q < c->nranks && rc == REDIO_OK; ++q) {
+        const size_t o = piece * COMM_PIECE;
+        if (x[q].sendn > o) {
+            const size_t n = x[q].sendn - o < COMM_PIECE ? x[q].sendn - o : COMM_PIECE;
+            rc = nccl_rc(r, r->Send(x[q].sendp + o, n, ncclFloat, q, c->comm, st), "ncclSend");
+            any = true;
+        }
+        if (rc == REDIO_OK && x[q].recvn > o) {
+            const size_t n = x[q].recvn - o < COMM_PIECE ? x[q].recvn - o : COMM_PIECE;
+            rc = nccl_rc(r, r->Recv(x[q].recvp + o, n, ncclFloat, q, c->comm, st), "ncclRecv");
+            any = true;
+        }
+    }
+    return rc;
+}
+static size_t xfer_pieces(const PeerXfer *x, int n)
+{
+    size_t most = 0;
+    for (int q = 0; q < n; ++q) {
+        most = x[q].sendn > most ? x[q].sendn : most;
+        most = x[q].recvn > most ? x[q].recvn : most;
+    }
+    return (most + COMM_PIECE - 1) / COMM_PIECE;
+}
+// all transfers of ONE rank on its stream
+static int xfer_rank(const Rccl *r, redio_comm *c, const std::vector<PeerXfer> &x, hipStream_t st)
+{
+    const size_t np = xfer_pieces(x.data(), c->nranks);
+    for (size_t k = 0; k < np; ++k) {
+        int rc = nccl_rc(r, r->GroupStart(), "ncclGroupStart");
+        if (rc) return rc;
+        bool any = false;
+        rc = xfer_group(r, c, x.data(), k, st, any);
+        const int rc2 = nccl_rc(r, r->GroupEnd(), "ncclGroupEnd");
+        if (rc || rc2) return rc ? rc : rc2;
+    }
+    return REDIO_OK;
+}
+
 // offsets (in rows) of every rank's block in the regrouped output, and their sum
 static size_t row_offsets(const size_t *rows_per_rank, int n, std::vector<size_t> &off)
 {
@@ -159,6 +207,28 @@ static size_t row_offsets(const size_t *rows_per_rank, int n, std::vector<size_t
     size_t tot = 0;
     for (int q = 0; q < n; ++q) { off[(size_t)q] = tot; tot += rows_per_rank[q]; }
     return tot;
+}
+
+// The same exchange with the receive placement given explicitly: rank q's rows land at row out_row_offset[q] of d_out.  A slice
+// that is analysed in several pieces (so that the exchange of piece i runs beside the analysis of piece i + 1 on another HIP
+// stream) places piece i of rank q at q * rows_of_a_whole_slice + i * rows_of_a_piece and so builds the time-ordered result in place.
+extern "C" int redio_pfb_exchange_at(redio_comm *c, const void *d_grouped, void *d_out, const size_t *rows_per_rank, const size_t *out_row_offset,
+                                     size_t chans_per_rank, void *stream)
+{
+    if (!c || !rows_per_rank || !out_row_offset || chans_per_rank == 0) return REDIO_ERR_ARG;
+    const Rccl *r = rccl();
+    if (!r) return REDIO_ERR_COMM;
+    const size_t mine = rows_per_rank[c->rank];
+    size_t total = 0;
+    for (int q = 0; q < c->nranks; ++q) total += rows_per_rank[q];
+    if ((mine && !d_grouped) || (total && !d_out)) return REDIO_ERR_ARG;
+    hipError_t he = hipSetDevice(c->device);
+    if (he != hipSuccess) return REDIO_ERR_HIP_BASE - (int)he;
+    const size_t fl = 2 * chans_per_rank;
+    std::vector<PeerXfer> x((size_t)c->nranks);
+    for (int q = 0; q < c->nranks; ++q)
+        x[(size_t)q] = {(const float *)d_grouped + (size_t)q * mine * fl, mine * fl, (float *)d_out + out_row_offset[q] * fl, rows_per_rank[q] * fl};
+    return xfer_rank(r, c, x, (hipStream_t)stream);
 }
 
 extern "C" int redio_pfb_exchange(redio_comm *c, const void *d_grouped, void *d_out, const size_t *rows_per_rank, size_t chans_per_rank, void *stream)
@@ -173,16 +243,10 @@ extern "C" int redio_pfb_exchange(redio_comm *c, const void *d_grouped, void *d_
     hipError_t he = hipSetDevice(c->device);
     if (he != hipSuccess) return REDIO_ERR_HIP_BASE - (int)he;
     const size_t fl = 2 * chans_per_rank; // floats per row of one group
-    int rc = nccl_rc(r, r->GroupStart(), "ncclGroupStart");
-    if (rc) return rc;
-    for (int q = 0; q < c->nranks && rc == REDIO_OK; ++q) {
-        // to rank q: my rows of q's channels (group q of my layout); from rank q: its rows of my channels
-        if (mine) rc = nccl_rc(r, r->Send((const float *)d_grouped + (size_t)q * mine * fl, mine * fl, ncclFloat, q, c->comm, (hipStream_t)stream), "ncclSend");
-        if (rc == REDIO_OK && rows_per_rank[q])
-            rc = nccl_rc(r, r->Recv((float *)d_out + off[(size_t)q] * fl, rows_per_rank[q] * fl, ncclFloat, q, c->comm, (hipStream_t)stream), "ncclRecv");
-    }
-    const int rc2 = nccl_rc(r, r->GroupEnd(), "ncclGroupEnd");
-    return rc ? rc : rc2;
+    std::vector<PeerXfer> x((size_t)c->nranks);
+    for (int q = 0; q < c->nranks; ++q) // to rank q: my rows of q's channels (group q of my layout); from rank q: its rows of my channels
+        x[(size_t)q] = {(const float *)d_grouped + (size_t)q * mine * fl, mine * fl, (float *)d_out + off[(size_t)q] * fl, rows_per_rank[q] * fl};
+    return xfer_rank(r, c, x, (hipStream_t)stream);
 }
 
 // every rank of one process in one call (comms from redio_comm_init_all): one RCCL group around all sends and receives
@@ -195,19 +259,26 @@ extern "C" int redio_pfb_exchange_all(redio_comm *const *comms, int ndev, const 
     std::vector<size_t> off;
     row_offsets(rows_per_rank, ndev, off);
     const size_t fl = 2 * chans_per_rank;
-    int rc = nccl_rc(r, r->GroupStart(), "ncclGroupStart");
-    if (rc) return rc;
-    for (int g = 0; g < ndev && rc == REDIO_OK; ++g) {
+    std::vector<std::vector<PeerXfer>> xs((size_t)ndev, std::vector<PeerXfer>((size_t)ndev));
+    size_t np = 0;
+    for (int g = 0; g < ndev; ++g) {
         redio_comm *c = comms[g];
-        if (!c || c->nranks != ndev) { rc = REDIO_ERR_ARG; break; }
-        hipStream_t st = streams ? (hipStream_t)streams[g] : nullptr;
+        if (!c || c->nranks != ndev) return REDIO_ERR_ARG;
         const size_t mine = rows_per_rank[g];
-        for (int q = 0; q < ndev && rc == REDIO_OK; ++q) {
-            if (mine) rc = nccl_rc(r, r->Send((const float *)d_grouped[g] + (size_t)q * mine * fl, mine * fl, ncclFloat, q, c->comm, st), "ncclSend");
-            if (rc == REDIO_OK && rows_per_rank[q])
-                rc = nccl_rc(r, r->Recv((float *)d_out[g] + off[(size_t)q] * fl, rows_per_rank[q] * fl, ncclFloat, q, c->comm, st), "ncclRecv");
-        }
+        for (int q = 0; q < ndev; ++q)
+            xs[(size_t)g][(size_t)q] = {(const float *)d_grouped[g] + (size_t)q * mine * fl, mine * fl, (float *)d_out[g] + off[(size_t)q] * fl, rows_per_rank[q] * fl};
+        const size_t p = xfer_pieces(xs[(size_t)g].data(), ndev);
+        np = p > np ? p : np;
     }
-    const int rc2 = nccl_rc(r, r->GroupEnd(), "ncclGroupEnd");
-    return rc ? rc : rc2;
+    for (size_t k = 0; k < np; ++k) { // one group per piece index around every rank's sends and receives
+        int rc = nccl_rc(r, r->GroupStart(), "ncclGroupStart");
+        if (rc) return rc;
+        for (int g = 0; g < ndev && rc == REDIO_OK; ++g) {
+            bool any = false;
+            rc = xfer_group(r, comms[g], xs[(size_t)g].data(), k, streams ? (hipStream_t)streams[g] : nullptr, any);
+        }
+        const int rc2 = nccl_rc(r, r->GroupEnd(), "ncclGroupEnd");
+        if (rc || rc2) return rc ? rc : rc2;
+    }
+    return REDIO_OK;
 }

@@ -398,6 +398,16 @@ class Comm:
               "pfb_exchange")
         return out
 
+    def exchange_at(self, grouped, rows_per_rank, out, out_row_offset, stream=None):
+        """redio_pfb_exchange_at: rank q's rows land at row out_row_offset[q] of `out`; enqueued on `stream` (a torch stream;
+        default: the current one) -- the piece-wise form that overlaps the exchange with the next piece's analysis."""
+        rows = [int(r) for r in rows_per_rank]
+        offs = [int(o) for o in out_row_offset]
+        st = current_stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        check(lib().redio_pfb_exchange_at(self._h, _dev_ptr(grouped), _dev_ptr(out), (C.c_size_t * self.size)(*rows),
+                                          (C.c_size_t * self.size)(*offs), grouped.shape[2], st), "pfb_exchange_at")
+        return out
+
     def __del__(self, _safe_destroy=_safe_destroy):
         if getattr(self, "_h", None):
             _safe_destroy("redio_comm_destroy", self._h)

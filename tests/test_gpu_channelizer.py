@@ -172,3 +172,15 @@ def test_bench_shards_launcher_correctness_half(gpu, redio, config):
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert '"ok": true' in out.stdout
+
+
+def test_exchange_messages_above_one_gibibyte(gpu, redio):
+    """One ncclSend / ncclRecv pair above 1 GiB was measured to deliver only its first gigabyte (tools/rccl_self_probe.py), so the
+    exchange cuts every transfer into 512 MiB pieces: a 1.0 GiB + 4 KiB and a 1.5 GiB message come back intact."""
+    comm = redio.Comm.single()
+    for rows in ((1 << 21) + 8, 3 << 20):
+        g = gpu.view_as_complex(gpu.randn((1, rows, 64, 2), device="cuda"))
+        out = comm.exchange(g, [rows])
+        gpu.cuda.synchronize()
+        assert gpu.equal(out, g[0]), rows
+        del g, out

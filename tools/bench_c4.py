@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="cabi = redio_pfb_exchange (RCCL send/recv group through the C ABI); torch = all_to_all_single")
     ap.add_argument("--check", action="store_true", help="compare this rank's regrouped rows with the oracle on a short stream and exit")
+    ap.add_argument("--pieces", type=int, default=4, help="analyse the slice in this many pieces; the exchange of piece i runs on a second HIP stream "
+                                                          "beside the analysis of piece i + 1 (C-ABI exchange only)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -78,16 +80,50 @@ def main():
             print(json.dumps({"check": "channelizer exchange vs oracle", "n_gpus": world, "exchange": a.exchange, "ok": bool(flag.item())}))
         dist.destroy_process_group()
         sys.exit(0 if flag.item() else 1)
+    # piece-wise pipeline: analysis of piece i + 1 on the compute stream while piece i is exchanged on the communication stream
+    def pipelined(xs_all, rows_all, out_all, pieces):
+        comm_s = pipelined.stream
+        rp = -(-rows_all // pieces)
+        for i in range(pieces):
+            r0, r1 = i * rp, min((i + 1) * rp, rows_all)
+            if r1 <= r0:
+                break
+            if pipelined.free[i % 2] is not None:      # this piece buffer was last sent two pieces ago
+                torch.cuda.current_stream().wait_event(pipelined.free[i % 2])
+            g = pipelined.gbuf[i % 2].view(-1)[: world * (r1 - r0) * cpg].view(world, r1 - r0, cpg)
+            plan(xs_all[M * r0: M * (r1 + P - 1)], ngroups=world, out=g)
+            ev = torch.cuda.Event(); ev.record()
+            comm_s.wait_event(ev)
+            comm.exchange_at(g, [r1 - r0] * world, out_all, [q * rows_all + r0 for q in range(world)], stream=comm_s)
+            done = torch.cuda.Event(); done.record(comm_s)
+            pipelined.free[i % 2] = done
+        torch.cuda.current_stream().wait_stream(comm_s)
+        return out_all
+    if use_cabi:
+        pipelined.stream = torch.cuda.Stream()
+        rp_max = -(-nrows // max(a.pieces, 1))
+        pipelined.gbuf = [torch.empty((world, rp_max, cpg), dtype=torch.complex64, device="cuda") for _ in range(2)]
+        pipelined.free = [None, None]
     t_analysis = timed(lambda: plan(x, ngroups=world, out=grouped))
     t_both = timed(lambda: exchange(plan(x, ngroups=world, out=grouped)))
     mine = exchange(grouped)
     assert mine.shape == (world * nrows, cpg)
+    t_pipe = None
+    if use_cabi and a.pieces > 1:
+        pipe_buf = torch.empty_like(mine_buf)
+        t_pipe = timed(lambda: pipelined(x, nrows, pipe_buf, a.pieces))
+        torch.cuda.synchronize()
+        if not torch.equal(pipe_buf, mine):
+            bad = (torch.view_as_real(pipe_buf) != torch.view_as_real(mine)).any(dim=2).any(dim=1).nonzero().flatten()
+            raise AssertionError(f"piece-wise pipeline differs from the one-shot exchange: {bad.numel()} rows, first {bad[:8].tolist()}, last {bad[-4:].tolist()} of {mine.shape[0]}")
     if rank == 0:
         egress = nrows * (M - cpg) * 8                  # bytes this GPU sends to its peers per step
         print(json.dumps({"workload": "BASELINE.json configs[3]: 64-channel polyphase channelizer, P=16, channels sharded over the GPUs",
                           "n_gpus": world, "samples_per_gpu": n, "steps": a.steps,
                           "analysis_GSps": world * n / t_analysis / 1e9, "analysis_plus_exchange_GSps": world * n / t_both / 1e9,
                           "ms_analysis": t_analysis * 1e3, "ms_analysis_plus_exchange": t_both * 1e3,
+                          "ms_pipelined": None if t_pipe is None else t_pipe * 1e3, "pieces": a.pieces,
+                          "pipelined_GSps": None if t_pipe is None else world * n / t_pipe / 1e9,
                           "exchange_egress_GBps_per_gpu": (egress / max(t_both - t_analysis, 1e-9) / 1e9) if world > 1 else None,
                           "scaling": "weak",
                           "collective": "redio_pfb_exchange: RCCL ncclSend/ncclRecv group (C ABI)" if use_cabi else "all_to_all_single (%s)" % a.backend}))
