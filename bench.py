@@ -14,7 +14,7 @@ Rank 0 prints ONE JSON line.  `value` is exactly what the flags time (W warm-up 
 two barriers).  `roofline` is for the dominant (only) kernel, chain_v4_kernel: algorithmic bytes = 9.6 B per input
 sample (8 B read + 8/5 B written) over the kernel's mean duration in the timed region, measured with HIP
 events on the launch stream; `launch_ms_series` are those per-launch times.  The chip raises its clock over the first
-~100 launches of a burst, so after the headline the same launch is repeated `--steady` more times (default 300) and
+~100 launches of a burst, so after the headline the same launch is repeated `--steady` more times (default 1000) and
 reported as `steady_state` with its own kernel time and fraction -- never as `value`.  `roofline.traffic` comes from
 the rocprofv3 PMC passes of a separate run (`traffic_source`).  `cpu_baseline` is the CPU oracle (oracle/, a port of
 the reference's algorithm) timed on this host on a bounded sample: all cores as independent replicas (`value`), one
@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--steady", type=int, default=300, help="further launches after the timed region, reported as steady_state (0 = skip)")
+    ap.add_argument("--steady", type=int, default=1000, help="further launches after the timed region, reported as steady_state (0 = skip)")
     ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (default 2^28 = 2 GiB)")
     ap.add_argument("--unfused", action="store_true", help="run FIR and FFT as two kernels (12.8 B/sample)")
     ap.add_argument("--exact", action="store_true", help="reference rounding (mul+add) instead of fmaf in the FIR")
