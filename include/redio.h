@@ -302,8 +302,8 @@ enum {
     REDIO_SRC_ERR_BAD_INTERNAL_STATE = 22
 };
 typedef struct redio_src redio_src;
-/* converter: 0 best / 1 medium / 2 fastest sinc (3 zero-order-hold and 4 linear are not built:
- * REDIO_SRC_ERR_BAD_CONVERTER; the reference only ever asks for 1) */
+/* converter (samplerate.rs:26-30): 0 best / 1 medium / 2 fastest sinc, 3 zero-order hold, 4 linear; anything else
+ * REDIO_SRC_ERR_BAD_CONVERTER (the reference only ever asks for 1).  nchan independent mono streams, stored as rows. */
 int redio_src_create(redio_src **h, int converter, int nchan);
 int redio_src_destroy(redio_src *h);
 int redio_src_reset(redio_src *h);
@@ -321,7 +321,8 @@ int redio_src_set_mode(redio_src *h, int mode);
 int redio_src_process(redio_src *h, const void *d_in, long input_frames, long in_stride, void *d_out, long output_frames,
                       long out_stride, double src_ratio, int end_of_input, long *input_frames_used,
                       long *output_frames_gen, void *stream);
-/* host buffers, mono, synchronous: the body of the src_process drop-in (include/samplerate.h) */
+/* host buffers, interleaved frames of the handle's nchan channels (mono: plain samples), synchronous: the body of the
+ * src_process drop-in (include/samplerate.h); every channel is converted exactly as a mono stream */
 int redio_src_process_host(redio_src *h, const float *data_in, long input_frames, float *data_out, long output_frames,
                            double src_ratio, int end_of_input, long *input_frames_used, long *output_frames_gen);
 /* diagnostics: buffer-refill epochs of this handle served by the periodic-phase kernel (constant rational ratios such as

@@ -9,8 +9,9 @@
  * SRC_DATA is the C layout behind the Rust struct at samplerate.rs:15-24 (64 bytes on LP64).
  * src_process writes input_frames_used / output_frames_gen back through the pointer, as the
  * reference relies on (samplerate.rs:76,84).  Converter 1 (SRC_SINC_MEDIUM_QUALITY), channels 1 is
- * what the reference uses (:61); sinc converters 0-2 are built, 3-4 and channels > 1 return NULL
- * with the library's error code.  Deviation stated in DESIGN.md: the coefficient tables are not the
+ * what the reference uses (:61); all five converters it declares (:26-30: three sinc classes, zero-order
+ * hold, linear) and channels >= 1 (interleaved frames, each channel converted as a mono stream) are built;
+ * a converter above 4 or a channel count below 1 returns NULL with the library's error code.  Deviation stated in DESIGN.md: the coefficient tables are not the
  * library's (they cannot be reproduced here), so sample values differ from the real library within
  * its quality class; control flow and frame counts follow the published 0.1.8 algorithm.
  */
