@@ -431,6 +431,70 @@ static int dev_bank_graph(const char *in, const char *out_pfb, const char *out_o
     return 0;
 }
 
+// BASELINE.json configs[3] driven the way the reference's host works (src/ratpak.rs:60-185: one OS thread per block, all in ONE
+// process): the stream is time-sharded over every visible GPU, one channelizer thread per GPU writes the per-destination layout,
+// and the main thread regroups with redio_pfb_exchange_all (RCCL send/recv in one group) -- no Python, no torch.
+// Output file: for every device g, [all rows in time order][channels of g].
+static int dev_c4_sharded(const char *in, const char *out, int want_dev)
+{
+    using cf = std::complex<float>;
+    auto x = read_bin<cf>(in);
+    const int M = 64, P = 16;
+    int ndev = 0;
+    dev::check(redio_device_count(&ndev));
+    if (want_dev > 0 && want_dev < ndev) ndev = want_dev;
+    while (M % ndev) --ndev;
+    const size_t total_rows = x.size() / M, nout = total_rows - P + 1, cpg = (size_t)M / ndev;
+    const std::vector<float> proto = dsputils::lpf_corrected((size_t)M * P, 0.45f / M);
+    std::vector<redio_comm *> comms((size_t)ndev, nullptr);
+    dev::check(redio_comm_init_all(comms.data(), ndev, nullptr));
+    std::vector<size_t> first((size_t)ndev), rows((size_t)ndev);
+    for (int g = 0; g < ndev; ++g) { // contiguous output rows, the remainder to the lowest ranks (sharding.channelizer_time_shard)
+        const size_t base = nout / ndev, extra = nout % ndev;
+        rows[(size_t)g] = base + ((size_t)g < extra ? 1 : 0);
+        first[(size_t)g] = (size_t)g * base + ((size_t)g < extra ? (size_t)g : extra);
+    }
+    std::vector<void *> d_grouped((size_t)ndev, nullptr), d_out((size_t)ndev, nullptr), streams((size_t)ndev, nullptr);
+    std::vector<std::thread> th;
+    std::atomic<int> failed{0};
+    for (int g = 0; g < ndev; ++g)
+        th.push_back(spawn([&, g]() { // the channelizer block of GPU g
+            try {
+                dev::check(redio_set_device(g));
+                redio_pfb *h = nullptr;
+                dev::check(redio_pfb_create(&h, proto.data(), M, P, REDIO_FIR_FUSED));
+                const size_t nin = (rows[(size_t)g] + P - 1) * M;
+                void *d_in = nullptr;
+                dev::check(redio_malloc(&d_in, nin * sizeof(cf)));
+                dev::check(redio_malloc(&d_grouped[(size_t)g], rows[(size_t)g] * M * sizeof(cf)));
+                dev::check(redio_malloc(&d_out[(size_t)g], nout * cpg * sizeof(cf)));
+                dev::check(redio_stream_create(&streams[(size_t)g]));
+                dev::check(redio_upload(d_in, x.data() + first[(size_t)g] * M, nin * sizeof(cf), streams[(size_t)g]));
+                dev::check(redio_pfb_enqueue(h, d_in, nin, d_grouped[(size_t)g], ndev, streams[(size_t)g]));
+                dev::check(redio_stream_sync(streams[(size_t)g]));
+                redio_free(d_in);
+                redio_pfb_destroy(h);
+            } catch (...) { failed = 1; throw; }
+        }));
+    for (auto &t : th) t.join();
+    if (failed) return 4;
+    dev::check(redio_pfb_exchange_all(comms.data(), ndev, d_grouped.data(), d_out.data(), rows.data(), cpg, streams.data()));
+    std::vector<cf> all;
+    for (int g = 0; g < ndev; ++g) {
+        dev::check(redio_set_device(g));
+        dev::check(redio_stream_sync(streams[(size_t)g]));
+        std::vector<cf> mine(nout * cpg);
+        dev::check(redio_download(mine.data(), d_out[(size_t)g], mine.size() * sizeof(cf), nullptr));
+        dev::check(redio_stream_sync(nullptr));
+        all.insert(all.end(), mine.begin(), mine.end());
+        redio_free(d_grouped[(size_t)g]); redio_free(d_out[(size_t)g]); redio_stream_destroy(streams[(size_t)g]);
+        redio_comm_destroy(comms[(size_t)g]);
+    }
+    write_bin(out, all);
+    std::printf("devices %d\n", ndev);
+    return 0;
+}
+
 // a stream cut into messages of awkward, varying lengths through the carried-history blocks: the concatenated outputs are those
 // of ONE stateless call on the whole stream
 static int dev_stream_graph(const char *in, const char *out_chain, const char *out_fir, const char *out_ovs, size_t seed)
@@ -489,6 +553,7 @@ int main(int argc, char **argv)
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
         if (mode == "devchain" && argc == 6) return dev_chain_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
         if (mode == "devstream" && argc == 7) return dev_stream_graph(argv[2], argv[3], argv[4], argv[5], (size_t)std::atol(argv[6]));
+        if (mode == "devc4" && argc == 5) return dev_c4_sharded(argv[2], argv[3], std::atoi(argv[4]));
         if (mode == "devshaper" && argc == 6) return dev_shaper_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]));
         if (mode == "devmix" && argc == 6) return dev_mix_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), std::atof(argv[5]));
         if (mode == "devbank" && argc == 6) return dev_bank_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));

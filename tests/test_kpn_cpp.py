@@ -130,6 +130,24 @@ def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tm
 
 
 @pytest.mark.gpu
+def test_sharded_channelizer_from_one_cpp_process(exe, gpu, oracle, tmp_path):
+    """BASELINE.json configs[3] with no Python in the loop: one C++ process, one channelizer thread per visible GPU, the
+    regrouping through redio_comm_init_all / redio_pfb_exchange_all (RCCL) -- the reference's thread-per-block host model
+    (src/ratpak.rs:60-185).  Every device's [all rows][its channels] equals the oracle's channelizer of the whole stream."""
+    M, P, rows = 64, 16, 3001
+    x = oracle.synth_iq(0x5EED0004, 0, M * rows)
+    x.tofile(tmp_path / "in.bin")
+    out = subprocess.run([exe, "devc4", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ndev = int(out.stdout.split("devices")[1].split()[0])
+    want = oracle.pfb_channelizer(x, oracle.lpf_corrected(M * P, 0.45 / M), M, P, True)
+    cpg, nout = M // ndev, rows - P + 1
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.complex64).reshape(ndev, nout, cpg)
+    for g in range(ndev):
+        assert np.array_equal(bits(got[g]), bits(np.ascontiguousarray(want[:, g * cpg:(g + 1) * cpg]))), g
+
+
+@pytest.mark.gpu
 def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
     x = oracle.synth_f32(3, 0, 10000)
     x.tofile(tmp_path / "in.bin")
