@@ -102,7 +102,7 @@ struct redio_src {
     int *d_pint; // dpos | skipL | skipR, 256 each
     int period_hint;
     char *h_arena; size_t arena_cap, arena_used; // pinned: the periodic tables of one call, carved out epoch by epoch
-    long periodic_launches, general_launches; // diagnostics (redio_src_path_counts)
+    long periodic_launches, general_launches, tile_launches; // diagnostics (redio_src_path_counts); tile: general epochs that took the LDS-tile kernel
     // converters 3 / 4 (zero-order hold, linear): the value carried from the previous call, per channel, and the reset flag
     float *d_last; int zl_reset;
     float *d_rows_in, *d_rows_out; size_t rows_in_cap, rows_out_cap; // interleaved host form, nchan > 1: de-interleaved rows
@@ -163,7 +163,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->fast_inc = 0; s->d_cl = s->d_cr = nullptr; s->ncl = s->ncr = 0;
     s->d_pL = s->d_pR = nullptr; s->pL_cap = s->pR_cap = 0; s->d_pint = nullptr; s->period_hint = 0;
     s->h_pos = s->h_start = s->h_inc = nullptr; s->h_scale = nullptr; s->h_arena = nullptr; s->arena_cap = s->arena_used = 0;
-    s->periodic_launches = s->general_launches = 0;
+    s->periodic_launches = s->general_launches = s->tile_launches = 0;
     s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
     s->h_coeffs = coeffs;
     if (zl) {
@@ -511,6 +511,21 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
     ++f->general_launches;
     SRC_TRY(hipMemcpyAsync(f->d_pos + first, f->h_pos + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
     SRC_TRY(hipMemcpyAsync(f->d_start + first, f->h_start + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
+    if (f->window_ok) { // constant increment and scale, positions in order: the LDS-tile form of the general kernel
+        const int inc = f->h_inc[(size_t)first];
+        const double scale = f->h_scale[(size_t)first];
+        bool tile_ok = count >= 64;
+        for (long k = 1; tile_ok && k < count; ++k)
+            tile_ok = f->h_inc[(size_t)(first + k)] == inc && f->h_scale[(size_t)(first + k)] == scale &&
+                      f->h_pos[(size_t)(first + k)] >= f->h_pos[(size_t)(first + k - 1)];
+        const size_t lds = tile_ok ? src_tile_lds_bytes(f->h_pos + first, count, 128, f->coeff_half_len, inc) : 0;
+        if (lds) {
+            hipError_t e = launch_src_tile(f->d_buf[f->cur], f->buf_stride, nullptr, 0, f->buf_stride, f->buf_stride, f->d_coeffs, f->coeff_half_len,
+                                           f->d_pos + first, f->d_start + first, inc, scale, d_out + first, out_stride, count, f->nchan, lds, st);
+            if (e == hipSuccess) { ++f->tile_launches; return REDIO_OK; }
+            if (e != hipErrorNotSupported) return hip_rc(e);
+        }
+    }
     SRC_TRY(hipMemcpyAsync(f->d_inc + first, f->h_inc + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
     SRC_TRY(hipMemcpyAsync(f->d_scale + first, f->h_scale + first, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
     SRC_TRY(launch_src_exact(f->d_buf[f->cur], f->buf_stride, f->d_coeffs, f->coeff_half_len, f->d_pos + first, f->d_start + first,
@@ -659,6 +674,152 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
     return REDIO_OK;
 }
 
+// Would the refill epochs of this call run the periodic-phase kernel (small per-phase tables, no per-tap interpolation: the faster
+// form where it applies)?  Same period test and table-size rule as try_periodic_epoch, on the first n outputs of the dry run.
+static bool window_prefers_periodic(const redio_src *f, long n, int inc)
+{
+    const int *pos = f->h_pos, *start = f->h_start;
+    for (int P = 1; P <= 256 && 2L * P <= n; ++P) {
+        if (start[P] != start[0]) continue;
+        const int Q = pos[P] - pos[0];
+        bool ok = true;
+        for (long k = 0; ok && k + P < n; ++k) ok = start[k + P] == start[k] && pos[k + P] - pos[k] == Q;
+        if (!ok) continue;
+        const long taps = 2L * ((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 2;
+        return (long)P * taps <= 65536;
+    }
+    return false;
+}
+
+// ---- single-launch path for ANY constant ratio ---------------------------------------------------------------------------
+// The library's control flow (refills, positions, phases) is run on counters with its own double recurrence, exactly as the
+// epoch loop of src_process_impl runs it, but nothing is launched per refill: every output's absolute position in the window
+// [old buffer image | new input] and its start index are recorded and the LDS-tile kernel evaluates them 16384 at a time (a call
+// at ratio 0.0213 has 46 refill epochs of 120 outputs each: far too little work per launch; a long call's next chunk is being
+// decided by the host while the previous one runs), then the part of the buffer image later calls can read is rebuilt.  Ratios whose
+// phases repeat with small tables are left to the epoch path's periodic kernel (window_prefers_periodic).  Same in_used / out_gen / final state as the epoch path (tests compare the two).  Returns 1 when it
+// handled the call, 0 when not eligible, an error code otherwise.
+static int try_general_window(redio_src *f, const SrcInput &in, long in_count, float *d_out, long out_stride, long out_count,
+                              double src_ratio_arg, int end_of_input, long *in_used_out, long *out_gen_out, hipStream_t st)
+{
+    if (end_of_input || f->b_real_end >= 0 || !in.dev || out_count < 256) return 0;
+    if (fabs(f->last_ratio - src_ratio_arg) > 1e-10) return 0; // the ratio varies inside the call: per-output increments
+    const double src_ratio = f->last_ratio;
+    double count = (f->coeff_half_len + 2.0) / f->index_inc;
+    const double minr = f->last_ratio < src_ratio_arg ? f->last_ratio : src_ratio_arg;
+    if (minr < 1.0) count /= minr;
+    const int half = (int)lrint(count) + 1;
+    const double fp_one = (double)(1 << SRC_SHIFT);
+    const double float_increment = f->index_inc * (src_ratio < 1.0 ? src_ratio : 1.0);
+    const int inc = (int)lrint(float_increment * fp_one);
+    const double scale = float_increment / f->index_inc;
+    const double step = 1.0 / src_ratio;
+    constexpr int NT = 128;          // outputs per workgroup of the tile kernel
+    constexpr long CHUNK = 16384;    // outputs per launch: the host's recurrence for the next chunk runs beside the kernel of this one
+    constexpr long PROBE = 1024;     // outputs looked at before the first launch to choose between this path and periodic epochs
+    if ((double)NT * step + 2.0 * (double)((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 16.0 > 15000.0) return 0; // no LDS tile holds it
+    int rc = ensure_scratch(f, (size_t)out_count);
+    if (rc) return rc;
+    auto wrap = [&](int x) { while (x >= f->b_len) x -= f->b_len; return x; };
+    const long a_limit_max = 0x7fffffffl;
+    // dry run of sinc_mono_vari_process / prepare_data on counters
+    int b_current = f->b_current, b_end = f->b_end;
+    long A0 = 0, in_used = 0, out_gen = 0, launched = 0;
+    // absolute index of input[0]: the window is [old image | input], and the image's b_end is where the next new sample goes --
+    // through every refill (a move shifts A0 and b_end by opposite amounts, an append moves b_end and in_used together)
+    const long a_in0 = (b_current == 0 && f->b_end == 0) ? half : (long)b_end;
+    const long a_limit = a_in0 + in_count > 0 ? a_in0 + in_count : 1; // absolute indices below this exist in the window
+    bool probed = false;
+    auto launch_chunk = [&](long first, long n) -> int {
+        if (n <= 0) return 1;
+        const size_t lds = src_tile_lds_bytes(f->h_pos + first, n, NT, f->coeff_half_len, inc);
+        if (!lds) return 0;
+        if (hipMemcpyAsync(f->d_pos + first, f->h_pos + first, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(f->d_start + first, f->h_start + first, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+            return hip_rc(hipGetLastError());
+        hipError_t e = launch_src_tile(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, a_limit, f->d_coeffs, f->coeff_half_len,
+                                       f->d_pos + first, f->d_start + first, inc, scale, d_out + first, out_stride, n, f->nchan, lds, st);
+        if (e == hipErrorNotSupported) return 0;
+        if (e != hipSuccess) return hip_rc(e);
+        ++f->general_launches; ++f->tile_launches;
+        return 1;
+    };
+    // giving the call back to the epoch path after launches were issued: they read h_pos / h_start asynchronously, and that path
+    // refills the same arrays -- wait for them first (the outputs they wrote are simply written again)
+    auto give_back = [&](int code) { if (launched > 0) hipStreamSynchronize(st); return code; };
+    double input_index = f->last_position;
+    double rem = fmod_one(input_index);
+    b_current = wrap(b_current + (int)lrint(input_index - rem));
+    input_index = rem;
+    while (out_gen < out_count) {
+        int samples_in_hand = wrap(b_end - b_current + f->b_len);
+        if (samples_in_hand <= half) {
+            int len;
+            if (b_current == 0) {
+                len = f->b_len - 2 * half;
+                b_current = b_end = half;
+            } else if (b_end + half + 1 < f->b_len) {
+                len = f->b_len - b_current - half;
+                if (len < 0) len = 0;
+            } else {
+                len = b_end - b_current;
+                A0 += b_current - half;
+                b_current = half;
+                b_end = b_current + len;
+                len = f->b_len - b_current - half;
+                if (len < 0) len = 0;
+            }
+            const long avail = in_count - in_used;
+            if (avail < len) len = (int)avail;
+            if (len < 0 || b_end + len > f->b_len) return give_back(0); // let the epoch path report the library's error
+            if (len > 0 && A0 + b_end - in_used != a_in0) return give_back(0); // cannot happen (see a_in0)
+            b_end += len;
+            in_used += len;
+            samples_in_hand = wrap(b_end - b_current + f->b_len);
+            if (samples_in_hand <= half) break;
+        }
+        int start_fp = (int)lrint(input_index * float_increment * fp_one);
+        long at = A0 + b_current;
+        if (start_fp == inc) { start_fp = 0; at += 1; } // the next sample at phase zero: same taps, same samples, same order
+        if (at >= a_limit_max) return give_back(0);
+        f->h_start[(size_t)out_gen] = start_fp;
+        f->h_pos[(size_t)out_gen] = (int)at;
+        ++out_gen;
+        if (!probed && out_gen == PROBE) {
+            probed = true;
+            if (window_prefers_periodic(f, out_gen, inc)) return 0;
+        }
+        if (out_gen - launched >= CHUNK) {
+            const int r = launch_chunk(launched, out_gen - launched);
+            if (r != 1) return give_back(r);
+            launched = out_gen;
+        }
+        input_index += step;
+        rem = fmod_one(input_index);
+        b_current = wrap(b_current + (int)lrint(input_index - rem));
+        input_index = rem;
+    }
+    if (!probed && window_prefers_periodic(f, out_gen, inc)) return 0;
+    {
+        const int r = launch_chunk(launched, out_gen - launched);
+        if (r != 1) return give_back(r);
+        launched = out_gen;
+    }
+    // rebuild [b_current - half, b_end) of the final image into the other buffer
+    const int other = f->cur ^ 1;
+    long j0 = (long)b_current - half, j1 = b_end;
+    if (j0 < 0) j0 = 0;
+    SRC_TRY(launch_src_window_image(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, A0, j0, j1, f->d_buf[other], f->nchan, st));
+    f->cur = other;
+    f->b_current = b_current;
+    f->b_end = b_end;
+    f->last_position = input_index;
+    f->last_ratio = src_ratio;
+    if (in_used_out) *in_used_out = in_used;
+    if (out_gen_out) *out_gen_out = out_gen;
+    return 1;
+}
+
 // src_process + sinc_mono_vari_process; outputs land in d_out[nchan][out_stride]
 static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames, float *d_out, long out_stride, long output_frames,
                             double src_ratio_arg, int end_of_input, long *in_used_out, long *out_gen_out, hipStream_t st)
@@ -681,6 +842,9 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
                                                out_gen_out, st);
         if (handled == 1) return REDIO_OK;
         if (handled != 0) return handled;
+        const int general = try_general_window(f, in, in_count, d_out, out_stride, out_count, src_ratio_arg, end_of_input, in_used_out, out_gen_out, st);
+        if (general == 1) return REDIO_OK;
+        if (general != 0) return general;
     }
     int rc = ensure_scratch(f, (size_t)out_count);
     if (rc) return rc;

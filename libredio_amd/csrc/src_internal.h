@@ -14,6 +14,13 @@ bool src_periodic_shape(int P, int Q, int NL, int NR, int dpos_max, int G, int *
 hipError_t launch_src_periodic(const float *win, long win_stride, const double *Lc, const double *Rc, const int *dpos, const int *skipL,
                                const int *skipR, int P, int Q, int NL, int NR, int maxskipL, int maxskipR, int dpos_max, int pos0,
                                double scale, float *out, long out_stride, long nout, int nchan, hipStream_t s);
+// general phase with an LDS tile of the buffer image and the two wings of an output on two threads (constant increment and scale)
+size_t src_tile_lds_bytes(const int *pos_host, long nout, int nt, int coeff_half_len, int increment);
+hipError_t launch_src_tile(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0, long a_limit,
+                           const float *coeffs, int coeff_half_len, const int *pos, const int *start,
+                           int increment, double scale, float *out, long out_stride, long nout, int nchan, size_t lds_bytes, hipStream_t s);
+hipError_t launch_src_window_image(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0, long A0f, long j0, long j1,
+                                   float *new_img, int nchan, hipStream_t s);
 hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,
                              const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, bool fast,
                              long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,

@@ -232,6 +232,119 @@ __device__ __forceinline__ void src_tile_load(XT *xs, const SrcWindow &w, int ch
     }
 }
 
+// ---- general phase, LDS tile: any constant ratio (0.0213, 3.7 ...) without a table per phase ----------------------------------
+// src_sinc_exact_kernel gives an output to one lane and lets it walk ~2 * half_len / increment taps with dependent loads from
+// global memory: with a few thousand outputs per channel the launch has little parallelism and is bound by load latency (8 ms for
+// 64 channels x 2^18 frames at ratio 0.0213).  Here a workgroup takes NT consecutive outputs of one channel, stages the span of
+// the buffer image behind them in LDS, and gives the two wings of an output to two threads (they are independent sums that meet
+// only in scale * (left + right)).  A wing is a counted loop (its tap count is known up front), walked U taps per step with the
+// next step's table entries (global, L1 / L2-resident) and samples (LDS) requested before the current step's arithmetic.  Per tap
+// exactly the expression of calc_output_single -- fraction from the low 12 bits, the float difference of two adjacent entries,
+// icoeff in double, the product rounded, the sum in ascending order -- so the result is bit-identical to the per-lane kernel.
+// Samples come through a SrcWindow: an epoch's buffer image (everything "old image"), or -- for a whole call in ONE launch -- the
+// window [old image | new input] addressed by absolute index, with the positions the host's dry run of the library's control
+// flow produced (try_general_window, src_host.hip).
+template <int NT, int U>
+__global__ __launch_bounds__(2 * NT) void src_sinc_tile_kernel(SrcWindow w, long a_limit, const float *__restrict__ coeffs,
+                                                               int coeff_half_len, const int *__restrict__ pos, const int *__restrict__ start,
+                                                               int increment, double scale, float *__restrict__ out, long out_stride, long nout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    __shared__ double rsum[NT];
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const long k0 = (long)blockIdx.x * NT;
+    const int nvalid = (int)((nout - k0 < NT) ? nout - k0 : NT);
+    const int max_filter_index = coeff_half_len << SRC_SHIFT_BITS;
+    const int cmax = max_filter_index / increment; // no wing has more than cmax + 1 taps
+    const int lo = pos[k0] - cmax, hi = pos[k0 + nvalid - 1] + 1 + cmax; // positions are non-decreasing inside an epoch (checked by the host)
+    for (int n = tid; n <= hi - lo; n += 2 * NT) {
+        long a = (long)lo + n;
+        a = a < 0 ? 0 : (a < a_limit ? a : a_limit - 1); // clamped indices are never read by a tap that exists
+        xs[n] = win_load(w, ch, a);
+    }
+    __syncthreads();
+    const bool right = tid >= NT; // wave-uniform
+    const int o = right ? tid - NT : tid;
+    double acc = 0.0;
+    if (o < nvalid) {
+        const int p = pos[k0 + o] - lo, st = start[k0 + o];
+        int fi = right ? increment - st : st;
+        const int cc = (max_filter_index - fi) / increment;
+        fi += cc * increment;                     // the far end of the wing
+        int di = right ? p + 1 + cc : p - cc;
+        const int step = right ? -1 : 1;
+        const int ntaps = cc + 1;
+        const double inv_fp_one = 1.0 / (double)(1 << SRC_SHIFT_BITS);
+        float c0[U], c1[U], xv[U];
+        int fr[U];
+        auto fetch = [&](int t) { // taps t .. t + U - 1 (clamped: a tap past the end is fetched again and not used)
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int tt = t + j < ntaps ? t + j : ntaps - 1;
+                const int f = fi - tt * increment;
+                const int indx = f >> SRC_SHIFT_BITS;
+                fr[j] = f & ((1 << SRC_SHIFT_BITS) - 1);
+                c0[j] = coeffs[indx];
+                c1[j] = coeffs[indx + 1];
+                xv[j] = xs[di + tt * step];
+            }
+        };
+        fetch(0);
+        for (int t = 0; t < ntaps; t += U) {
+            float k0v[U], k1v[U], xc[U];
+            int fc[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) { k0v[j] = c0[j]; k1v[j] = c1[j]; xc[j] = xv[j]; fc[j] = fr[j]; }
+            if (t + U < ntaps) fetch(t + U);
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (t + j < ntaps) {
+                    const double fraction = (double)fc[j] * inv_fp_one;
+                    const float dc = k1v[j] - k0v[j];
+                    const double icoeff = (double)k0v[j] + fraction * (double)dc;
+                    acc += icoeff * (double)xc[j];
+                }
+        }
+    }
+    if (right) rsum[o] = acc;
+    __syncthreads();
+    if (!right && o < nvalid) out[(long)ch * out_stride + k0 + o] = (float)(scale * (acc + rsum[o]));
+}
+
+// LDS floats the tile of outputs [k0, k0 + nt) needs, from the host's copy of the positions; 0 if some tile cannot fit
+size_t src_tile_lds_bytes(const int *pos_host, long nout, int nt, int coeff_half_len, int increment)
+{
+    const int cmax = (coeff_half_len << SRC_SHIFT_BITS) / increment;
+    long worst = 0;
+    for (long k0 = 0; k0 < nout; k0 += nt) {
+        const long k1 = k0 + nt < nout ? k0 + nt : nout;
+        const long span = (long)pos_host[k1 - 1] - pos_host[k0] + 2 * (long)cmax + 2;
+        worst = span > worst ? span : worst;
+    }
+    const size_t b = (size_t)worst * sizeof(float);
+    return b <= 60 * 1024 ? b : 0; // two or three workgroups per CU
+}
+
+// old_img / input / a_in0: the window (an epoch launch passes its image as old_img, input = nullptr, a_in0 = a_limit = its length)
+hipError_t launch_src_tile(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0, long a_limit,
+                           const float *coeffs, int coeff_half_len, const int *pos, const int *start,
+                           int increment, double scale, float *out, long out_stride, long nout, int nchan, size_t lds_bytes, hipStream_t s)
+{
+    if (nout <= 0 || nchan <= 0) return hipSuccess;
+    constexpr int NT = 128;
+    const SrcWindow w = {old_img, old_stride, input ? input : old_img, input ? in_stride : old_stride, a_in0};
+    auto kern = src_sinc_tile_kernel<NT, 4>;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((nout + NT - 1) / NT), (unsigned)nchan);
+    hipLaunchKernelGGL(kern, grid, dim3(2 * NT), lds_bytes, s, w, a_limit, coeffs, coeff_half_len, pos, start, increment, scale, out, out_stride, nout);
+    return hipGetLastError();
+}
+constexpr int SRC_TILE_NT = 128;
+
 // The two wings of one output at zero phase: left = sum_t L[t]*x[t], right = sum_t R[t]*x[c-t], each a
 // strictly ordered double sum (far end first, multiply and add rounded separately) exactly as
 // calc_output_single runs them.  The wings are independent chains, so they run side by side, U taps
@@ -543,6 +656,16 @@ __global__ __launch_bounds__(256) void src_window_image_kernel(SrcWindow w, long
 {
     const long j = j0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < j1) dst[(long)blockIdx.y * dst_stride + j] = win_load(w, blockIdx.y, A0 + j);
+}
+
+hipError_t launch_src_window_image(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0, long A0f, long j0, long j1,
+                                   float *new_img, int nchan, hipStream_t s)
+{
+    if (j1 <= j0 || nchan <= 0) return hipSuccess;
+    const SrcWindow w = {old_img, old_stride, input, in_stride, a_in0};
+    dim3 grid((unsigned)((j1 - j0 + 255) / 256), (unsigned)nchan);
+    hipLaunchKernelGGL(src_window_image_kernel, grid, dim3(256), 0, s, w, A0f, j0, j1, new_img, old_stride);
+    return hipGetLastError();
 }
 
 hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,

@@ -251,7 +251,8 @@ def test_c3_256_channels_two_messages(gpu, redio, oracle):
 
 @pytest.mark.parametrize("nch", [1, 5])
 @pytest.mark.parametrize("ratio,conv,periodic", [(48000 / 44100, 1, True), (2.0, 1, True), (1.5, 1, True), (0.3, 1, True), (4 / 3, 2, True),
-                                                 (44100 / 48000, 0, True), (0.75, 1, True), (0.0213, 1, False), (3.7, 1, None)])
+                                                 (44100 / 48000, 0, True), (0.75, 1, True), (0.0213, 1, False), (3.7, 1, None),
+                                                 (2 ** 0.5, 1, False), (0.0917, 2, False), (3.14159265358979 / 3, 0, False)])
 def test_rational_ratios_take_the_periodic_phase_kernel_bit_exactly(gpu, redio, oracle, ratio, conv, periodic, nch):
     """samplerate::resample takes any ratio: f64 (samplerate.rs:59).  A constant rational ratio makes the per-output
     (filter start index, position step) repeat every P outputs; those epochs run src_sinc_periodic_kernel (P sets of
