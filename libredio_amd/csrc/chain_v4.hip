@@ -128,21 +128,6 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     }
 }
 
-// CU count of the device the calling thread is bound to (kept per device: a process may drive several GPUs)
-static int num_cus_v4()
-{
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        int n = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        cus[dev] = n > 0 ? n : 256;
-    }
-    return cus[dev];
-}
-
 template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false>
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg)
@@ -157,7 +142,7 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     // half empty, and the launch ends when the most crowded CU does (measured: wave lifetimes 320-570 us).
     constexpr size_t LDS = (160 * 1024 / (4 * WPS)) - 480 > LDS_NEED ? (160 * 1024 / (4 * WPS)) - 480 : LDS_NEED;
     static_assert((4 * WPS + 1) * LDS > 160 * 1024, "one more wave must not fit");
-    long waves = 4L * WPS * num_cus_v4();
+    long waves = 4L * WPS * num_cus();
     if (waves > nblocks) waves = nblocks;
     const long bpw = (nblocks + waves - 1) / waves;
     const long grid = (nblocks + bpw - 1) / bpw;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, int K, 
 #pragma unroll
     for (int j = 0; j < CH; ++j) h[j] = (!GUARD || j0 + j < K) ? taps[j0 + j] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < WIN; ++i)
+    for (int i = 0; i < WIN; ++i) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int j = i - r * D;
@@ -83,25 +83,59 @@ __device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, int K, 
                 if (!GUARD || j0 + j < K) acc[r] = mac<FUSED>(xv[i], h[j], acc[r]);
             }
         }
+    }
 }
 
+// Memory side (round 2; the skeleton alone -- tile in, tile out, no arithmetic -- ran at 2.9 TB/s with 8-byte loads and each lane
+// storing its R consecutive outputs; 5.5 TB/s now): the tile arrives as 16-byte loads, and the outputs leave through an LDS
+// transpose (lane writes its R results at a stride of R + 1 elements, conflict-free; the workgroup reads them back in output
+// order) so that every store instruction writes 1 KiB of consecutive bytes.  A persistent form (a workgroup walks tiles with the
+// next tile's loads in flight during the arithmetic) was built and measured slower -- at 64 taps / 1 the tile's LDS traffic
+// (237 KB: window reads, tile, transpose) and its multiply-adds each fill most of the time on their own, and fewer resident waves
+// hide less of it: profiles/r02_fir_generic_experiments.txt.
 template <typename T, int D, int R, bool FUSED>
 __global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ x, long n_in, const float *__restrict__ taps, int K,
-                                                          T *__restrict__ y, long n_out)
+                                                          T *__restrict__ y, long n_out, int vec_in, int vec_out)
 {
-    constexpr int NT = 256, CH = 16, TILE_OUT = NT * R, LSTR = R * D;
+    constexpr int NT = 256, CH = 16, TILE_OUT = NT * R, LSTR = R * D, VEC = 16 / (int)sizeof(T);
     constexpr bool PAD = (LSTR % 2) == 0;
+    static_assert((R & (R - 1)) == 0, "R is a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *xs = reinterpret_cast<T *>(smem);
     const int tid = threadIdx.x;
     const int kc = (K + CH - 1) / CH * CH;
     const int tile_in = (TILE_OUT - 1) * D + kc;
     const long in0 = (long)blockIdx.x * TILE_OUT * D;
+    auto put = [&](int n, T v) { xs[PAD ? n + n / LSTR : n] = v; };
+    if (vec_in) { // x is 16-byte aligned (in0 * sizeof(T) always is)
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + in0);
+        const int nv = (tile_in + VEC - 1) / VEC;
 #pragma unroll 4
-    for (int n = tid; n < tile_in; n += NT) {
-        T v{};
-        if (in0 + n < n_in) v = x[in0 + n];
-        xs[PAD ? n + n / LSTR : n] = v;
+        for (int v = tid; v < nv; v += NT) {
+            const int n = v * VEC;
+            if (in0 + n + VEC <= n_in) {
+                const float4 q = x4[v];
+                if constexpr (sizeof(T) == 8) {
+                    put(n, T{q.x, q.y}); put(n + 1, T{q.z, q.w});
+                } else {
+                    put(n, q.x); put(n + 1, q.y); put(n + 2, q.z); put(n + 3, q.w);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    T v1{};
+                    if (in0 + n + e < n_in) v1 = x[in0 + n + e];
+                    put(n + e, v1); // at most VEC - 1 elements past tile_in: inside the allocation (launch_chunked)
+                }
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int n = tid; n < tile_in; n += NT) {
+            T v{};
+            if (in0 + n < n_in) v = x[in0 + n];
+            put(n, v);
+        }
     }
     __syncthreads();
     T acc[R];
@@ -111,10 +145,29 @@ __global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ 
     const int nfull = K / CH;
     for (int c = 0; c < nfull; ++c) fir_chunk<T, D, R, FUSED, false>(xs, base, c * CH, K, taps, acc);
     if (nfull * CH < K) fir_chunk<T, D, R, FUSED, true>(xs, base, nfull * CH, K, taps, acc);
-    const long o0 = (long)blockIdx.x * TILE_OUT + (long)tid * R;
+    const long o0 = (long)blockIdx.x * TILE_OUT;
+    // outputs through LDS: element e of the tile sits at ys[(e / R) * (R + 1) + e % R]
+    __syncthreads(); // every wave is done with the input tile
+    T *ys = xs;
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (o0 + r < n_out) y[o0 + r] = acc[r];
+    for (int r = 0; r < R; ++r) ys[tid * (R + 1) + r] = acc[r];
+    __syncthreads();
+    const long left = n_out - o0; // outputs of this tile that exist
+#pragma unroll
+    for (int v = tid; v < TILE_OUT / VEC; v += NT) {
+        const int e0 = v * VEC;
+        T o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = ys[((e0 + e) / R) * (R + 1) + ((e0 + e) & (R - 1))];
+        if (vec_out && e0 + VEC <= left) {
+            const float *f = reinterpret_cast<const float *>(o);
+            reinterpret_cast<float4 *>(y + o0)[v] = make_float4(f[0], f[1], f[2], f[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (e0 + e < left) y[o0 + e0 + e] = o[e];
+        }
+    }
 }
 
 template <typename T, int D, int R, bool FUSED>
@@ -122,15 +175,18 @@ static hipError_t launch_chunked(const T *x, long n_in, const float *taps, int K
 {
     constexpr int TILE_OUT = 256 * R, LSTR = R * D;
     const int kc = (K + 15) / 16 * 16;
-    const long tile_in = (long)(TILE_OUT - 1) * D + kc;
-    const size_t lds = (size_t)(tile_in + ((LSTR % 2) == 0 ? tile_in / LSTR : 0) + 2) * sizeof(T);
+    const long tile_in = (long)(TILE_OUT - 1) * D + kc + 4; // + the tail of the last 16-byte load
+    long elems = tile_in + ((LSTR % 2) == 0 ? tile_in / LSTR : 0) + 2;
+    if (elems < 256L * (R + 1)) elems = 256L * (R + 1); // the output transpose reuses the tile
+    const size_t lds = (size_t)elems * sizeof(T);
     if (lds > 150 * 1024) return hipErrorNotSupported;
     auto kern = fir_chunked_kernel<T, D, R, FUSED>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((n_out + TILE_OUT - 1) / TILE_OUT)), dim3(256), lds, s, x, n_in, taps, K, y, n_out);
+    const int vec_in = (reinterpret_cast<uintptr_t>(x) & 15) == 0, vec_out = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_out + TILE_OUT - 1) / TILE_OUT)), dim3(256), lds, s, x, n_in, taps, K, y, n_out, vec_in, vec_out);
     return hipGetLastError();
 }
 

@@ -62,6 +62,21 @@ hipError_t launch_synth_f32(float *out, uint32_t seed, uint64_t first, long n, h
 bool ovsave_big_size(int nfft);
 hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const float2 *x, long hop, float2 *a, float2 *b, const float2 *Hc,
                              float2 *out, long nblk, float scale, hipStream_t s);
+// CU count of the device the calling thread is bound to (kept per device: a process may drive several GPUs)
+inline int num_cus()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[dev] = n > 0 ? n : 256;
+    }
+    return cus[dev];
+}
+
 } // namespace redio
 
 // plan shapes for the carried-history layer (stream_carry.hip); defined next to each plan struct

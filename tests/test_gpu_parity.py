@@ -368,3 +368,35 @@ def test_chain_full_size_properties(gpu, redio, oracle):
     out3 = chain(x)
     s3 = gpu.view_as_real(out3).view(gpu.int32).sum(dtype=gpu.int64).item()
     assert s1 == s3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,d", [(64, 1), (31, 2), (101, 3), (100, 4), (255, 5), (77, 8), (255, 10), (500, 1), (1000, 2), (16, 1), (1, 1), (5, 3)])
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("fused", [False, True])
+def test_fir_streaming_kernel_long_inputs(gpu, redio, oracle, k, d, cplx, fused):
+    """Long inputs (hundreds of tiles per decimation class, 16-byte loads and the transposed stores on the aligned view, the
+    element-wise paths on the unaligned one): dsputils::convolve's fold order (dsputils.rs:30-32) per output, checked on
+    windows spread over the stream, at both ends and around the last tile boundaries."""
+    n = 600 * 2048 * d + 12345 + k
+    x = (oracle.synth_iq if cplx else oracle.synth_f32)(4242 + k, 0, n)
+    taps = oracle.synth_f32(99 + d, 0, k)
+    plan = redio.Fir(taps, d, complex_input=cplx, fused=fused)
+    dx = gpu.from_numpy(x).cuda()
+    got = plan(dx).cpu().numpy()
+    nout = plan.nout(n)
+    assert got.shape[0] == nout == (n - k) // d + 1
+    rng = np.random.default_rng(k * 31 + d)
+    starts = [0, nout - 3000, max(0, nout - 20000)] + [int(v) for v in rng.integers(0, nout - 3000, 12)]
+    # the last tile boundaries (tiles are 512 ... 2048 outputs)
+    starts += [max(0, (nout // 2048 - j) * 2048 - 1500) for j in range(0, 4)]
+    for o0 in starts:
+        o1 = min(nout, o0 + 3000)
+        want = oracle.fir(x[o0 * d: (o1 - 1) * d + k], taps, d, fused)
+        assert np.array_equal(bits(got[o0:o1]), bits(want)), (k, d, cplx, fused, o0)
+    # an unaligned view of the same stream: same outputs, shifted
+    off = 1
+    got2 = plan(dx[off:]).cpu().numpy()
+    m = min(len(got2), 5000)
+    want2 = oracle.fir(x[off: off + (m - 1) * d + k], taps, d, fused)
+    assert np.array_equal(bits(got2[:m]), bits(want2))

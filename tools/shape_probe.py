@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Run ONE plan shape a few times (for rocprofv3 passes on a secondary kernel):
+    python3 tools/shape_probe.py fir K D [log2n] [launches]
+    python3 tools/shape_probe.py pfb M P [log2n] [launches]
+    python3 tools/shape_probe.py fft N 0 [log2n] [launches]
+Prints the HIP-event mean per launch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import libredio_amd as R
+
+kind, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 26)
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+x = R.synth_iq(1, 0, n)
+if kind == "fir":
+    plan = R.Fir(R.dsputils.lpf_corrected(a, 0.4 / b if b > 1 else 0.2), b, fused=True)
+    out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
+    run = lambda: plan(x, out=out)
+elif kind == "pfb":
+    plan = R.Channelizer(R.dsputils.lpf_corrected(a * b, 0.45 / a), a, b)
+    out = torch.empty((plan.nrows(n), a), dtype=torch.complex64, device="cuda")
+    run = lambda: plan(x, out=out)
+else:
+    x = x[: n // a * a]
+    plan = R.Fft(a)
+    out = torch.empty_like(x)
+    run = lambda: plan(x, out=out)
+for _ in range(3): run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print(f"{kind} {a} {b}: {ms:.3f} ms per launch, {n / ms / 1e6:.1f} GS/s")
