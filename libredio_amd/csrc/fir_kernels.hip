@@ -59,11 +59,13 @@ __global__ __launch_bounds__(NT) void fir_tiled_kernel(const T *__restrict__ x, 
 // need for these taps (statically indexed registers), the 16 taps arrive as one scalar load, and the
 // multiply-adds are fully unrolled inside the chunk.  Every accumulator still receives its products in
 // ascending tap order (chunks ascending, taps ascending inside a chunk), so results are bit-identical to the
-// reference fold.  The last, partial chunk runs the same code with a wave-uniform guard per tap.
-template <typename T, int D, int R, bool FUSED, bool GUARD>
-__device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, int K, const float *__restrict__ taps, T (&acc)[R])
+// reference fold.  The K % 16 taps behind the last whole chunk run as chunks of 8, 4, 2 and 1 taps (the binary
+// digits of the remainder): the same straight-line code at smaller sizes, no per-tap guard (a guarded 16-tap
+// chunk compiled to a select per product and cost as much as three whole chunks).
+template <typename T, int D, int R, bool FUSED, int CH>
+__device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, const float *__restrict__ taps, T (&acc)[R])
 {
-    constexpr int CH = 16, WIN = CH + (R - 1) * D, LSTR = R * D;
+    constexpr int WIN = CH + (R - 1) * D, LSTR = R * D;
     constexpr bool PAD = (LSTR % 2) == 0;
     T xv[WIN];
 #pragma unroll
@@ -73,17 +75,29 @@ __device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, int K, 
     }
     float h[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) h[j] = (!GUARD || j0 + j < K) ? taps[j0 + j] : 0.0f;
+    for (int j = 0; j < CH; ++j) h[j] = taps[j0 + j];
 #pragma unroll
-    for (int i = 0; i < WIN; ++i) {
+    for (int i = 0; i < WIN; ++i)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int j = i - r * D;
-            if (j >= 0 && j < CH) {
-                if (!GUARD || j0 + j < K) acc[r] = mac<FUSED>(xv[i], h[j], acc[r]);
-            }
+            if (j >= 0 && j < CH) acc[r] = mac<FUSED>(xv[i], h[j], acc[r]);
         }
-    }
+}
+
+// all K taps of the R outputs of a lane: whole chunks, then the remainder's binary digits
+template <typename T, int D, int R, bool FUSED, int CH = 16>
+__device__ __forceinline__ void fir_chunks(const T *xs, int base, int K, const float *__restrict__ taps, T (&acc)[R])
+{
+    static_assert(CH == 16 || CH == 32, "whole-chunk size");
+    const int nfull = K / CH;
+    for (int c = 0; c < nfull; ++c) fir_chunk<T, D, R, FUSED, CH>(xs, base, c * CH, taps, acc);
+    int j0 = nfull * CH;
+    if (CH == 32 && (K & 16)) { fir_chunk<T, D, R, FUSED, 16>(xs, base, j0, taps, acc); j0 += 16; }
+    if (K & 8) { fir_chunk<T, D, R, FUSED, 8>(xs, base, j0, taps, acc); j0 += 8; }
+    if (K & 4) { fir_chunk<T, D, R, FUSED, 4>(xs, base, j0, taps, acc); j0 += 4; }
+    if (K & 2) { fir_chunk<T, D, R, FUSED, 2>(xs, base, j0, taps, acc); j0 += 2; }
+    if (K & 1) fir_chunk<T, D, R, FUSED, 1>(xs, base, j0, taps, acc);
 }
 
 // Memory side (round 2; the skeleton alone -- tile in, tile out, no arithmetic -- ran at 2.9 TB/s with 8-byte loads and each lane
@@ -93,7 +107,7 @@ __device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, int K, 
 // next tile's loads in flight during the arithmetic) was built and measured slower -- at 64 taps / 1 the tile's LDS traffic
 // (237 KB: window reads, tile, transpose) and its multiply-adds each fill most of the time on their own, and fewer resident waves
 // hide less of it: profiles/r02_fir_generic_experiments.txt.
-template <typename T, int D, int R, bool FUSED>
+template <typename T, int D, int R, bool FUSED, int CHW>
 __global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ x, long n_in, const float *__restrict__ taps, int K,
                                                           T *__restrict__ y, long n_out, int vec_in, int vec_out)
 {
@@ -142,9 +156,7 @@ __global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ 
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = T{};
     const int base = tid * (LSTR + (PAD ? 1 : 0));
-    const int nfull = K / CH;
-    for (int c = 0; c < nfull; ++c) fir_chunk<T, D, R, FUSED, false>(xs, base, c * CH, K, taps, acc);
-    if (nfull * CH < K) fir_chunk<T, D, R, FUSED, true>(xs, base, nfull * CH, K, taps, acc);
+    fir_chunks<T, D, R, FUSED, CHW>(xs, base, K, taps, acc);
     const long o0 = (long)blockIdx.x * TILE_OUT;
     // outputs through LDS: element e of the tile sits at ys[(e / R) * (R + 1) + e % R]
     __syncthreads(); // every wave is done with the input tile
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ 
     }
 }
 
-template <typename T, int D, int R, bool FUSED>
+template <typename T, int D, int R, bool FUSED, int CHW = 16>
 static hipError_t launch_chunked(const T *x, long n_in, const float *taps, int K, T *y, long n_out, hipStream_t s)
 {
     constexpr int TILE_OUT = 256 * R, LSTR = R * D;
@@ -180,7 +192,7 @@ static hipError_t launch_chunked(const T *x, long n_in, const float *taps, int K
     if (elems < 256L * (R + 1)) elems = 256L * (R + 1); // the output transpose reuses the tile
     const size_t lds = (size_t)elems * sizeof(T);
     if (lds > 150 * 1024) return hipErrorNotSupported;
-    auto kern = fir_chunked_kernel<T, D, R, FUSED>;
+    auto kern = fir_chunked_kernel<T, D, R, FUSED, CHW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -238,9 +250,9 @@ static hipError_t launch_fir_t(const T *x, long n_in, const float *taps, int K, 
         case 2: e = launch_chunked<T, 2, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
         case 3: e = launch_chunked<T, 3, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
         case 4: e = launch_chunked<T, 4, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 5: e = launch_chunked<T, 5, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 5: e = launch_chunked<T, 5, 4, FUSED, 32>(x, n_in, taps, K, y, n_out, s); break; // 32-tap chunks: +7 % at this decimation
         case 8: e = launch_chunked<T, 8, 2, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 10: e = launch_chunked<T, 10, 2, FUSED>(x, n_in, taps, K, y, n_out, s); break;
+        case 10: e = launch_chunked<T, 10, 2, FUSED, 32>(x, n_in, taps, K, y, n_out, s); break; // +10 %
         default: break;
         }
         if (e != hipErrorNotSupported) return e;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE plan shape a few times (for rocprofv3 passes on a secondary kernel):
-    python3 tools/shape_probe.py fir K D [log2n] [launches]
+    python3 tools/shape_probe.py fir|firr|firx|firrx K D [log2n] [launches]
     python3 tools/shape_probe.py pfb M P [log2n] [launches]
     python3 tools/shape_probe.py fft N 0 [log2n] [launches]
 Prints the HIP-event mean per launch."""
@@ -13,9 +13,12 @@ kind, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 26)
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 x = R.synth_iq(1, 0, n)
-if kind == "fir":
-    plan = R.Fir(R.dsputils.lpf_corrected(a, 0.4 / b if b > 1 else 0.2), b, fused=True)
-    out = torch.empty(plan.nout(n), dtype=torch.complex64, device="cuda")
+if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference rounding (multiply and add rounded separately)
+    cplx = kind in ("fir", "firx")
+    if not cplx:
+        x = R.synth_f32(1, 0, n)
+    plan = R.Fir(R.dsputils.lpf_corrected(a, 0.4 / b if b > 1 else 0.2), b, complex_input=cplx, fused=kind in ("fir", "firr"))
+    out = torch.empty(plan.nout(n), dtype=x.dtype, device="cuda")
     run = lambda: plan(x, out=out)
 elif kind == "pfb":
     plan = R.Channelizer(R.dsputils.lpf_corrected(a * b, 0.45 / a), a, b)
