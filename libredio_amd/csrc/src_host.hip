@@ -6,6 +6,7 @@
 // outputs depend on one buffer image, so each refill epoch costs one compute launch.
 #include "../../include/redio.h"
 #include "redio_internal.h"
+#include "src_position.h"
 #include "src_internal.h"
 #include <math.h>
 #include <new>
@@ -112,12 +113,7 @@ struct redio_src {
     hipStream_t host_stream; // the host-buffer entry point's own stream: states on different threads do not serialise
 };
 
-static double fmod_one(double x)
-{
-    double res = x - (double)lrint(x);
-    if (res < 0.0) return res + 1.0;
-    return res;
-}
+static inline double fmod_one(double x) { return src_fmod_one(x); }
 static bool is_bad_src_ratio(double r) { return r < (1.0 / SRC_MAX_RATIO) || r > (1.0 * SRC_MAX_RATIO); }
 
 extern "C" int redio_src_reset(redio_src *s)
@@ -794,10 +790,7 @@ static int try_general_window(redio_src *f, const SrcInput &in, long in_count, f
             if (r != 1) return give_back(r);
             launched = out_gen;
         }
-        input_index += step;
-        rem = fmod_one(input_index);
-        b_current = wrap(b_current + (int)lrint(input_index - rem));
-        input_index = rem;
+        b_current = wrap(b_current + src_advance(input_index, step));
     }
     if (!probed && window_prefers_periodic(f, out_gen, inc)) return 0;
     {
@@ -908,10 +901,7 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
         f->h_scale[(size_t)out_gen] = scale;
         f->h_pos[(size_t)out_gen] = at;
         ++out_gen;
-        input_index += step;
-        rem = fmod_one(input_index);
-        f->b_current = wrap(f->b_current + (int)lrint(input_index - rem));
-        input_index = rem;
+        f->b_current = wrap(f->b_current + src_advance(input_index, step));
     }
     rc = flush_epoch(f, epoch_first, out_gen - epoch_first, d_out, out_stride, st);
     if (rc) return rc;

@@ -317,3 +317,22 @@ extern "C" void emu_stream_split(size_t hist, size_t W, size_t H, size_t n, size
     const redio::StreamSplit s = redio::stream_split(hist, W, H, n);
     out5[0] = s.nh; out5[1] = s.head_in; out5[2] = s.nb; out5[3] = s.off; out5[4] = s.body_in;
 }
+
+// the resampler's position recurrence: short form (libredio_amd/csrc/src_position.h) against the library's literal expression
+#include "../../libredio_amd/csrc/src_position.h"
+extern "C" long emu_src_advance_mismatches(const double *x, const double *step, long n, long chain)
+{
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        double a = x[i], b = x[i];
+        for (long k = 0; k < chain; ++k) { // follow both recurrences for `chain` outputs
+            const int adv_a = redio::src_advance(a, step[i]);
+            b += step[i];
+            const double rem = redio::src_fmod_one(b);
+            const int adv_b = (int)lrint(b - rem);
+            b = rem;
+            if (adv_a != adv_b || memcmp(&a, &b, sizeof(double)) != 0) { ++bad; break; }
+        }
+    }
+    return bad;
+}

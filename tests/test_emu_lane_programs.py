@@ -64,3 +64,30 @@ def test_fir_tile_program_real(emu, oracle):
             y = np.zeros(len(want) + 8, np.float32)
             assert emu.emu_fir_f32(x, len(x), taps, k, d, fused, y) == len(want)
             assert np.array_equal(bits(y[: len(want)]), bits(want))
+
+
+def test_resampler_position_recurrence_short_form(emu):
+    """src_position.h: for step < 1 (every upsampling ratio) the library's per-output recurrence (libsamplerate 0.1.8,
+    sinc_mono_vari_process; samplerate.rs:61 drives it) reduces to add / compare / subtract.  Same doubles, same advances
+    as the literal fmod_one form: random operands, the rounding edges around 0.5, 1 and 1.5, and long chains at the ratios
+    the resampler tests use."""
+    emu.emu_src_advance_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long]
+    emu.emu_src_advance_mismatches.restype = C.c_long
+    rng = np.random.default_rng(7)
+    eps = 2.0 ** -53
+    xs, steps = [], []
+    # random pairs over the whole range of ratios (1/256 .. 256)
+    xs += list(rng.random(200000)); steps += list(1.0 / rng.uniform(1.0 / 256, 256.0, 200000))
+    # edges: sums that land on or next to 0.5, 1.0, 1.5 and just below 2.0
+    for target in (0.5, 1.0, 1.5, 2.0 - 2 * eps):
+        for d in (-3, -2, -1, 0, 1, 2, 3):
+            for x in (0.0, 0.25, 0.5 - eps, 0.5, 0.75, 1.0 - eps, rng.random()):
+                st = target - x + d * eps
+                if 0.0 < st:
+                    xs.append(x); steps.append(st)
+    x = np.array(xs, dtype=np.float64); st = np.array(steps, dtype=np.float64)
+    assert emu.emu_src_advance_mismatches(x.ctypes.data, st.ctypes.data, len(x), 64) == 0
+    # long chains at real ratios
+    ratios = np.array([48000 / 44100, 2.0, 1.5, 4 / 3, 1.0884, 2 ** 0.5, 3.7, 256.0, 1.0, 0.3, 0.02, 0.0213], dtype=np.float64)
+    x0 = np.zeros(len(ratios))
+    assert emu.emu_src_advance_mismatches(x0.ctypes.data, (1.0 / ratios).ctypes.data, len(ratios), 2000000) == 0
