@@ -1681,6 +1681,7 @@ template <bool INV>
 __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
                                                             long ntiles, int lgN, const float2 *__restrict__ mulH = nullptr)
 {
+    __shared__ float2 Ls2[4 * 64 * 17];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = (long)blockIdx.x * 4 + w;
     if (tile >= ntiles) return;
@@ -1714,14 +1715,28 @@ __global__ __launch_bounds__(256) void fftbig_first2_kernel(const float2 *in, fl
     for (int k = 0; k < 8; k += 2)
         bfly4x2<INV>(a[0][k], a[1][k], a[2][k], a[3][k], tw[k * fs], tw[2 * k * fs], tw[3 * k * fs],
                      a[0][k + 1], a[1][k + 1], a[2][k + 1], a[3][k + 1], tw[(k + 1) * fs], tw[2 * (k + 1) * fs], tw[3 * (k + 1) * fs]);
-    // source column r = 64 c + lane is column h = digit reversal of r (nd digits) of the working array; 32 rows per column
-    unsigned h = 0;
-    for (int d = 0, rr = 64 * c + lane; d < nd; ++d, rr >>= 2) h = (h << 2) | (rr & 3);
-    float4 *o = reinterpret_cast<float4 *>(dst + 32l * h);
+    // source column r = 64 c + run is column h = digit reversal of r (nd digits) of the working array: 32 rows = one 256-byte run per
+    // column, and the runs of a wave's 64 columns lie far apart (their low digits become the high ones).  A lane storing its own run
+    // would put 64 separate 16-byte pieces into every store instruction; the results go through a wave-private LDS image instead
+    // (two rounds of 16 rows), and each instruction writes eight complete 128-byte half-runs (eight lanes each).
+    unsigned hc = 0;
+    for (int d = 0, cc = c; d < nd - 3; ++d, cc >>= 2) hc = (hc << 2) | (cc & 3);
+    float2 *Lw = Ls2 + w * (64 * 17);
 #pragma unroll
-    for (int d2 = 0; d2 < 4; ++d2)
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) o[(8 * d2 + j) / 2] = make_float4(a[d2][j].x, a[d2][j].y, a[d2][j + 1].x, a[d2][j + 1].y); // row b0 + 2 d1 + 8 d2
+        for (int k = 0; k < 16; ++k) Lw[lane * 17 + k] = a[2 * half + (k >> 3)][k & 7]; // row b0 + 2 d1 + 8 d2 = 16 half + k
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned run = 8u * i + (lane >> 3), f = lane & 7;
+            const unsigned rev = ((run & 3) << 4) | (run & 12) | (run >> 4); // the run's three digits reversed
+            const unsigned h = (rev << (2 * (nd - 3))) | hc;
+            const float2 v0 = Lw[run * 17 + 2 * f], v1 = Lw[run * 17 + 2 * f + 1];
+            reinterpret_cast<float4 *>(dst + 32l * h + 16 * half)[f] = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
+        wave_lds_fence();
+    }
 }
 
 // the passes after the gather pass: rows 2^lm apart, `left` radix-4 stages to go
