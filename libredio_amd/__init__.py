@@ -104,6 +104,7 @@ def lib():
         _sig(getattr(L, f"redio_{n}_stream_pending"), sz, vp)
         _sig(getattr(L, f"redio_{n}_stream_enqueue"), i, vp, vp, sz, vp, C.POINTER(sz), vp)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
+    _sig(L.redio_chain_enqueue_u8, i, vp, vp, sz, vp, vp)
     pl = C.POINTER(C.c_long)
     _sig(L.redio_graph_begin, i, vp)
     _sig(L.redio_graph_end, i, vp, C.POINTER(vp))

@@ -8,11 +8,13 @@ from . import check, lib
 from .plans import _dev_ptr, current_stream
 
 
-def data_to_samples(data):
+def data_to_samples(data, out=None):
     """uint8 CUDA tensor of IQ byte pairs -> complex64 (i as f32/127.0 - 1.0). Odd length raises."""
     import torch
     assert data.dtype == torch.uint8
-    out = torch.empty(data.numel() // 2, dtype=torch.complex64, device=data.device)
+    if out is None:
+        out = torch.empty(data.numel() // 2, dtype=torch.complex64, device=data.device)
+    assert out.dtype == torch.complex64 and out.numel() >= data.numel() // 2
     check(lib().redio_data_to_samples(_dev_ptr(data), data.numel(), _dev_ptr(out), current_stream()), "data_to_samples")
     return out
 

@@ -25,7 +25,10 @@ __device__ __forceinline__ void static_for4(F &&f)
 
 // FIR_ONLY: the same data movement and FIR, but the decimated samples are stored instead of transformed
 // (the stand-alone decimating FIR of redio_fir_* for this shape); `out` then holds 1024 outputs per block.
-template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false>
+// IN_U8: `x` is the receiver's own format, interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162: i as f32 / 127.0 - 1.0):
+// a lane's 16-byte load of two cf32 samples becomes a 4-byte load of the same two samples, converted on the way into the LDS image --
+// 2 + 1.6 bytes per sample through HBM instead of 8 + 8 + 1.6 for the conversion kernel followed by this one.
+template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false>
 __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
                                                            const float2 *__restrict__ tw, float2 *__restrict__ out,
                                                            long nblocks, long blocks_per_wave, unsigned long long *dbg)
@@ -52,20 +55,26 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     if (b0 >= nblocks) return;
     const long b1 = (b0 + blocks_per_wave < nblocks) ? b0 + blocks_per_wave : nblocks;
     const long nsub = 4 * (b1 - b0);                  // sub-tiles of this wave, consecutive in the stream
-    // float4 index of the first NEW sample of sub-tile j (the halo precedes it)
-    const v4f_t *src0 = reinterpret_cast<const v4f_t *>(x + b0 * 1024 * (long)D) + lane;
+    // index of the first NEW pair of samples of sub-tile j (the halo precedes it): a pair is one float4, or one u32 of I/Q bytes
+    using pair_t = typename std::conditional<IN_U8, unsigned, v4f_t>::type;
+    const pair_t *src0 = (IN_U8 ? reinterpret_cast<const pair_t *>(reinterpret_cast<const unsigned *>(x) + b0 * 512 * (long)D)
+                                : reinterpret_cast<const pair_t *>(x + b0 * 1024 * (long)D)) + lane;
+    auto samples = [](pair_t w) -> v4f_t {
+        if constexpr (IN_U8) return v4f_t{i2f(w & 255u), i2f((w >> 8) & 255u), i2f((w >> 16) & 255u), i2f(w >> 24)};
+        else return w;
+    };
 
-    v4f_t pre[NLD];
+    pair_t pre[NLD];
     auto fetch = [&](long j) { // new samples of sub-tile j: [HALO + j*SUB_NEW, HALO + (j+1)*SUB_NEW)
-        const v4f_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
+        const pair_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
         static_for4<NLD>([&](auto I) { pre[I.value] = src[64 * I.value]; });
     };
     auto park = [&]() {
-        static_for4<NLD>([&](auto I) { xs4[G::lds_index(HALO + 2 * (lane + 64 * I.value)) / 2] = pre[I.value]; });
+        static_for4<NLD>([&](auto I) { xs4[G::lds_index(HALO + 2 * (lane + 64 * I.value)) / 2] = samples(pre[I.value]); });
     };
 
     // prologue: the head (the only halo this wave ever fetches) and the first sub-tile
-    if (lane < HALO_V) xs4[G::lds_index(2 * lane) / 2] = src0[0];
+    if (lane < HALO_V) xs4[G::lds_index(2 * lane) / 2] = samples(src0[0]);
     fetch(0);
     park();
     wave_lds_fence();
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     }
 }
 
-template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false>
+template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false>
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg)
 {
@@ -146,8 +155,8 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     if (waves > nblocks) waves = nblocks;
     const long bpw = (nblocks + waves - 1) / waves;
     const long grid = (nblocks + bpw - 1) / bpw;
-    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
-    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
     return hipGetLastError();
 }
 
@@ -155,6 +164,12 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
                            hipStream_t s, unsigned long long *dbg)
 {
     return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg); // last-stage twiddles resident
+}
+
+// u8 I/Q bytes in (4-byte aligned), spectra out: data_to_samples -> 127-tap FIR / 5 -> 1024-point FFT in one kernel
+hipError_t launch_chain_v4_u8(const void *bytes, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, hipStream_t s)
+{
+    return launch_v4_t<127, 5, 2, 8, false, true, true>((const float2 *)bytes, taps, tw, out, nblocks, fused, s, nullptr);
 }
 
 // the same kernel for the other tap / decimation pairs with a fused build (K - D even, image within the per-wave LDS budget)

@@ -17,17 +17,6 @@
 
 namespace redio {
 
-// rtlsdr.rs:159: i as f32 / 127.0 - 1.0.  The IEEE quotient without the division sequence: q0 = b*r with
-// r = fl(1/127), one residual step e = b - 127*q0 (exact in an FMA), q = q0 + e*r.  This is the correctly
-// rounded b/127 for every byte b -- the domain has 256 points and tests/test_gpu_ingest.py checks all of
-// them against the oracle's plain division.
-__device__ __forceinline__ float i2f(unsigned b)
-{
-    const float fb = (float)b, r = 1.0f / 127.0f;
-    const float q0 = mul_rn(fb, r);
-    const float e = fma_rn(-q0, 127.0f, fb);
-    return sub_rn(fma_rn(e, r, q0), 1.0f);
-}
 __device__ __forceinline__ float norm_f32(float re, float im)
 {
     return (float)sqrt((double)re * (double)re + (double)im * (double)im);

@@ -479,6 +479,8 @@ struct redio_chain {
     float2 *d_mid; // intermediate for the two-kernel path (redio_chain_reserve)
     size_t mid_elems;
     unsigned long long *d_stamps; // diagnostic per-wave stamps of THIS plan's launches (redio_chain_set_debug_stamps), else null
+    float2 *d_conv; // converted samples for redio_chain_enqueue_u8 on shapes / pointers without the one-kernel form (grown on first use)
+    size_t conv_elems;
 };
 
 extern "C" int redio_chain_create(redio_chain **h, const float *taps, size_t ntaps, size_t decim, int nfft, unsigned flags)
@@ -502,6 +504,7 @@ extern "C" int redio_chain_destroy(redio_chain *h)
     redio_fir_destroy(h->fir);
     redio_fft_destroy(h->fft);
     if (h->d_mid) hipFree(h->d_mid);
+    if (h->d_conv) hipFree(h->d_conv);
     delete h;
     return REDIO_OK;
 }
@@ -567,6 +570,34 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     RD_TRY(launch_fir(d_in, (long)need_in, h->fir->d_taps, (int)h->fir->ntaps, (long)h->fir->decim, h->d_mid, (long)ny,
                       true, fused_math, (hipStream_t)stream));
     return redio_fft_enqueue(h->fft, h->d_mid, d_out, nblk, stream);
+}
+
+// rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> the chain, from the receiver's u8 I/Q bytes
+extern "C" int redio_chain_enqueue_u8(redio_chain *h, const void *d_bytes, size_t nbytes, void *d_out, void *stream)
+{
+    if (!h || (nbytes & 1)) return REDIO_ERR_ARG;
+    const size_t n_in = nbytes / 2;
+    const size_t nblk = redio_chain_nblocks(h, n_in);
+    if (nblk == 0) return REDIO_OK;
+    if (!d_bytes || !d_out || d_bytes == d_out) return REDIO_ERR_ARG;
+    RD_TRY(hipSetDevice(h->fir->device));
+    if (redio_chain_is_fused(h)) {
+        hipError_t e = launch_chain_u8(h->fft->dev, d_bytes, h->fir->d_taps, (int)h->fir->ntaps, (long)h->fir->decim, (float2 *)d_out, (long)nblk,
+                                       (h->fir->flags & REDIO_FIR_FUSED) != 0, (hipStream_t)stream);
+        if (e != hipErrorNotSupported) return hip_rc(e);
+    }
+    // other shapes, or bytes that are not 4-byte aligned: convert into a plan-owned buffer, then the cf32 entry point (same results)
+    if (n_in > h->conv_elems) {
+        if (stream_is_capturing((hipStream_t)stream)) return REDIO_ERR_NOT_RESERVED;
+        RD_TRY(hipStreamSynchronize((hipStream_t)stream)); // launches that still read the old buffer
+        if (h->d_conv) hipFree(h->d_conv);
+        h->d_conv = nullptr; h->conv_elems = 0;
+        RD_TRY(hipMalloc((void **)&h->d_conv, n_in * sizeof(float2)));
+        h->conv_elems = n_in;
+    }
+    int rc = redio_data_to_samples(d_bytes, nbytes, h->d_conv, stream);
+    if (rc) return rc;
+    return redio_chain_enqueue(h, h->d_conv, n_in, d_out, stream);
 }
 
 // shapes of the plans, for the carried-history layer (stream_carry.hip)

@@ -98,6 +98,20 @@ RD_HD float2 cmul_rn(float2 a, float2 b)
 RD_HD float2 cadd_rn(float2 a, float2 b) { return make_float2(add_rn(a.x, b.x), add_rn(a.y, b.y)); }
 RD_HD float2 csub_rn(float2 a, float2 b) { return make_float2(sub_rn(a.x, b.x), sub_rn(a.y, b.y)); }
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// rtlsdr.rs:159: i as f32 / 127.0 - 1.0.  The IEEE quotient without the division sequence: q0 = b*r with
+// r = fl(1/127), one residual step e = b - 127*q0 (exact in an FMA), q = q0 + e*r.  This is the correctly
+// rounded b/127 for every byte b -- the domain has 256 points and tests/test_gpu_ingest.py checks all of
+// them against the oracle's plain division.
+__device__ __forceinline__ float i2f(unsigned b)
+{
+    const float fb = (float)b, r = 1.0f / 127.0f;
+    const float q0 = mul_rn(fb, r);
+    const float e = fma_rn(-q0, 127.0f, fb);
+    return sub_rn(fma_rn(e, r, q0), 1.0f);
+}
+#endif
+
 // murmur3 fmix32-based synthetic input; identical on host and device by construction
 RD_HD uint32_t fmix32(uint32_t h)
 {

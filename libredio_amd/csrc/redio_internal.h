@@ -51,6 +51,8 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
 
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
+hipError_t launch_chain_u8(const FftPlanDev &p, const void *bytes, const float *taps, int K, long D, float2 *out, long nblocks, bool fused,
+                           hipStream_t s);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
                         float2 *out, long nblocks, bool fused, hipStream_t s, unsigned long long *dbg = nullptr);
 

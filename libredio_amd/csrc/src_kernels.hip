@@ -343,7 +343,6 @@ hipError_t launch_src_tile(const float *old_img, long old_stride, const float *i
     hipLaunchKernelGGL(kern, grid, dim3(2 * NT), lds_bytes, s, w, a_limit, coeffs, coeff_half_len, pos, start, increment, scale, out, out_stride, nout);
     return hipGetLastError();
 }
-constexpr int SRC_TILE_NT = 128;
 
 // The two wings of one output at zero phase: left = sum_t L[t]*x[t], right = sum_t R[t]*x[c-t], each a
 // strictly ordered double sum (far end first, multiply and add rounded separately) exactly as

@@ -134,6 +134,18 @@ class Chain:
         check(lib().redio_chain_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "chain_enqueue")
         return out
 
+    def from_bytes(self, raw, out=None):
+        """redio_chain_enqueue_u8: the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162)
+        straight into the chain; the spectra of bitfount.data_to_samples(raw) followed by this plan, bit for bit."""
+        import torch
+        assert raw.dtype == torch.uint8 and raw.numel() % 2 == 0
+        nb = self.nblocks(raw.numel() // 2)
+        if out is None:
+            out = torch.empty((nb, self.nfft), dtype=torch.complex64, device=raw.device)
+        assert out.numel() >= nb * self.nfft
+        check(lib().redio_chain_enqueue_u8(self._h, _dev_ptr(raw), raw.numel(), _dev_ptr(out), current_stream()), "chain_enqueue_u8")
+        return out
+
     def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_chain_destroy", self._h)

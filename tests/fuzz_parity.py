@@ -57,6 +57,12 @@ while time.time() < t_end:
         got = R.Chain(taps, dd, nfc, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.chain_fir_fft(x, taps, dd, nfc, fused=fused)
         check("chain", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, nfc, fused, nb, extra))
+        # the same plan from the receiver's u8 I/Q bytes (redio_chain_enqueue_u8), any byte alignment
+        off = int(rng.integers(0, 4))
+        raw = rng.integers(0, 256, 2 * n + off, dtype=np.uint8)
+        got = R.Chain(taps, dd, nfc, fused=fused).from_bytes(torch.from_numpy(raw).cuda()[off:]).cpu().numpy()
+        want = O.chain_fir_fft(O.data_to_samples(raw[off:]), taps, dd, nfc, fused=fused)
+        check("chain_u8", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, nfc, fused, nb, extra, off))
     elif which == 3:    # overlap-save
         nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 8192, 8192, 32768, 65536, 1000, int(rng.integers(2, 12000))]))
         k = int(rng.integers(1, nfft + 1)); hop = nfft - k + 1

@@ -127,3 +127,49 @@ def test_shipped_graph_front_end_end_to_end(gpu, redio, oracle):
     for b, r in zip(bufs, bufs_ref):
         assert np.array_equal(bits(b.cpu().numpy()), bits(r))
         assert np.array_equal(redio.bitfount.discretize(b).cpu().numpy(), oracle.discretize(r).astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("shape", [(127, 5, 1024), (63, 5, 1024), (127, 5, 256), (31, 2, 64)])
+def test_chain_from_u8_bytes(gpu, redio, oracle, shape, fused):
+    """redio_chain_enqueue_u8: rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> FIR (dsputils.rs:30-32) -> kissfft (kissfft.rs:20-29) from the
+    receiver's u8 I/Q bytes.  (127, 5, 1024) is one kernel (the conversion happens on the way into the LDS image); other shapes and
+    unaligned bytes convert first.  Same spectra as the oracle's data_to_samples followed by its chain, bit for bit: every byte value,
+    ragged lengths, one block, no block, misaligned bytes, wave-run boundaries."""
+    k, d, nfft = shape
+    taps = oracle.synth_f32(17, 0, k)
+    plan = redio.Chain(taps, d, nfft, fused=fused)
+    rng = np.random.default_rng(k + d + nfft)
+    for nblk, extra in ((0, 3), (1, 0), (3, d * nfft // 3), (70, d * nfft - 2), (1100, 5)):
+        nsamp = (nblk * nfft - 1) * d + k + extra if nblk else k - 1
+        raw = rng.integers(0, 256, 2 * nsamp + 4, dtype=np.uint8)
+        if len(raw) >= 256:
+            raw[:256] = np.arange(256, dtype=np.uint8)   # every byte value at least once
+        for off in (0, 2, 1):   # 4-byte aligned, sample-aligned only, odd address
+            view = raw[off: off + 2 * nsamp]
+            dv = gpu.from_numpy(raw).cuda()[off: off + 2 * nsamp]
+            got = plan.from_bytes(dv).cpu().numpy()
+            want = oracle.chain_fir_fft(oracle.data_to_samples(view), taps, d, nfft, fused=fused)
+            assert got.shape == want.shape == (nblk, nfft)
+            assert np.array_equal(bits(got), bits(want)), (shape, fused, nblk, extra, off)
+    with pytest.raises(Exception):
+        plan.from_bytes(gpu.zeros(7, dtype=gpu.uint8, device="cuda"))   # odd byte count: rtlsdr.rs:160 would index out of bounds
+
+
+@pytest.mark.gpu
+def test_chain_from_u8_bytes_full_size(gpu, redio):
+    """BASELINE.json configs[1] at 2^28 samples, from bytes: the one-kernel form gives the bits of the conversion kernel followed by
+    the cf32 chain (itself checked against the oracle above and in test_gpu_parity.py) on every block."""
+    import libredio_amd.bitfount as B
+    n = 1 << 28
+    taps = redio.dsputils.lpf_corrected(127, 0.08)
+    plan = redio.Chain(taps, 5, 1024, fused=True)
+    g = gpu.Generator(device="cuda"); g.manual_seed(5)
+    raw = gpu.randint(0, 256, (2 * n,), dtype=gpu.uint8, device="cuda", generator=g)
+    got = plan.from_bytes(raw)
+    x = B.data_to_samples(raw)
+    want = plan(x)
+    del x
+    assert got.shape == want.shape == (plan.nblocks(n), 1024)
+    assert gpu.equal(gpu.view_as_real(got).view(gpu.int32), gpu.view_as_real(want).view(gpu.int32))

@@ -172,6 +172,23 @@ if "firshapes" in which:
         b = (8 if cplx else 4) * (1 + 1 / d)
         fl = (4 if cplx else 2) * k / d
         print(f"FIR K={k} D={d} {'cf32' if cplx else 'f32'}: {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  {b*m/ms/1e6/8000:.1%} of HBM roofline, {fl*m/ms/1e9:.1f} TFLOP/s")
+if "u8chain" in which:
+    # the receiver's format in: u8 I/Q bytes -> data_to_samples -> 127-tap FIR / 5 -> 1024-point FFT, one kernel against two
+    from libredio_amd import bitfount as B
+    taps = R.dsputils.lpf_corrected(127, 0.08)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    raw = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    for fused in (True, False):
+        plan = R.Chain(taps, 5, 1024, fused=fused)
+        out = torch.empty((plan.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: plan.from_bytes(raw, out=out), n=100, warm=30)
+        conv = torch.empty(n, dtype=torch.complex64, device="cuda")
+        def two():
+            B.data_to_samples(raw, out=conv); plan(conv, out=out)
+        ms2 = timeit(two, n=50, warm=10)
+        b = 2 + 8 / 5
+        print(f"u8 I/Q bytes -> chain ({'fmaf' if fused else 'reference rounding'}), one kernel: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {b*n/ms/1e6:.0f} GB/s algorithmic "
+              f"({b*n/ms/1e6/8000:.1%} of 8 TB/s at 3.6 B/sample) | conversion kernel + cf32 chain: {ms2:.3f} ms  {n/ms2/1e6:.1f} GS/s")
 if "srcgen" in which:
     # the general (non-uniform phase) resampler path: arbitrary ratios, one launch per buffer refill
     import time
