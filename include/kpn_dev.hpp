@@ -166,6 +166,24 @@ inline void fir_fft_chain(Receiver<View<std::complex<float>>> u, Sender<View<std
     }
 }
 
+// the receiver's messages straight into the chain: u8 I/Q bytes (rtlsdr::rtlSource, rtlsdr.rs:127-152) -> data_to_samples
+// (rtlsdr.rs:159-162) -> FIR -> FFT as ONE kernel for the north-star shape (redio_chain_enqueue_u8)
+inline void bytes_fir_fft_chain(Receiver<View<uint8_t>> u, Sender<View<std::complex<float>>> v, std::vector<float> taps, size_t decim, int nfft,
+                                bool fused)
+{
+    BlockStream st;
+    redio_chain *h = nullptr;
+    check(redio_chain_create(&h, taps.data(), taps.size(), decim, nfft, fused ? REDIO_FIR_FUSED : 0));
+    struct G { redio_chain *h; ~G() { redio_chain_destroy(h); } } g{h};
+    for (;;) {
+        auto d = u.recv();
+        auto o = make<std::complex<float>>(redio_chain_nblocks(h, d.len / 2) * (size_t)nfft);
+        check(redio_chain_enqueue_u8(h, d.data(), d.len, o.data(), st));
+        check(redio_stream_sync(st));
+        v.send_unwrap(std::move(o));
+    }
+}
+
 // the front end of the shipped graph: u8 IQ bytes -> |x| (rtlsdr.rs:159-162 + ratpak.rs:64-68)
 inline void ingest_mag(Receiver<View<uint8_t>> u, Sender<View<float>> v)
 {

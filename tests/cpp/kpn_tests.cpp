@@ -544,6 +544,31 @@ static int dev_stream_graph(const char *in, const char *out_chain, const char *o
     return 0;
 }
 
+// the receiver's byte messages (rtlsdr::rtlSource sends Vec<u8>, rtlsdr.rs:127-152) through the one-kernel bytes -> spectra block
+static int dev_bytes_chain(const char *in, const char *out, size_t msg_bytes)
+{
+    using cf = std::complex<float>;
+    auto raw = read_bin<uint8_t>(in);
+    const std::vector<float> taps = dsputils::lpf_corrected(127, 0.08f);
+    auto [s0, r0] = channel<std::vector<uint8_t>>();
+    auto [s1, r1] = channel<dev::View<uint8_t>>();
+    auto [s2, r2] = channel<dev::View<cf>>();
+    auto [s3, r3] = channel<std::vector<cf>>();
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s0), &raw, msg_bytes]() mutable {
+        for (size_t o = 0; o < raw.size(); o += msg_bytes)
+            s.send(std::vector<uint8_t>(raw.begin() + (long)o, raw.begin() + (long)std::min(raw.size(), o + msg_bytes)));
+    }));
+    th.push_back(spawn([r = std::move(r0), s = std::move(s1)]() mutable { dev::to_device<uint8_t>(std::move(r), std::move(s)); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::bytes_fir_fft_chain(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    th.push_back(spawn([r = std::move(r2), s = std::move(s3)]() mutable { dev::to_host<cf>(std::move(r), std::move(s)); }));
+    std::vector<cf> a;
+    while (auto v = r3.try_recv_blocking()) a.insert(a.end(), v->begin(), v->end());
+    for (auto &t : th) t.join();
+    write_bin(out, a);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -553,6 +578,7 @@ int main(int argc, char **argv)
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
         if (mode == "devchain" && argc == 6) return dev_chain_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
         if (mode == "devstream" && argc == 7) return dev_stream_graph(argv[2], argv[3], argv[4], argv[5], (size_t)std::atol(argv[6]));
+        if (mode == "devbytes" && argc == 5) return dev_bytes_chain(argv[2], argv[3], (size_t)std::atol(argv[4]));
         if (mode == "devc4" && argc == 5) return dev_c4_sharded(argv[2], argv[3], std::atoi(argv[4]));
         if (mode == "devshaper" && argc == 6) return dev_shaper_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]));
         if (mode == "devmix" && argc == 6) return dev_mix_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), std::atof(argv[5]));

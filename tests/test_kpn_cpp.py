@@ -130,6 +130,23 @@ def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tm
 
 
 @pytest.mark.gpu
+def test_byte_messages_through_the_one_kernel_chain_block(exe, gpu, oracle, tmp_path):
+    """dev::bytes_fir_fft_chain in a C++ kpn graph: the receiver's Vec<u8> messages (rtlsdr.rs:127-152) -> device -> data_to_samples +
+    FIR + FFT in one kernel per message -> host.  Per message the spectra of the oracle's data_to_samples (rtlsdr.rs:159-162) and
+    chain on that message (stateless blocks: the reference's own message semantics)."""
+    msg = 2 * (5 * 1024 * 6 + 122 + 777)           # six blocks and a ragged tail per message
+    raw = np.random.default_rng(3).integers(0, 256, 3 * msg + 2 * (5 * 1024 + 122), dtype=np.uint8)
+    raw.tofile(tmp_path / "raw.bin")
+    out = subprocess.run([exe, "devbytes", str(tmp_path / "raw.bin"), str(tmp_path / "spec.bin"), str(msg)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    taps = oracle.lpf_corrected(127, 0.08)
+    want = np.concatenate([oracle.chain_fir_fft(oracle.data_to_samples(raw[o:o + msg]), taps, 5, 1024, True).reshape(-1)
+                           for o in range(0, len(raw), msg)])
+    got = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.gpu
 def test_sharded_channelizer_from_one_cpp_process(exe, gpu, oracle, tmp_path):
     """BASELINE.json configs[3] with no Python in the loop: one C++ process, one channelizer thread per visible GPU, the
     regrouping through redio_comm_init_all / redio_pfb_exchange_all (RCCL) -- the reference's thread-per-block host model
