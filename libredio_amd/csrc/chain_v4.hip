@@ -169,7 +169,7 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
 // u8 I/Q bytes in (4-byte aligned), spectra out: data_to_samples -> 127-tap FIR / 5 -> 1024-point FFT in one kernel
 hipError_t launch_chain_v4_u8(const void *bytes, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, hipStream_t s)
 {
-    return launch_v4_t<127, 5, 2, 8, false, true, true>((const float2 *)bytes, taps, tw, out, nblocks, fused, s, nullptr);
+    return launch_v4_t<127, 5, 2, 8, false, true, true>((const float2 *)bytes, taps, tw, out, nblocks, fused, s, nullptr); // 3 waves per SIMD: 0.52 against 0.46 ms
 }
 
 // the same kernel for the other tap / decimation pairs with a fused build (K - D even, image within the per-wave LDS budget)
