@@ -217,6 +217,10 @@ int redio_pfb_create(redio_pfb **h, const float *proto_taps_host, int nchan, int
 int redio_pfb_destroy(redio_pfb *h);
 size_t redio_pfb_nrows(const redio_pfb *h, size_t n_in);
 int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, int ngroups, void *stream);
+/* the same from the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, src/rtlsdr/src/rtlsdr.rs:159-162), nbytes / 2 samples,
+ * bit for bit the rows of redio_data_to_samples + redio_pfb_enqueue: one kernel for 64 channels x 16 taps per branch (10 instead of
+ * 26 bytes per sample through HBM), other shapes convert into a plan-owned buffer first (grown on first use). */
+int redio_pfb_enqueue_u8(redio_pfb *h, const void *d_bytes, size_t nbytes, void *d_out, int ngroups, void *stream);
 /* scratch of the two-pass shapes for inputs of up to n_in samples (the fused 64-channel kernel needs none) */
 int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups);
 

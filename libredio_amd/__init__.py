@@ -146,6 +146,7 @@ def lib():
     _sig(L.redio_pfb_destroy, i, vp)
     _sig(L.redio_pfb_nrows, sz, vp, sz)
     _sig(L.redio_pfb_enqueue, i, vp, vp, sz, vp, i, vp)
+    _sig(L.redio_pfb_enqueue_u8, i, vp, vp, sz, vp, i, vp)
     _sig(L.redio_comm_unique_id, i, vp)
     _sig(L.redio_comm_init_rank, i, C.POINTER(vp), i, i, vp)
     _sig(L.redio_comm_init_all, i, C.POINTER(vp), i, C.POINTER(i))

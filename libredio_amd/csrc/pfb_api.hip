@@ -8,6 +8,8 @@
 
 namespace redio {
 bool pfb_supported(int nchan, int taps_per_branch);
+hipError_t launch_pfb_u8(const void *bytes, const float *h, const float2 *tw64, float2 *out, long rows, int taps_per_branch, int ngroups, bool fused,
+                         hipStream_t s);
 hipError_t launch_pfb(const float2 *x, const float *h, const float2 *tw64, float2 *out, long rows, int taps_per_branch,
                       int ngroups, bool fused, hipStream_t s);
 
@@ -81,6 +83,8 @@ struct redio_pfb {
     bool fused_kernel;       // the 64-channel kernel of pfb_kernels.hip
     float2 *d_v, *d_w;       // generic shapes: branch outputs / transform outputs before regrouping (grown on first use)
     size_t v_elems, w_elems;
+    float2 *d_conv;          // redio_pfb_enqueue_u8 on shapes without the one-kernel form: the converted samples (grown on first use)
+    size_t conv_elems;
 };
 
 extern "C" int redio_pfb_create(redio_pfb **h, const float *proto, int nchan, int taps_per_branch, unsigned flags)
@@ -93,7 +97,7 @@ extern "C" int redio_pfb_create(redio_pfb **h, const float *proto, int nchan, in
     redio_pfb *p = new (std::nothrow) redio_pfb();
     if (!p) return REDIO_ERR_NOMEM;
     p->device = dev; p->nchan = nchan; p->taps_per_branch = taps_per_branch; p->flags = flags; p->d_h = nullptr; p->d_tw = nullptr;
-    p->fft = nullptr; p->d_v = p->d_w = nullptr; p->v_elems = p->w_elems = 0;
+    p->fft = nullptr; p->d_v = p->d_w = nullptr; p->v_elems = p->w_elems = 0; p->d_conv = nullptr; p->conv_elems = 0;
     p->fused_kernel = pfb_supported(nchan, taps_per_branch);
     const size_t nt = (size_t)nchan * taps_per_branch;
     std::vector<float2> tw((size_t)nchan);
@@ -122,6 +126,7 @@ extern "C" int redio_pfb_destroy(redio_pfb *h)
     hipFree(h->d_tw);
     hipFree(h->d_v);
     hipFree(h->d_w);
+    hipFree(h->d_conv);
     redio_fft_destroy(h->fft);
     delete h;
     return REDIO_OK;
@@ -199,4 +204,35 @@ extern "C" int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, vo
                    (h->flags & REDIO_FIR_FUSED) != 0, (hipStream_t)stream);
     if (e == hipErrorNotSupported) return REDIO_ERR_UNSUPPORTED;
     return hip_rc(e);
+}
+
+// rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> the channelizer, from the receiver's u8 I/Q bytes
+extern "C" int redio_pfb_enqueue_u8(redio_pfb *h, const void *d_bytes, size_t nbytes, void *d_out, int ngroups, void *stream)
+{
+    if (!h || (nbytes & 1)) return REDIO_ERR_ARG;
+    const size_t n_in = nbytes / 2;
+    const size_t rows = redio_pfb_nrows(h, n_in);
+    if (rows == 0) return REDIO_OK;
+    if (!d_bytes || !d_out || d_bytes == d_out) return REDIO_ERR_ARG;
+    if (ngroups < 1 || h->nchan % ngroups) return REDIO_ERR_ARG;
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_rc(e);
+    if (h->fused_kernel) {
+        e = launch_pfb_u8(d_bytes, h->d_h, h->d_tw, (float2 *)d_out, (long)rows, h->taps_per_branch, ngroups, (h->flags & REDIO_FIR_FUSED) != 0,
+                          (hipStream_t)stream);
+        if (e != hipErrorNotSupported) return hip_rc(e);
+    }
+    if (n_in > h->conv_elems) { // other shapes: convert first (grown on first use, never inside a capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return REDIO_ERR_NOT_RESERVED;
+        e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return hip_rc(e);
+        hipFree(h->d_conv); h->d_conv = nullptr; h->conv_elems = 0;
+        e = hipMalloc((void **)&h->d_conv, n_in * sizeof(float2));
+        if (e != hipSuccess) return hip_rc(e);
+        h->conv_elems = n_in;
+    }
+    const int rc = redio_data_to_samples(d_bytes, nbytes, h->d_conv, stream);
+    if (rc) return rc;
+    return redio_pfb_enqueue(h, h->d_conv, n_in, d_out, ngroups, stream);
 }

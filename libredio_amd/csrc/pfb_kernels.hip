@@ -7,12 +7,16 @@
 // (512 contiguous bytes per wave instruction), and prefetches the next tile's rows while it computes.
 #include "fft_wave.h"
 #include "pfb_core.h"
+#include <type_traits>
 #include "redio_internal.h"
 
 namespace redio {
 
 // ROWMAJOR: the plain [row][64] output (ngroups == 1) with 32-byte stores and no index division.
-template <int P, bool FUSED, bool ROWMAJOR>
+// IN_U8: `x` is the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162); a lane's 8-byte sample load
+// becomes a 2-byte load, converted when the sample enters the register window: 2 + 8 bytes per sample through HBM instead of 8 + 8
+// (+ 2 + 8 for a conversion kernel in front).
+template <int P, bool FUSED, bool ROWMAJOR, bool IN_U8 = false>
 __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x, const float *__restrict__ h,
                                                     const float2 *__restrict__ tw, float2 *__restrict__ out, long rows,
                                                     long rows_per_wave, int ngroups)
@@ -31,9 +35,15 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     for (int p = 0; p < P; ++p) g[p] = h[PFB_M * p + lane];
     // row r of the input = (x + 64 r)[lane]: wave-uniform row pointer + one 32-bit lane offset per load; rows past the
     // end of the stream (only the last tiles of the last wave ever ask for them) are clamped on a separate path
-    auto load_rows = [&](float2(&dst)[PFB_TILE], long first) {
+    using raw_t = typename std::conditional<IN_U8, unsigned short, float2>::type; // one sample as it lies in memory
+    const raw_t *xraw = reinterpret_cast<const raw_t *>(x);
+    auto sample = [](raw_t w) -> float2 {
+        if constexpr (IN_U8) return make_float2(i2f(w & 255u), i2f((unsigned)w >> 8));
+        else return w;
+    };
+    auto load_rows = [&](raw_t(&dst)[PFB_TILE], long first) {
         if (first + PFB_TILE - 1 <= last_in_row) {
-            const float2 *xr = x + PFB_M * first;
+            const raw_t *xr = xraw + PFB_M * first;
 #pragma unroll
             for (int ti = 0; ti < PFB_TILE; ++ti) dst[ti] = (xr + PFB_M * ti)[(unsigned)lane];
         } else {
@@ -41,21 +51,21 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
             for (int ti = 0; ti < PFB_TILE; ++ti) {
                 long r = first + ti;
                 r = r < last_in_row ? r : last_in_row;
-                dst[ti] = (x + PFB_M * r)[(unsigned)lane];
+                dst[ti] = (xraw + PFB_M * r)[(unsigned)lane];
             }
         }
     };
     float2 win[P];
 #pragma unroll
-    for (int p = 0; p < P - 1; ++p) win[p] = (x + PFB_M * (t0 + p))[(unsigned)lane];
-    float2 cur[PFB_TILE], nx[PFB_TILE];
+    for (int p = 0; p < P - 1; ++p) win[p] = sample((xraw + PFB_M * (t0 + p))[(unsigned)lane]);
+    raw_t cur[PFB_TILE], nx[PFB_TILE];
     load_rows(cur, t0 + P - 1);
     for (long tb = t0; tb < t1; tb += PFB_TILE) {
         if (tb + PFB_TILE < t1) load_rows(nx, tb + PFB_TILE + P - 1);
         // branch FIRs: lane = branch, strict fold over p (dsputils.rs:31)
 #pragma unroll
         for (int ti = 0; ti < PFB_TILE; ++ti) {
-            win[(ti + P - 1) % P] = cur[ti];
+            win[(ti + P - 1) % P] = sample(cur[ti]);
             float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
             for (int p = 0; p < P; ++p) acc = mac<FUSED>(win[(ti + p) % P], g[p], acc);
@@ -109,7 +119,7 @@ bool pfb_supported(int nchan, int taps_per_branch)
     return nchan == PFB_M && (taps_per_branch == 4 || taps_per_branch == 8 || taps_per_branch == 16);
 }
 
-template <int P>
+template <int P, bool IN_U8 = false>
 static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw, float2 *out, long rows, int ngroups,
                                bool fused, hipStream_t s)
 {
@@ -122,11 +132,11 @@ static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw
     const unsigned grid = (unsigned)((nwaves + 3) / 4);
     const size_t lds = 4 * PFB_LDS * sizeof(float2);
     if (ngroups == 1) {
-        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, true>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
-        else hipLaunchKernelGGL((pfb64_kernel<P, false, true>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, true, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        else hipLaunchKernelGGL((pfb64_kernel<P, false, true, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
     } else {
-        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, false>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
-        else hipLaunchKernelGGL((pfb64_kernel<P, false, false>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, false, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        else hipLaunchKernelGGL((pfb64_kernel<P, false, false, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
     }
     return hipGetLastError();
 }
@@ -141,6 +151,15 @@ hipError_t launch_pfb(const float2 *x, const float *h, const float2 *tw64, float
     case 4: return launch_pfb_t<4>(x, h, tw64, out, rows, ngroups, fused, s);
     default: return hipErrorNotSupported;
     }
+}
+
+// the same kernel reading u8 I/Q bytes (2-byte aligned; 16 taps per branch, the BASELINE shape, only)
+hipError_t launch_pfb_u8(const void *bytes, const float *h, const float2 *tw64, float2 *out, long rows, int taps_per_branch, int ngroups, bool fused,
+                         hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    if (taps_per_branch != 16 || (reinterpret_cast<uintptr_t>(bytes) & 1)) return hipErrorNotSupported;
+    return launch_pfb_t<16, true>((const float2 *)bytes, h, tw64, out, rows, ngroups, fused, s);
 }
 
 } // namespace redio

@@ -331,6 +331,18 @@ class Channelizer:
         check(lib().redio_pfb_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), int(ngroups), current_stream()), "pfb_enqueue")
         return out
 
+    def from_bytes(self, raw, ngroups=1, out=None):
+        """redio_pfb_enqueue_u8: the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162) straight
+        into the channelizer; the rows of bitfount.data_to_samples(raw) followed by this plan, bit for bit."""
+        import torch
+        assert raw.dtype == torch.uint8 and raw.numel() % 2 == 0
+        rows = self.nrows(raw.numel() // 2)
+        if out is None:
+            shape = (rows, self.nchan) if ngroups == 1 else (ngroups, rows, self.nchan // ngroups)
+            out = torch.empty(shape, dtype=torch.complex64, device=raw.device)
+        check(lib().redio_pfb_enqueue_u8(self._h, _dev_ptr(raw), raw.numel(), _dev_ptr(out), int(ngroups), current_stream()), "pfb_enqueue_u8")
+        return out
+
     def __del__(self, _safe_destroy=_safe_destroy):  # bound at definition: module globals may be gone at shutdown
         if getattr(self, "_h", None):
             _safe_destroy("redio_pfb_destroy", self._h)

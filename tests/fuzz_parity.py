@@ -80,6 +80,11 @@ while time.time() < t_end:
         got = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.pfb_channelizer(x, h, M, P, fused)
         check("pfb", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows))
+        off = int(rng.integers(0, 4))   # the same plan from u8 I/Q bytes (redio_pfb_enqueue_u8), any byte alignment
+        raw = rng.integers(0, 256, 2 * len(x) + off, dtype=np.uint8)
+        got = R.Channelizer(h, M, P, fused=fused).from_bytes(torch.from_numpy(raw).cuda()[off:]).cpu().numpy()
+        want = O.pfb_channelizer(O.data_to_samples(raw[off:]), h, M, P, fused)
+        check("pfb_u8", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows, off))
     elif which == 6:    # ingest: bytes -> samples -> |x| -> block sums -> slicer, any length / offset
         from libredio_amd import bitfount as B
         n = int(rng.integers(1, 60000)); off = 8 * int(rng.integers(0, 3))

@@ -184,3 +184,49 @@ def test_exchange_messages_above_one_gibibyte(gpu, redio):
         gpu.cuda.synchronize()
         assert gpu.equal(out, g[0]), rows
         del g, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("M,P", [(64, 16), (64, 8), (32, 4), (100, 5)])
+def test_channelizer_from_u8_bytes(gpu, redio, oracle, M, P, fused):
+    """redio_pfb_enqueue_u8: rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> polyphase branches -> M-point kissfft per row from the
+    receiver's bytes.  64 x 16 is one kernel (the conversion happens where a sample enters the register window); other shapes and
+    odd addresses convert first.  The oracle's rows, bit for bit: ragged lengths, no row, grouped layouts, every byte value."""
+    h = oracle.synth_f32(5, 0, M * P)
+    plan = redio.Channelizer(h, M, P, fused=fused)
+    rng = np.random.default_rng(M + P)
+    for rows, extra in ((0, 5), (1, 0), (17, 3), (400, M - 1), (5000, 1)):
+        nsamp = M * (rows + P - 1) + extra if rows else M * (P - 1) + extra
+        raw = rng.integers(0, 256, 2 * nsamp + 2, dtype=np.uint8)
+        if len(raw) >= 256:
+            raw[:256] = np.arange(256, dtype=np.uint8)
+        for off in (0, 2, 1):
+            view = raw[off: off + 2 * nsamp]
+            dv = gpu.from_numpy(raw).cuda()[off: off + 2 * nsamp]
+            want = oracle.pfb_channelizer(oracle.data_to_samples(view), h, M, P, fused)
+            got = plan.from_bytes(dv).cpu().numpy().reshape(-1, M)
+            assert got.shape == np.asarray(want).reshape(-1, M).shape
+            assert np.array_equal(bits(got), bits(np.asarray(want).reshape(-1, M))), (M, P, fused, rows, extra, off)
+        if rows and M % 4 == 0:
+            g = plan.from_bytes(gpu.from_numpy(raw).cuda()[: 2 * nsamp], ngroups=4).cpu().numpy().reshape(4, -1, M // 4)
+            want = np.asarray(oracle.pfb_channelizer(oracle.data_to_samples(raw[: 2 * nsamp]), h, M, P, fused)).reshape(-1, M)
+            for q in range(4):
+                assert np.array_equal(bits(g[q]), bits(np.ascontiguousarray(want[:, q * (M // 4):(q + 1) * (M // 4)])))
+
+
+@pytest.mark.gpu
+def test_channelizer_from_u8_bytes_full_size(gpu, redio):
+    """BASELINE.json configs[3]'s per-GPU slice (2^28 samples) from bytes: the one-kernel form against the conversion kernel followed
+    by the cf32 channelizer, every row."""
+    import libredio_amd.bitfount as B
+    n = 1 << 28
+    plan = redio.Channelizer(redio.dsputils.lpf_corrected(1024, 0.45 / 64))
+    g = gpu.Generator(device="cuda"); g.manual_seed(6)
+    raw = gpu.randint(0, 256, (2 * n,), dtype=gpu.uint8, device="cuda", generator=g)
+    got = plan.from_bytes(raw)
+    x = B.data_to_samples(raw)
+    want = plan(x)
+    del x
+    assert got.shape == want.shape
+    assert gpu.equal(gpu.view_as_real(got).view(gpu.int32), gpu.view_as_real(want).view(gpu.int32))

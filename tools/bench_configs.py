@@ -189,6 +189,20 @@ if "u8chain" in which:
         b = 2 + 8 / 5
         print(f"u8 I/Q bytes -> chain ({'fmaf' if fused else 'reference rounding'}), one kernel: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {b*n/ms/1e6:.0f} GB/s algorithmic "
               f"({b*n/ms/1e6/8000:.1%} of 8 TB/s at 3.6 B/sample) | conversion kernel + cf32 chain: {ms2:.3f} ms  {n/ms2/1e6:.1f} GS/s")
+if "u8c4" in which:
+    # the channelizer from the receiver's bytes: one kernel against the conversion kernel + the cf32 channelizer
+    from libredio_amd import bitfount as B
+    plan = R.Channelizer(R.dsputils.lpf_corrected(1024, 0.45 / 64))
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    raw = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.empty((plan.nrows(n), 64), dtype=torch.complex64, device="cuda")
+    ms = timeit(lambda: plan.from_bytes(raw, out=out), n=50, warm=20)
+    conv = torch.empty(n, dtype=torch.complex64, device="cuda")
+    def two():
+        B.data_to_samples(raw, out=conv); plan(conv, out=out)
+    ms2 = timeit(two, n=30, warm=10)
+    print(f"u8 I/Q bytes -> C4 channelizer 64ch P=16, one kernel: {ms:.3f} ms  {n/ms/1e6:.1f} GS/s  {10*n/ms/1e6:.0f} GB/s algorithmic ({10*n/ms/1e6/8000:.1%} of 8 TB/s at 10 B/sample)"
+          f" | conversion kernel + cf32 channelizer: {ms2:.3f} ms  {n/ms2/1e6:.1f} GS/s")
 if "srcgen" in which:
     # the general (non-uniform phase) resampler path: arbitrary ratios, one launch per buffer refill
     import time
