@@ -280,6 +280,11 @@ size_t redio_chain_stream_pending(const redio_chain_stream *h);
 int redio_chain_stream_enqueue(redio_chain_stream *h, const void *d_new, size_t n_new, void *d_out, size_t *nout, void *stream);
 typedef struct redio_pfb_stream redio_pfb_stream;
 int redio_pfb_stream_create(redio_pfb_stream **h, redio_pfb *plan);
+/* the chain / channelizer streams fed with the receiver's interleaved u8 I/Q bytes (rtlsdr.rs:127-162): d_new points to bytes,
+ * n_new still counts SAMPLES (2 bytes each); the history is carried as bytes and every window runs redio_*_enqueue_u8.
+ * All other redio_{chain,pfb}_stream_* calls apply unchanged. */
+int redio_chain_stream_create_u8(redio_chain_stream **h, redio_chain *plan);
+int redio_pfb_stream_create_u8(redio_pfb_stream **h, redio_pfb *plan);
 int redio_pfb_stream_destroy(redio_pfb_stream *h);
 int redio_pfb_stream_reset(redio_pfb_stream *h);
 size_t redio_pfb_stream_nout(const redio_pfb_stream *h, size_t n_new);

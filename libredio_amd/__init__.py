@@ -103,6 +103,8 @@ def lib():
         _sig(getattr(L, f"redio_{n}_stream_nout"), sz, vp, sz)
         _sig(getattr(L, f"redio_{n}_stream_pending"), sz, vp)
         _sig(getattr(L, f"redio_{n}_stream_enqueue"), i, vp, vp, sz, vp, C.POINTER(sz), vp)
+    for n in ("chain", "pfb"):
+        _sig(getattr(L, f"redio_{n}_stream_create_u8"), i, C.POINTER(vp), vp)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
     _sig(L.redio_chain_enqueue_u8, i, vp, vp, sz, vp, vp)
     pl = C.POINTER(C.c_long)

@@ -26,7 +26,7 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : RED
 #define SC_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_rc(_e); } while (0)
 
 namespace {
-enum Kind { K_FIR, K_CHAIN, K_PFB, K_OVSAVE };
+enum Kind { K_FIR, K_CHAIN, K_PFB, K_OVSAVE, K_CHAIN_U8, K_PFB_U8 }; // _U8: the samples are interleaved u8 I/Q byte pairs
 struct Carry {
     int device = 0;
     Kind kind = K_FIR;
@@ -52,6 +52,8 @@ int run(const Carry &c, const void *d_in, size_t n_in, void *d_out, void *stream
     case K_CHAIN: return redio_chain_enqueue((redio_chain *)c.plan, d_in, n_in, d_out, stream);
     case K_PFB: return redio_pfb_enqueue((redio_pfb *)c.plan, d_in, n_in, d_out, 1, stream);
     case K_OVSAVE: return redio_ovsave_enqueue((redio_ovsave *)c.plan, d_in, n_in, d_out, stream);
+    case K_CHAIN_U8: return redio_chain_enqueue_u8((redio_chain *)c.plan, d_in, 2 * n_in, d_out, stream);
+    case K_PFB_U8: return redio_pfb_enqueue_u8((redio_pfb *)c.plan, d_in, 2 * n_in, d_out, 1, stream);
     }
     return REDIO_ERR_ARG;
 }
@@ -203,6 +205,26 @@ extern "C" int redio_chain_stream_create(redio_chain_stream **h, redio_chain *pl
     redio_chain_shape(plan, &K, &D, &nfft, &dev);
     // the two-kernel path of the plan (unfused shapes, odd sample offsets) sizes its intermediate on first use
     return make(h, K_CHAIN, plan, dev, ((size_t)nfft - 1) * D + K, (size_t)nfft * D, 8, (size_t)nfft, 8);
+}
+// the same streams fed with the receiver's u8 I/Q bytes (2 bytes per sample; n_new still counts SAMPLES): the history is carried
+// as bytes, and every window runs redio_chain_enqueue_u8 / redio_pfb_enqueue_u8
+extern "C" int redio_chain_stream_create_u8(redio_chain_stream **h, redio_chain *plan)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    if (!plan) return REDIO_ERR_ARG;
+    size_t K, D; int nfft, dev;
+    redio_chain_shape(plan, &K, &D, &nfft, &dev);
+    return make(h, K_CHAIN_U8, plan, dev, ((size_t)nfft - 1) * D + K, (size_t)nfft * D, 2, (size_t)nfft, 8);
+}
+extern "C" int redio_pfb_stream_create_u8(redio_pfb_stream **h, redio_pfb *plan)
+{
+    if (!h) return REDIO_ERR_ARG;
+    *h = nullptr;
+    if (!plan) return REDIO_ERR_ARG;
+    int M, P, dev;
+    redio_pfb_shape(plan, &M, &P, &dev);
+    return make(h, K_PFB_U8, plan, dev, (size_t)M * P, (size_t)M, 2, (size_t)M, 8);
 }
 extern "C" int redio_pfb_stream_create(redio_pfb_stream **h, redio_pfb *plan)
 {

@@ -157,11 +157,14 @@ class Stream:
     segmentation of the input gives the bits of one stateless call on the whole stream (the stateless plans keep the
     reference's per-message semantics, dsputils.rs:30-32).  `plan` is a Fir, Chain, Channelizer or OverlapSave."""
 
-    def __init__(self, plan):
+    def __init__(self, plan, u8=False):
+        """u8=True (Chain and Channelizer): the stream arrives as the receiver's interleaved u8 I/Q bytes (uint8 tensors, two
+        bytes per sample; redio_{chain,pfb}_stream_create_u8)."""
         kind = {Fir: "fir", Chain: "chain"}.get(type(plan)) or {"Channelizer": "pfb", "OverlapSave": "ovsave"}[type(plan).__name__]
-        self._kind, self._plan = kind, plan          # the plan must outlive the stream handle
+        assert not u8 or kind in ("chain", "pfb")
+        self._kind, self._plan, self._u8 = kind, plan, bool(u8)          # the plan must outlive the stream handle
         self._h = C.c_void_p()
-        check(getattr(lib(), f"redio_{kind}_stream_create")(C.byref(self._h), plan._h), f"{kind}_stream_create")
+        check(getattr(lib(), f"redio_{kind}_stream_create" + ("_u8" if u8 else ""))(C.byref(self._h), plan._h), f"{kind}_stream_create")
 
     def _f(self, name):
         return getattr(lib(), f"redio_{self._kind}_stream_{name}")
@@ -182,13 +185,18 @@ class Stream:
         import torch
         real = self._kind == "fir" and not self._plan.complex_input
         want = torch.float32 if real else torch.complex64
-        assert x.dtype == want, f"expected {want}"
-        n = self.nout(x.numel())
+        if self._u8:
+            assert x.dtype == torch.uint8 and x.numel() % 2 == 0, "expected an even number of uint8 bytes"
+            nsamp = x.numel() // 2
+        else:
+            assert x.dtype == want, f"expected {want}"
+            nsamp = x.numel()
+        n = self.nout(nsamp)
         if out is None:
             out = torch.empty(max(n, 1), dtype=want, device=x.device)
         assert out.numel() >= n
         got = C.c_size_t(0)
-        check(self._f("enqueue")(self._h, _dev_ptr(x) if x.numel() else None, x.numel(), _dev_ptr(out), C.byref(got), current_stream()),
+        check(self._f("enqueue")(self._h, _dev_ptr(x) if x.numel() else None, nsamp, _dev_ptr(out), C.byref(got), current_stream()),
               f"{self._kind}_stream_enqueue")
         assert got.value == n
         return out[:n]

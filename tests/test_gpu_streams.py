@@ -160,3 +160,33 @@ def test_exchange_argument_checks(gpu, redio):
     rows = (C.c_size_t * 1)(4)
     assert L.redio_pfb_exchange(comm._h, None, None, rows, 8, None) == -1                                # rows announced, no buffers
     assert L.redio_pfb_exchange(comm._h, None, None, rows, 0, None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["chain", "chain_small", "pfb", "pfb_generic"])
+def test_u8_byte_streams(gpu, redio, oracle, kind):
+    """redio_{chain,pfb}_stream_create_u8: the receiver's byte stream (rtlsdr.rs:127-162) cut into messages of awkward lengths, the
+    history carried as bytes on the device.  The concatenated outputs are those of the oracle's data_to_samples + plan on the whole
+    stream, whatever the cuts (odd sample counts put later windows on 2-byte boundaries: those take the converting path)."""
+    rng = np.random.default_rng(len(kind))
+    if kind.startswith("chain"):
+        k, d, nfft = (127, 5, 1024) if kind == "chain" else (31, 2, 64)
+        taps = oracle.synth_f32(3, 0, k)
+        plan = redio.Chain(taps, d, nfft, fused=True)
+        n = 9 * nfft * d + 777
+        one = lambda v: oracle.chain_fir_fft(v, taps, d, nfft, fused=True).reshape(-1)
+    else:
+        M, P = (64, 16) if kind == "pfb" else (100, 5)
+        h = oracle.synth_f32(4, 0, M * P)
+        plan = redio.Channelizer(h, M, P, fused=True)
+        n = M * 700 + 13
+        one = lambda v: np.asarray(oracle.pfb_channelizer(v, h, M, P, True)).reshape(-1)
+    raw = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+    want = one(oracle.data_to_samples(raw))
+    draw = gpu.from_numpy(raw).cuda()
+    for cuts in ([0, n], [0, 1, 2, 1001, 1002, 40000 % n, n], sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 9)]))):
+        cuts = sorted(set(cuts))
+        st = redio.Stream(plan, u8=True)
+        outs = [st(draw[2 * lo: 2 * hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
+        got = gpu.cat(outs).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (kind, cuts)

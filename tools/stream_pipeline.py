@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-resident input end to end: pinned host buffers -> H2D copy on one HIP stream while the previous chunk
-runs data_to_samples -> FIR/5 -> FFT-1024 on another (double buffered).  The chain runs as a STREAM
+runs data_to_samples -> FIR/5 -> FFT-1024 on another (double buffered; from bytes that is ONE kernel per window).  The chain runs as a STREAM
 (redio_chain_stream_*): the 126-sample FIR seam and the partial block at the end of every chunk are carried on the
 device, so the spectra are those of the uninterrupted stream -- nothing is lost at chunk boundaries.  Reports the
 PCIe-inclusive rate, which is what a host that hands over host buffers gets; never bench.py's `value`.
@@ -17,7 +17,7 @@ nchunks = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n = 1 << (int(sys.argv[3]) if len(sys.argv) > 3 else 26)
 taps = R.dsputils.lpf_corrected(127, 0.08)
 chain = R.Chain(taps, 5, 1024, fused=True)
-stream = R.Stream(chain)
+stream = R.Stream(chain, u8=(fmt == "u8"))   # bytes: carried as bytes, every window one kernel (redio_chain_stream_create_u8)
 nblk = chain.nblocks(n) + 1          # a chunk can complete one block more than it holds (the carried partial block)
 bytes_per_sample = 2 if fmt == "u8" else 8
 host = [torch.randint(0, 256, (n * bytes_per_sample,), dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -37,7 +37,7 @@ def run(chunks):
             copied[b].record(copy_s)
         with torch.cuda.stream(comp_s):
             comp_s.wait_event(copied[b])
-            x = B.data_to_samples(dev_raw[b]) if fmt == "u8" else dev_raw[b].view(torch.complex64)
+            x = dev_raw[b] if fmt == "u8" else dev_raw[b].view(torch.complex64)
             stream(x, out=dev_out[b].view(-1))   # history carried: [tail | chunk] without copying the chunk
             done[b].record(comp_s)
     torch.cuda.synchronize()
