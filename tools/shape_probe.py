@@ -2,6 +2,7 @@
 """Run ONE plan shape a few times (for rocprofv3 passes on a secondary kernel):
     python3 tools/shape_probe.py fir|firr|firx|firrx K D [log2n] [launches]
     python3 tools/shape_probe.py pfb M P [log2n] [launches]
+    python3 tools/shape_probe.py src CHANNELS LOG2FRAMES
     python3 tools/shape_probe.py fft N 0 [log2n] [launches]
 Prints the HIP-event mean per launch."""
 import sys, os
@@ -12,7 +13,7 @@ import libredio_amd as R
 kind, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 26)
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
-x = R.synth_iq(1, 0, n)
+x = R.synth_iq(1, 0, n) if kind != "src" else None
 if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference rounding (multiply and add rounded separately)
     cplx = kind in ("fir", "firx")
     if not cplx:
@@ -20,6 +21,12 @@ if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference r
     plan = R.Fir(R.dsputils.lpf_corrected(a, 0.4 / b if b > 1 else 0.2), b, complex_input=cplx, fused=kind in ("fir", "firr"))
     out = torch.empty(plan.nout(n), dtype=x.dtype, device="cuda")
     run = lambda: plan(x, out=out)
+elif kind == "src":   # a = channels, b = log2 frames per channel; ratio 1/50 (BASELINE.json configs[2])
+    xr = torch.stack([R.synth_f32(100 + c, 0, 1 << b) for c in range(a)])
+    plan = R.Src(a, 1)
+    n = a << b
+    def run():
+        plan.reset(); plan.process(xr, 0.02)
 elif kind == "pfb":
     plan = R.Channelizer(R.dsputils.lpf_corrected(a * b, 0.45 / a), a, b)
     out = torch.empty((plan.nrows(n), a), dtype=torch.complex64, device="cuda")
