@@ -136,9 +136,12 @@ int redio_chain_reserve(redio_chain *h, size_t n_in);
 int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_out, void *stream);
 /* The receiver's own format in: interleaved u8 I/Q bytes (rtlsdr::data_to_samples, src/rtlsdr/src/rtlsdr.rs:159-162: i as f32 / 127.0 - 1.0)
  * straight into the chain -- nbytes / 2 samples, the spectra redio_data_to_samples + redio_chain_enqueue would give, bit for bit.
- * (127, 5, 1024) on 4-byte aligned bytes is ONE kernel (3.6 bytes per sample through HBM instead of 25.6); other shapes convert
+ * The shapes with a fused cf32 kernel (above) on 4-byte aligned bytes are ONE kernel ((127, 5): 3.6 bytes per sample through HBM instead
+ * of 25.6); other shapes convert
  * into a plan-owned buffer first (grown on first use: REDIO_ERR_NOT_RESERVED inside a stream capture). */
 int redio_chain_enqueue_u8(redio_chain *h, const void *d_bytes, size_t nbytes, void *d_out, void *stream);
+/* sizes that buffer (and the two-kernel path's intermediate) for messages of up to nbytes bytes, so that enqueue_u8 never allocates */
+int redio_chain_reserve_u8(redio_chain *h, size_t nbytes);
 /* diagnostic, per plan: while d_buf (4 x u64 per wave of the launch, device memory) is set, the fused kernel of THIS
  * plan writes {shader cycles, 100 MHz ticks, start tick, XCC/HW id} per wave into it (tools/clock_probe.py reads the
  * clock the chip holds from it).  NULL (default) turns it off.  Timings of stamped launches are never quoted. */
@@ -221,6 +224,7 @@ int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, 
  * bit for bit the rows of redio_data_to_samples + redio_pfb_enqueue: one kernel for 64 channels x 16 taps per branch (10 instead of
  * 26 bytes per sample through HBM), other shapes convert into a plan-owned buffer first (grown on first use). */
 int redio_pfb_enqueue_u8(redio_pfb *h, const void *d_bytes, size_t nbytes, void *d_out, int ngroups, void *stream);
+int redio_pfb_reserve_u8(redio_pfb *h, size_t nbytes, int ngroups); /* as redio_pfb_reserve, for messages of up to nbytes bytes */
 /* scratch of the two-pass shapes for inputs of up to n_in samples (the fused 64-channel kernel needs none) */
 int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups);
 

@@ -107,6 +107,8 @@ def lib():
         _sig(getattr(L, f"redio_{n}_stream_create_u8"), i, C.POINTER(vp), vp)
     _sig(L.redio_chain_enqueue, i, vp, vp, sz, vp, vp)
     _sig(L.redio_chain_enqueue_u8, i, vp, vp, sz, vp, vp)
+    _sig(L.redio_chain_reserve_u8, i, vp, sz)
+    _sig(L.redio_pfb_reserve_u8, i, vp, sz, i)
     pl = C.POINTER(C.c_long)
     _sig(L.redio_graph_begin, i, vp)
     _sig(L.redio_graph_end, i, vp, C.POINTER(vp))

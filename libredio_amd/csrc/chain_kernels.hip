@@ -14,6 +14,8 @@ namespace redio {
 hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                            hipStream_t s, unsigned long long *dbg); // chain_v4.hip
 hipError_t launch_chain_v4_u8(const void *bytes, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused, hipStream_t s);
+hipError_t launch_chain_v4_shape_u8(int K, int D, const void *bytes, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
+                                    hipStream_t s);
 hipError_t launch_chain_v4_shape(int K, int D, const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                                  hipStream_t s); // chain_v4.hip
 
@@ -34,14 +36,15 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
     return launch_chain_v4_shape(K, (int)D, x, taps, p.tw, out, nblocks, fused, s);
 }
 
-// u8 I/Q input: only the north-star shape has the one-kernel form
+// u8 I/Q input: the shapes with a one-kernel form are those of the cf32 chain
 hipError_t launch_chain_u8(const FftPlanDev &p, const void *bytes, const float *taps, int K, long D, float2 *out, long nblocks, bool fused,
                            hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    if (p.nfft != 1024 || p.inverse || K != 127 || D != 5) return hipErrorNotSupported;
+    if (p.nfft != 1024 || p.inverse || !chain_supported(K, D, p.nfft)) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(bytes) & 3) != 0) return hipErrorNotSupported; // every sub-tile starts on an even sample
-    return launch_chain_v4_u8(bytes, taps, p.tw, out, nblocks, fused, s);
+    if (K == 127 && D == 5) return launch_chain_v4_u8(bytes, taps, p.tw, out, nblocks, fused, s);
+    return launch_chain_v4_shape_u8(K, (int)D, bytes, taps, p.tw, out, nblocks, fused, s);
 }
 
 } // namespace redio

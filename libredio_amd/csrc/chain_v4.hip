@@ -172,6 +172,17 @@ hipError_t launch_chain_v4_u8(const void *bytes, const float *taps, const float2
     return launch_v4_t<127, 5, 2, 8, false, true, true>((const float2 *)bytes, taps, tw, out, nblocks, fused, s, nullptr); // 3 waves per SIMD: 0.52 against 0.46 ms
 }
 
+hipError_t launch_chain_v4_shape_u8(int K, int D, const void *bytes, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
+                                    hipStream_t s)
+{
+    const float2 *x = (const float2 *)bytes;
+    if (K == 63 && D == 5) return launch_v4_t<63, 5, 2, 8, false, true, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    if (K == 127 && D == 1) return launch_v4_t<127, 1, 2, 8, false, true, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    if (K == 63 && D == 1) return launch_v4_t<63, 1, 2, 8, false, true, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    if (K == 127 && D == 3) return launch_v4_t<127, 3, 2, 8, false, true, true>(x, taps, tw, out, nblocks, fused, s, nullptr);
+    return hipErrorNotSupported;
+}
+
 // the same kernel for the other tap / decimation pairs with a fused build (K - D even, image within the per-wave LDS budget)
 hipError_t launch_chain_v4_shape(int K, int D, const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                                  hipStream_t s)

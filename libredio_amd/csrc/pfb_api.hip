@@ -206,6 +206,22 @@ extern "C" int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, vo
     return hip_rc(e);
 }
 
+// sizes what redio_pfb_enqueue_u8 needs beyond the one-kernel form for messages of up to nbytes bytes
+extern "C" int redio_pfb_reserve_u8(redio_pfb *h, size_t nbytes, int ngroups)
+{
+    if (!h) return REDIO_ERR_ARG;
+    const size_t n_in = nbytes / 2;
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_rc(e);
+    if (n_in > h->conv_elems) {
+        hipFree(h->d_conv); h->d_conv = nullptr; h->conv_elems = 0;
+        e = hipMalloc((void **)&h->d_conv, n_in * sizeof(float2));
+        if (e != hipSuccess) return hip_rc(e);
+        h->conv_elems = n_in;
+    }
+    return redio_pfb_reserve(h, n_in, ngroups);
+}
+
 // rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> the channelizer, from the receiver's u8 I/Q bytes
 extern "C" int redio_pfb_enqueue_u8(redio_pfb *h, const void *d_bytes, size_t nbytes, void *d_out, int ngroups, void *stream)
 {
@@ -222,15 +238,13 @@ extern "C" int redio_pfb_enqueue_u8(redio_pfb *h, const void *d_bytes, size_t nb
                           (hipStream_t)stream);
         if (e != hipErrorNotSupported) return hip_rc(e);
     }
-    if (n_in > h->conv_elems) { // other shapes: convert first (grown on first use, never inside a capture)
+    if (n_in > h->conv_elems) { // other shapes, un-reserved (redio_pfb_reserve_u8): grow on first use, never inside a capture
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return REDIO_ERR_NOT_RESERVED;
         e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) return hip_rc(e);
-        hipFree(h->d_conv); h->d_conv = nullptr; h->conv_elems = 0;
-        e = hipMalloc((void **)&h->d_conv, n_in * sizeof(float2));
-        if (e != hipSuccess) return hip_rc(e);
-        h->conv_elems = n_in;
+        const int rc = redio_pfb_reserve_u8(h, nbytes, ngroups);
+        if (rc) return rc;
     }
     const int rc = redio_data_to_samples(d_bytes, nbytes, h->d_conv, stream);
     if (rc) return rc;

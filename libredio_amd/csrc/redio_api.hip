@@ -572,6 +572,22 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     return redio_fft_enqueue(h->fft, h->d_mid, d_out, nblk, stream);
 }
 
+// sizes what redio_chain_enqueue_u8 needs beyond the one-kernel form for messages of up to nbytes bytes: the converted samples,
+// and the two-kernel path's intermediate behind them
+extern "C" int redio_chain_reserve_u8(redio_chain *h, size_t nbytes)
+{
+    if (!h) return REDIO_ERR_ARG;
+    const size_t n_in = nbytes / 2;
+    RD_TRY(hipSetDevice(h->fir->device));
+    if (n_in > h->conv_elems) {
+        if (h->d_conv) RD_TRY(hipFree(h->d_conv));
+        h->d_conv = nullptr; h->conv_elems = 0;
+        RD_TRY(hipMalloc((void **)&h->d_conv, n_in * sizeof(float2)));
+        h->conv_elems = n_in;
+    }
+    return redio_chain_reserve(h, n_in);
+}
+
 // rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> the chain, from the receiver's u8 I/Q bytes
 extern "C" int redio_chain_enqueue_u8(redio_chain *h, const void *d_bytes, size_t nbytes, void *d_out, void *stream)
 {
@@ -587,13 +603,11 @@ extern "C" int redio_chain_enqueue_u8(redio_chain *h, const void *d_bytes, size_
         if (e != hipErrorNotSupported) return hip_rc(e);
     }
     // other shapes, or bytes that are not 4-byte aligned: convert into a plan-owned buffer, then the cf32 entry point (same results)
-    if (n_in > h->conv_elems) {
+    if (n_in > h->conv_elems) { // un-reserved (redio_chain_reserve_u8): grow on first use, never inside a capture
         if (stream_is_capturing((hipStream_t)stream)) return REDIO_ERR_NOT_RESERVED;
         RD_TRY(hipStreamSynchronize((hipStream_t)stream)); // launches that still read the old buffer
-        if (h->d_conv) hipFree(h->d_conv);
-        h->d_conv = nullptr; h->conv_elems = 0;
-        RD_TRY(hipMalloc((void **)&h->d_conv, n_in * sizeof(float2)));
-        h->conv_elems = n_in;
+        int rc = redio_chain_reserve_u8(h, nbytes);
+        if (rc) return rc;
     }
     int rc = redio_data_to_samples(d_bytes, nbytes, h->d_conv, stream);
     if (rc) return rc;

@@ -134,6 +134,10 @@ class Chain:
         check(lib().redio_chain_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), current_stream()), "chain_enqueue")
         return out
 
+    def reserve_u8(self, nbytes):
+        """Size what from_bytes needs beyond the one-kernel form (other shapes, unaligned bytes) for messages of up to nbytes bytes."""
+        check(lib().redio_chain_reserve_u8(self._h, int(nbytes)), "chain_reserve_u8")
+
     def from_bytes(self, raw, out=None):
         """redio_chain_enqueue_u8: the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162)
         straight into the chain; the spectra of bitfount.data_to_samples(raw) followed by this plan, bit for bit."""

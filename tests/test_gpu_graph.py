@@ -79,3 +79,30 @@ def test_plan_scratch_is_reserved_not_grown_inside_a_capture(gpu, redio, oracle)
     g2.launch()
     gpu.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_u8_entry_points_inside_a_capture(gpu, redio, oracle):
+    """redio_chain_enqueue_u8: the one-kernel form (127, 5, 1024) allocates nothing and can be captured as it is; a shape that
+    converts first needs redio_chain_reserve_u8 before a capture (REDIO_ERR_NOT_RESERVED = -6 otherwise)."""
+    rng = np.random.default_rng(11)
+    for (k, d, nfft), needs_reserve in (((127, 5, 1024), False), ((31, 4, 64), True)):
+        taps = oracle.lpf_corrected(k, 0.08)
+        n = 3 * nfft * d + k + 9
+        raw = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+        dv = gpu.from_numpy(raw).cuda()
+        want = oracle.chain_fir_fft(oracle.data_to_samples(raw), taps, d, nfft, fused=True)
+        chain = redio.Chain(taps, d, nfft, fused=True)
+        out = gpu.zeros((chain.nblocks(n), nfft), dtype=gpu.complex64, device="cuda")
+        if needs_reserve:
+            g = redio.Graph()
+            with pytest.raises(redio.RedioError) as e:
+                with g:
+                    chain.from_bytes(dv, out)
+            assert e.value.code == -6
+            chain.reserve_u8(2 * n)
+        g2 = redio.Graph()
+        with g2:
+            chain.from_bytes(dv, out)
+        g2.launch()
+        gpu.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))

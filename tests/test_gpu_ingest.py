@@ -131,7 +131,7 @@ def test_shipped_graph_front_end_end_to_end(gpu, redio, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("shape", [(127, 5, 1024), (63, 5, 1024), (127, 5, 256), (31, 2, 64)])
+@pytest.mark.parametrize("shape", [(127, 5, 1024), (63, 5, 1024), (127, 1, 1024), (63, 1, 1024), (127, 3, 1024), (127, 5, 256), (31, 2, 64)])
 def test_chain_from_u8_bytes(gpu, redio, oracle, shape, fused):
     """redio_chain_enqueue_u8: rtlsdr::data_to_samples (rtlsdr.rs:159-162) -> FIR (dsputils.rs:30-32) -> kissfft (kissfft.rs:20-29) from the
     receiver's u8 I/Q bytes.  (127, 5, 1024) is one kernel (the conversion happens on the way into the LDS image); other shapes and
