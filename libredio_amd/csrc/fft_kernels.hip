@@ -788,17 +788,33 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
 struct TwGather {
     const float2 *tw; unsigned fs;
     __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return tw[n * k * fs]; }
+    __device__ __forceinline__ void get3(unsigned k, float2 &t1, float2 &t2, float2 &t3) const { t1 = get(1, k); t2 = get(2, k); t3 = get(3, k); }
 };
 struct TwOrdered {
     const float2 *T; unsigned m;
     __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[(n - 1) * m + k]; }
+    __device__ __forceinline__ void get3(unsigned k, float2 &t1, float2 &t2, float2 &t3) const { t1 = get(1, k); t2 = get(2, k); t3 = get(3, k); }
+};
+// the copy of a four-stage in-place pass, INTERLEAVED: entry k of a stage holds its three twiddles side by side, T[4 k + (n - 1)]
+// (the fourth slot pads the entry to 32 bytes).  A butterfly's three twiddles are then one 16-byte and one 8-byte load from one
+// 32-byte entry instead of three 8-byte loads from three planes m entries apart -- measured on the access pattern alone: the
+// in-place pass of 65536 points 283 -> 233 us per 2^26 points, of 2^24 points 318 -> 254 (profiles/r02_fft_pass_times.txt).
+struct TwInter {
+    const float2 *T;
+    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[4 * k + (n - 1)]; }
+    __device__ __forceinline__ void get3(unsigned k, float2 &t1, float2 &t2, float2 &t3) const
+    {
+        const float4 q = *reinterpret_cast<const float4 *>(T + 4 * (size_t)k); // 32-byte entries of a 256-byte aligned table
+        t1 = make_float2(q.x, q.y); t2 = make_float2(q.z, q.w); t3 = T[4 * (size_t)k + 2];
+    }
 };
 template <bool INV, typename TA, typename TB>
 __device__ __forceinline__ void big_macro16(float2 (&a)[16], TA ta, TB tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
 {
     {
         const unsigned k = l + m_lo * kk;
-        const float2 t1 = ta.get(1, k), t2 = ta.get(2, k), t3 = ta.get(3, k);
+        float2 t1, t2, t3;
+        ta.get3(k, t1, t2, t3);
 #pragma unroll
         for (int q = 0; q < 4; q += 2)
             bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
@@ -806,12 +822,29 @@ __device__ __forceinline__ void big_macro16(float2 (&a)[16], TA ta, TB tb, unsig
 #pragma unroll
     for (int u = 0; u < 4; u += 2) {
         const unsigned k = l + m_lo * (kk + u * m), kb = k + m_lo * m;
-        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], tb.get(1, k), tb.get(2, k), tb.get(3, k),
-                     a[u + 1], a[u + 5], a[u + 9], a[u + 13], tb.get(1, kb), tb.get(2, kb), tb.get(3, kb));
+        float2 p1, p2, p3, r1, r2, r3;
+        tb.get3(k, p1, p2, p3);
+        tb.get3(kb, r1, r2, r3);
+        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], p1, p2, p3, a[u + 1], a[u + 5], a[u + 9], a[u + 13], r1, r2, r3);
     }
 }
 // the ordered copy of one pass: stage t (sub-length m_lo 4^t) starts at m_lo (4^t - 1) and holds 3 m_lo 4^t entries
 __device__ __forceinline__ TwOrdered tw_ordered_stage(const float2 *T, unsigned m_lo, int t) { return TwOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
+// the interleaved copy: stage t (sub-length m_lo 4^t) starts at entry m_lo (4^t - 1) / 3 and holds m_lo 4^t entries of four float2
+__device__ __forceinline__ TwInter tw_inter_stage(const float2 *T, unsigned m_lo, int t) { return TwInter{T + 4 * (size_t)(m_lo * (((1u << (2 * t)) - 1) / 3))}; }
+__global__ __launch_bounds__(256) void fftbig_tables_inter_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned m_lo, int nstages, unsigned N)
+{
+    const unsigned total = m_lo * (((1u << (2 * nstages)) - 1) / 3); // entries over all stages
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int t = 0;
+        while (i >= m_lo * (((1u << (2 * (t + 1))) - 1) / 3)) ++t;
+        const unsigned m = m_lo << (2 * t), k = i - m_lo * (((1u << (2 * t)) - 1) / 3), fs = N / (4 * m);
+        T[4 * (size_t)i] = tw[k * fs];
+        T[4 * (size_t)i + 1] = tw[2 * k * fs];
+        T[4 * (size_t)i + 2] = tw[3 * k * fs];
+        T[4 * (size_t)i + 3] = make_float2(0.f, 0.f);
+    }
+}
 __global__ __launch_bounds__(256) void fftbig_tables_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned m_lo, int nstages, unsigned N)
 {
     const unsigned total = m_lo * ((1u << (2 * nstages)) - 1);
@@ -881,10 +914,10 @@ __device__ __forceinline__ void ovsave64k_mid_tile(const float2 *__restrict__ a_
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) big_macro16<false>(a[i], tw_ordered_stage(Tf, 256u, 0), tw_ordered_stage(Tf, 256u, 1), (unsigned)(F64K_COLS * c + col), 256u, 0u, 1u);
+    for (int i = 0; i < 4; ++i) big_macro16<false>(a[i], tw_inter_stage(Tf, 256u, 0), tw_inter_stage(Tf, 256u, 1), (unsigned)(F64K_COLS * c + col), 256u, 0u, 1u);
     f64w_exchange<false, false>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) big_macro16<false>(b[x], tw_ordered_stage(Tf, 256u, 2), tw_ordered_stage(Tf, 256u, 3), (unsigned)(F64K_COLS * c + col), 256u, (unsigned)(q + 4 * x), 16u);
+    for (int x = 0; x < 4; ++x) big_macro16<false>(b[x], tw_inter_stage(Tf, 256u, 2), tw_inter_stage(Tf, 256u, 3), (unsigned)(F64K_COLS * c + col), 256u, (unsigned)(q + 4 * x), 16u);
     const float2 *hc = Hc + F64K_COLS * c;
 #pragma unroll
     for (int x = 0; x < 4; ++x) { // sixteen spectrum taps as one batch of loads (the compiler would wait for them one by one)
@@ -933,10 +966,10 @@ __device__ __forceinline__ void ovsave64k_last_tile(const float2 *__restrict__ b
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[i][j] = (src + 256 * (64 * i + j))[lo_q16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) big_macro16<true>(a[i], tw_ordered_stage(Ti, 256u, 0), tw_ordered_stage(Ti, 256u, 1), (unsigned)(F64K_COLS * c + col), 256u, 0u, 1u);
+    for (int i = 0; i < 4; ++i) big_macro16<true>(a[i], tw_inter_stage(Ti, 256u, 0), tw_inter_stage(Ti, 256u, 1), (unsigned)(F64K_COLS * c + col), 256u, 0u, 1u);
     f64w_exchange<false, false>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) big_macro16<true>(b[x], tw_ordered_stage(Ti, 256u, 2), tw_ordered_stage(Ti, 256u, 3), (unsigned)(F64K_COLS * c + col), 256u, (unsigned)(q + 4 * x), 16u);
+    for (int x = 0; x < 4; ++x) big_macro16<true>(b[x], tw_inter_stage(Ti, 256u, 2), tw_inter_stage(Ti, 256u, 3), (unsigned)(F64K_COLS * c + col), 256u, (unsigned)(q + 4 * x), 16u);
     const long lim = hop - F64K_COLS * c - (long)lo_q1; // pos < hop
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -1462,10 +1495,10 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
         for (int j = 0; j < 16; ++j) a[i][j] = (base + (long)m_lo * (64 * i + j))[lo_ld]; // row 16 (4i + q) + j
     RD_SCHED_BARRIER();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw_ordered_stage(T, m_lo, 0), tw_ordered_stage(T, m_lo, 1), l, m_lo, 0u, 1u);
+    for (int i = 0; i < 4; ++i) big_macro16<INV>(a[i], tw_inter_stage(T, m_lo, 0), tw_inter_stage(T, m_lo, 1), l, m_lo, 0u, 1u);
     f64w_exchange<false, false>(a, b, Lw, lane);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw_ordered_stage(T, m_lo, 2), tw_ordered_stage(T, m_lo, 3), l, m_lo, (unsigned)(q + 4 * x), 16u);
+    for (int x = 0; x < 4; ++x) big_macro16<INV>(b[x], tw_inter_stage(T, m_lo, 2), tw_inter_stage(T, m_lo, 3), l, m_lo, (unsigned)(q + 4 * x), 16u);
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -1964,6 +1997,7 @@ static hipError_t launch_fft_tile_passes(const FftPlanDev &p, const float2 *in, 
 //   2^15: 3 + 5            (two passes instead of three)      2^18: 4 + 5, 2^20: 5 + 5   (two instead of three)
 //   2^19: 3 + 5 + 2, 2^22: 5 + 5 + 1  (three either way; shorter last pass; 2^24 measured slower as 5 + 5 + 2)     2^23: 3 + 5 + 4   (three instead of four)
 // Its in-place passes read their own ordered twiddle copies, stored behind plan A's tables.
+constexpr int FFTBIG_MID4_ELEMS = 340; // float2 per unit of row stride in the interleaved copy of a four-stage pass: 85 entries x 4
 struct BigPlanB { int first, nmid, mid[2], last; };
 static bool fftbig_plan_b(int lgN, BigPlanB &p)
 {
@@ -1984,7 +2018,7 @@ static size_t fftbig_five_elems(int lgN)
     if (!fftbig_plan_b(lgN, p)) return 0;
     size_t total = 0;
     int lm = fftbig_plan_b_lm0(p);
-    for (int i = 0; i < p.nmid; ++i) { total += (size_t)(p.mid[i] == 5 ? 1023 : 255) << lm; lm += 2 * p.mid[i]; }
+    for (int i = 0; i < p.nmid; ++i) { total += (size_t)(p.mid[i] == 5 ? 1023 : FFTBIG_MID4_ELEMS) << lm; lm += 2 * p.mid[i]; }
     return total;
 }
 // every 4^L size: the gather pass's ordered copy (sub-lengths 1, 4, 16, 64, 256), at the very end of the tables
@@ -2007,7 +2041,7 @@ size_t fftbig_tables_elems(int nfft)
     int lm, left;
     fftbig_after_first(lgN, lm, left);
     size_t total = 0;
-    for (; left >= 4; lm += 8, left -= 4) total += (size_t)255 << lm;
+    for (; left >= 4; lm += 8, left -= 4) total += (size_t)FFTBIG_MID4_ELEMS << lm;
     if (left == 3) total += (size_t)15 << (lgN - 6);
     return total + fftbig_five_elems(lgN) + fftbig_first_elems(lgN);
 }
@@ -2028,16 +2062,17 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
     fftbig_after_first(lgN, lm, left);
     float2 *T = tables;
     for (; left >= 4; lm += 8, left -= 4) {
-        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm, 4, (unsigned)nfft);
-        T += (size_t)255 << lm;
+        hipLaunchKernelGGL(fftbig_tables_inter_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm, 4, (unsigned)nfft);
+        T += (size_t)FFTBIG_MID4_ELEMS << lm;
     }
     if (left == 3) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft); T += (size_t)15 << (lgN - 6); }
     BigPlanB pb;
     if (fftbig_plan_b(lgN, pb)) {
         int lmb = fftbig_plan_b_lm0(pb);
         for (int i = 0; i < pb.nmid; ++i) {
-            hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, pb.mid[i], (unsigned)nfft);
-            T += (size_t)(pb.mid[i] == 5 ? 1023 : 255) << lmb;
+            if (pb.mid[i] == 5) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, 5, (unsigned)nfft);
+            else hipLaunchKernelGGL(fftbig_tables_inter_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, 4, (unsigned)nfft);
+            T += (size_t)(pb.mid[i] == 5 ? 1023 : FFTBIG_MID4_ELEMS) << lmb;
             lmb += 2 * pb.mid[i];
         }
     }
@@ -2074,7 +2109,7 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
                 T += (size_t)1023 << lm;
             } else {
                 hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T, ntiles, lgN, lm, vo, hop, scale);
-                T += (size_t)255 << lm;
+                T += (size_t)FFTBIG_MID4_ELEMS << lm;
             }
             lm += 2 * pb.mid[i];
         }
@@ -2094,7 +2129,7 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     for (; left >= 4; lm += 8, left -= 4) {
         float2 *vo = left == 4 ? vout : nullptr; // the last pass of all
         hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T, ntiles, lgN, lm, vo, hop, scale);
-        T += (size_t)255 << lm;
+        T += (size_t)FFTBIG_MID4_ELEMS << lm;
     }
     switch (left) {
     case 0: break;
