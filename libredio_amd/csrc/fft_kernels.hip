@@ -1995,7 +1995,7 @@ static hipError_t launch_fft_tile_passes(const FftPlanDev &p, const float2 *in, 
 // Plan B: sizes for which five-stage passes save a pass or end on a cheaper last pass.  first = stages of the gather pass (2: the
 // radix-2 stage + two radix-4 stages of 2 * 4^L), mid = stages of each in-place pass, last = trailing register-only stages.
 //   2^15: 3 + 5            (two passes instead of three)      2^18: 4 + 5, 2^20: 5 + 5   (two instead of three)
-//   2^19: 3 + 5 + 2, 2^22: 5 + 5 + 1  (three either way; shorter last pass; 2^24 measured slower as 5 + 5 + 2)     2^23: 3 + 5 + 4   (three instead of four)
+//   2^19: 3 + 5 + 2  (three either way; shorter last pass; 2^22 as 5 + 5 + 1 and 2^24 as 5 + 5 + 2 measured slower)     2^23: 3 + 5 + 4   (three instead of four)
 // Its in-place passes read their own ordered twiddle copies, stored behind plan A's tables.
 constexpr int FFTBIG_MID4_ELEMS = 340; // float2 per unit of row stride in the interleaved copy of a four-stage pass: 85 entries x 4
 struct BigPlanB { int first, nmid, mid[2], last; };
@@ -2006,7 +2006,7 @@ static bool fftbig_plan_b(int lgN, BigPlanB &p)
     case 18: p = {4, 1, {5, 0}, 0}; return true;
     case 19: p = {2, 1, {5, 0}, 2}; return true;
     case 20: p = {5, 1, {5, 0}, 0}; return true;
-    case 22: p = {5, 1, {5, 0}, 1}; return true;
+    // (2^22 as 5 + 5 + 1 was the faster plan until the four-stage pass got its interleaved twiddle copy: 4 + 4 + 3 now wins, 84 against 80 GS/s)
     case 23: p = {2, 2, {5, 4}, 0}; return true;
     default: return false;
     }
