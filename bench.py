@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-u8-leg", action="store_true", help="skip the from_u8_bytes leg (the same chain fed with u8 I/Q bytes, after the timed region)")
     ap.add_argument("--steady", type=int, default=1000, help="further launches after the timed region, reported as steady_state (0 = skip)")
     ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (default 2^28 = 2 GiB)")
     ap.add_argument("--unfused", action="store_true", help="run FIR and FFT as two kernels (12.8 B/sample)")
@@ -238,6 +239,29 @@ def main():
         lib.redio_event_destroy(e0)
         lib.redio_event_destroy(e1)
 
+    # outside the timed region: the same chain fed with the receiver's u8 I/Q bytes (redio_chain_enqueue_u8: data_to_samples folded
+    # into the kernel's loader, 3.6 bytes per sample through HBM) -- a different input format, reported beside value, never as value
+    u8_ms = None
+    if not a.exact and not a.unfused and not a.no_u8_leg and n % 2 == 0:
+        g = torch.Generator(device="cuda"); g.manual_seed(0x5EED0002 + rank)
+        raw = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        R.check(lib.redio_event_create(C.byref(e0)))
+        R.check(lib.redio_event_create(C.byref(e1)))
+        for _ in range(20):
+            chain.from_bytes(raw, out)
+        R.check(lib.redio_event_record(e0, stream))
+        for _ in range(100):
+            chain.from_bytes(raw, out)
+        R.check(lib.redio_event_record(e1, stream))
+        torch.cuda.synchronize()
+        ms = C.c_float()
+        R.check(lib.redio_event_elapsed_ms(e0, e1, C.byref(ms)))
+        u8_ms = ms.value / 100
+        lib.redio_event_destroy(e0)
+        lib.redio_event_destroy(e1)
+        del raw
+
     if rank == 0:
         kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
@@ -281,6 +305,12 @@ def main():
                                          "note": "same kernel built with separately rounded multiply and add: bit-identical to the "
                                                  "reference arithmetic; the headline build uses fmaf in the reference's tap order "
                                                  "(within the stated f32 tolerance, tests/test_gpu_parity.py)"}
+        if u8_ms is not None:
+            rec["from_u8_bytes"] = {"kernel_ms": u8_ms, "value_per_gpu": used / u8_ms / 1e3, "unit": "MSamples/s",
+                                    "alg_bytes_per_sample": 3.6, "frac": 3.6 * used / (u8_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "the same chain from interleaved u8 I/Q bytes (rtlsdr::data_to_samples folded into the kernel's "
+                                            "loader, redio_chain_enqueue_u8): 2 + 1.6 bytes per sample, VALU-bound; a different input "
+                                            "format from BASELINE.json configs[1] (f32 IQ), so beside value, never as value"}
         if not a.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_log2_samples)
         else:

@@ -630,8 +630,14 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
     const long in_count = input_frames, out_count = output_frames;
     long in_used = 0, out_gen = 0;
     double src_ratio = f->last_ratio, input_index = f->last_position, rem;
+    // The library counts interleaved SAMPLES (in_used, in_count multiples of the channel count) and compares
+    // in_used + channels * input_index with in_count in double; this loop counts frames, so the comparisons are written out in the
+    // library's units -- for a channel count that is not a power of two the product rounds, and the frame form of the same
+    // inequality can decide differently when the position sits on the boundary (found by the randomised run: 3 channels, 48000 / 44100).
+    const double chd = (double)f->nchan;
+    auto samples = [&](long frames) { return (double)(frames * (long)f->nchan); };
     while (input_index < 1.0 && out_gen < out_count) {
-        if (lin ? (in_used + (1.0 + input_index) >= in_count) : (in_used + input_index >= in_count)) break;
+        if (lin ? (samples(in_used) + chd * (1.0 + input_index) >= samples(in_count)) : (samples(in_used) + chd * input_index >= samples(in_count))) break;
         if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
             src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
         f->h_pos[(size_t)out_gen] = -1;
@@ -642,7 +648,7 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
     rem = fmod_one(input_index);
     in_used += lrint(input_index - rem);
     input_index = rem;
-    while (out_gen < out_count && (lin ? (in_used + input_index < in_count) : (in_used + input_index <= in_count))) {
+    while (out_gen < out_count && (lin ? (samples(in_used) + chd * input_index < samples(in_count)) : (samples(in_used) + chd * input_index <= samples(in_count)))) {
         if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
             src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
         f->h_pos[(size_t)out_gen] = (int)(in_used - 1);

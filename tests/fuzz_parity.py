@@ -109,6 +109,7 @@ while time.time() < t_end:
         from libredio_amd import kpn_dev as K
         n = int(rng.integers(1, 50000)); off = int(rng.integers(0, 9))
         v = np.repeat(rng.integers(0, 4, n), rng.integers(1, 6, n)).astype(np.uint8)[: n + off]
+        off = min(off, len(v))
         dev, ref = K.Rle(), O.Rle()
         ok = True
         cuts = sorted(set([off, len(v)] + [int(c) for c in rng.integers(off, len(v) + 1, 2)]))

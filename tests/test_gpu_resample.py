@@ -352,3 +352,25 @@ def test_interleaved_channels_through_the_drop_in(gpu, redio, oracle, conv, chan
             assert np.array_equal(bits(o1[c::channels]), bits(oc))
         pos += frames
     st.close()
+
+
+@pytest.mark.gpu
+def test_linear_converter_three_channels_boundary(gpu, redio, oracle):
+    """Found by tests/fuzz_parity.py (seed 777001): converter 4 (linear), 3 interleaved channels, ratio 48000 / 44100, messages of
+    6439 then 15317 frames -- the library compares in_used + channels * input_index with in_count in SAMPLE units (src_linear.c as
+    published; samplerate.rs:26-30 declares the converter), and with a channel count that is not a power of two the frame form of
+    the same inequality decided the last output of the second message differently (one frame more consumed and produced).
+    Counts, outputs and carried state must be the oracle's for these and neighbouring lengths."""
+    from libredio_amd import samplerate
+    ratio = 48000 / 44100
+    for conv in (4, 3):
+        for first in (6439, 6438, 6440):
+            st, ref = samplerate.State(conv, 3), oracle.Resampler(conv, 3)
+            for m in (first, 15317, 1, 2, 4099):
+                x = oracle.synth_f32(1000 + m, 0, m * 3)
+                cap = int(ratio * m + 1.0)
+                e1, a, u1 = st.process(x, ratio, cap, 0)
+                e2, b, u2 = ref.process(x, ratio, cap, False)
+                assert (e1, u1, len(a)) == (e2, u2, len(b)), (conv, first, m)
+                assert np.array_equal(bits(a), bits(b)), (conv, first, m)
+            st.close()
