@@ -109,6 +109,8 @@ struct redio_src {
     float *d_rows_in, *d_rows_out; size_t rows_in_cap, rows_out_cap; // interleaved host form, nchan > 1: de-interleaved rows
     int mode;                                // REDIO_SRC_EXACT / REDIO_SRC_FAST
     int window_ok;                           // single-launch path enabled (off: one launch per buffer refill)
+    int zl_channels;                         // converters 3 / 4: the channel count the library's end-of-input comparison multiplies by --
+                                             // the state's channels for an interleaved message, 1 for the batched rows (independent mono streams)
     size_t stage_in_cap, stage_out_cap;
     hipStream_t host_stream; // the host-buffer entry point's own stream: states on different threads do not serialise
 };
@@ -160,7 +162,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->d_pL = s->d_pR = nullptr; s->pL_cap = s->pR_cap = 0; s->d_pint = nullptr; s->period_hint = 0;
     s->h_pos = s->h_start = s->h_inc = nullptr; s->h_scale = nullptr; s->h_arena = nullptr; s->arena_cap = s->arena_used = 0;
     s->periodic_launches = s->general_launches = s->tile_launches = 0;
-    s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1;
+    s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1; s->zl_channels = 1;
     s->h_coeffs = coeffs;
     if (zl) {
         s->b_len = 0; s->buf_stride = 0;
@@ -634,8 +636,9 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
     // in_used + channels * input_index with in_count in double; this loop counts frames, so the comparisons are written out in the
     // library's units -- for a channel count that is not a power of two the product rounds, and the frame form of the same
     // inequality can decide differently when the position sits on the boundary (found by the randomised run: 3 channels, 48000 / 44100).
-    const double chd = (double)f->nchan;
-    auto samples = [&](long frames) { return (double)(frames * (long)f->nchan); };
+    const int units = f->zl_channels > 0 ? f->zl_channels : 1;
+    const double chd = (double)units;
+    auto samples = [&](long frames) { return (double)(frames * (long)units); };
     while (input_index < 1.0 && out_gen < out_count) {
         if (lin ? (samples(in_used) + chd * (1.0 + input_index) >= samples(in_count)) : (samples(in_used) + chd * input_index >= samples(in_count))) break;
         if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
@@ -930,6 +933,7 @@ extern "C" int redio_src_process(redio_src *s, const void *d_in, long input_fram
     SrcInput in = {nullptr, (const float *)d_in, in_stride};
     // pinned-free staging of the per-output parameters means the host arrays must stay untouched until
     // the uploads have run: synchronise at the end of the call (the uploads are tiny)
+    s->zl_channels = 1; // rows are independent mono streams
     int rc = src_process_impl(s, in, input_frames, (float *)d_out, out_stride, output_frames, src_ratio, end_of_input,
                               input_frames_used, output_frames_gen, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
@@ -997,6 +1001,7 @@ extern "C" int redio_src_process_host(redio_src *s, const float *data_in, long i
     long used = 0, gen = 0;
     float *d_rows = nch == 1 ? s->d_stage_out : s->d_rows_out;
     const long row_stride = nch == 1 ? (long)s->stage_out_cap : (output_frames > 0 ? output_frames : 1);
+    s->zl_channels = (int)nch; // one interleaved multi-channel stream, the library's own counting
     int rc = src_process_impl(s, in, input_frames, d_rows, row_stride, output_frames, src_ratio, end_of_input, &used, &gen, st);
     hipError_t e = hipSuccess;
     if (rc == REDIO_OK && gen > 0) {

@@ -289,7 +289,10 @@ static int zoh_linear_process(orc_src_state *p, orc_src_data *d)
         if (out_count > 0 && fabs(p->last_ratio - d->src_ratio) > 1e-20)
             src_ratio = p->last_ratio + out_gen * (d->src_ratio - p->last_ratio) / out_count;
         for (int ch = 0; ch < ch_n; ++ch) {
-            const float a = d->data_in[in_used - ch_n + ch];
+            /* in_used == 0 can reach this loop when the message holds a single frame (the loop above breaks at once): the
+             * published code then reads data_in[-channels + ch], before the array.  Defined here -- and in the device path --
+             * as the value carried from the previous message, which is what that address would hold in a contiguous stream. */
+            const float a = in_used >= ch_n ? d->data_in[in_used - ch_n + ch] : p->last_value[ch];
             d->data_out[out_gen] = lin ? (float)(a + input_index * (d->data_in[in_used + ch] - a)) : a;
             out_gen++;
         }

@@ -181,7 +181,7 @@ while time.time() < t_end:
         ratio = float(rng.choice([0.02, 0.5, 1.0, 2.0, 0.25, 1.0884, 48000 / 44100, 1.5, 0.3, float(rng.uniform(0.01, 3.0))]))
         st, ref, ok = samplerate.State(conv, ch), O.Resampler(conv, ch), True
         for _ in range(int(rng.integers(1, 5))):
-            m = int(rng.integers(1, 20000))
+            m = int(rng.integers(1, 20000)) if rng.integers(0, 4) else int(rng.integers(1, 6))   # now and then a message of a few frames
             x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m * ch)
             cap = int(ratio * m + 1.0)
             e1, a, u1 = st.process(x, ratio, cap, 0)
@@ -190,13 +190,13 @@ while time.time() < t_end:
         st.close()
         check("srcdrop", ok, (conv, ch, ratio))
     else:               # resampler, batched, random ratio and message cuts
-        nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 3))
+        nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 5))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 48000 / 44100, 1.5, 0.3, 4 / 3, 0.75, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
         n = int(rng.integers(1, 40000 if ratio < 10 else 400))
         x = np.stack([O.synth_f32(int(rng.integers(1, 1 << 30)), 0, n) for _ in range(nch)])
         plan = R.Src(nch, conv, mode=int(rng.choice([0, 2])))
         refs = [O.Resampler(conv) for _ in range(nch)]
-        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 3)]))
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 3)] + ([min(n, int(rng.integers(0, n + 1)) + 1)] if rng.integers(0, 2) else [])))
         ok = True
         dx = torch.from_numpy(x).cuda()
         for lo, hi in zip(cuts[:-1], cuts[1:]):

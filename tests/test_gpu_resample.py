@@ -374,3 +374,24 @@ def test_linear_converter_three_channels_boundary(gpu, redio, oracle):
                 assert (e1, u1, len(a)) == (e2, u2, len(b)), (conv, first, m)
                 assert np.array_equal(bits(a), bits(b)), (conv, first, m)
             st.close()
+
+
+@pytest.mark.gpu
+def test_batched_rows_zoh_linear_are_mono_streams(gpu, redio, oracle):
+    """redio_src_process on [nchan][frames] rows: every row is its own mono stream (samplerate.rs:61 resamples one channel), so
+    converters 3 / 4 must make the library's end-of-input decision with a channel count of ONE whatever nchan is -- the same
+    message lengths as the interleaved boundary case above, 3 and 5 rows."""
+    ratio = 48000 / 44100
+    for conv in (4, 3):
+        for nch in (3, 5):
+            plan = redio.Src(nch, conv)
+            refs = [oracle.Resampler(conv) for _ in range(nch)]
+            for m in (6439, 15317, 1, 2, 4099):
+                x = np.stack([oracle.synth_f32(77 + c + m, 0, m) for c in range(nch)])
+                cap = int(ratio * m + 1.0)
+                a, used = plan.process(gpu.from_numpy(x).cuda(), ratio, output_frames=cap)
+                a = a.cpu().numpy()
+                for c in range(nch):
+                    err, want, wused = refs[c].process(x[c], ratio, cap)
+                    assert err == 0 and wused == used and a.shape[1] == len(want), (conv, nch, m, c)
+                    assert np.array_equal(bits(a[c]), bits(want)), (conv, nch, m, c)
