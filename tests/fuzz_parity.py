@@ -140,7 +140,10 @@ while time.time() < t_end:
         ok = ok and got.shape == want.shape and np.array_equal(bits(got), bits(want))
         check("dropin", ok, (n, inv, nu, nv))
     elif which in (10, 11):   # carried-history streams: any plan, any cut of the stream == one stateless call on the whole stream
-        kind = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 6))
+        u8 = kind >= 4            # 4, 5: the chain / channelizer streams fed with u8 I/Q bytes
+        if u8:
+            kind -= 3             # -> 1 (chain), 2 (pfb)
         if kind == 0:
             k = int(rng.choice([1, 2, 17, 63, 127, 128, int(rng.integers(1, 600))])); d = int(rng.choice([1, 2, 3, 5, 8, 13, int(rng.integers(1, 300))]))
             cplx, fused = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -167,12 +170,21 @@ while time.time() < t_end:
             plan = R.OverlapSave(taps, nfft)
             one = lambda v: O.overlap_save(v, taps, nfft)
             n = int(rng.integers(0, nfft + 8 * (nfft - k + 1))); desc = ("ovsave", nfft, k)
-        x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, max(n, 1))[:n]
-        want = one(x) if n else np.zeros(0, x.dtype)
-        st = R.Stream(plan)
-        dx = torch.from_numpy(x).cuda() if n else torch.zeros(0, dtype=torch.complex64 if cplx else torch.float32, device="cuda")
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 12)))]))
-        outs = [st(dx[lo:hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
+        if u8:
+            raw = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+            x = O.data_to_samples(raw) if n else np.zeros(0, np.complex64)
+            want = one(x) if n else np.zeros(0, x.dtype)
+            st = R.Stream(plan, u8=True)
+            draw = torch.from_numpy(raw).cuda() if n else torch.zeros(0, dtype=torch.uint8, device="cuda")
+            outs = [st(draw[2 * lo: 2 * hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
+            desc = desc + ("u8",)
+        else:
+            x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, max(n, 1))[:n]
+            want = one(x) if n else np.zeros(0, x.dtype)
+            st = R.Stream(plan)
+            dx = torch.from_numpy(x).cuda() if n else torch.zeros(0, dtype=torch.complex64 if cplx else torch.float32, device="cuda")
+            outs = [st(dx[lo:hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
         got = torch.cat(outs).cpu().numpy() if outs else np.zeros(0, x.dtype)
         check("stream", got.shape == np.asarray(want).reshape(-1).shape and np.array_equal(bits(got), bits(np.asarray(want).reshape(-1))), desc + (n, cuts))
     elif which == 9:    # src_process drop-in (host buffers, one state, random messages)
