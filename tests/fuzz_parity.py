@@ -192,15 +192,18 @@ while time.time() < t_end:
         conv = int(rng.integers(0, 5)); ch = int(rng.choice([1, 1, 2, 3]))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 2.0, 0.25, 1.0884, 48000 / 44100, 1.5, 0.3, float(rng.uniform(0.01, 3.0))]))
         st, ref, ok = samplerate.State(conv, ch), O.Resampler(conv, ch), True
-        for _ in range(int(rng.integers(1, 5))):
+        nmsg = int(rng.integers(1, 5)); flush = bool(rng.integers(0, 2)); sizes = []
+        for i in range(nmsg):
             m = int(rng.integers(1, 20000)) if rng.integers(0, 4) else int(rng.integers(1, 6))   # now and then a message of a few frames
             x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m * ch)
-            cap = int(ratio * m + 1.0)
-            e1, a, u1 = st.process(x, ratio, cap, 0)
-            e2, b, u2 = ref.process(x, ratio, cap, False)
+            eoi = int(flush and i + 1 == nmsg)                      # the last message may carry end_of_input: the converter drains its tail
+            cap = int(ratio * m + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
+            e1, a, u1 = st.process(x, ratio, cap, eoi)
+            e2, b, u2 = ref.process(x, ratio, cap, bool(eoi))
             ok = ok and (e1, u1, len(a)) == (e2, u2, len(b)) and np.array_equal(bits(a), bits(b))
+            sizes.append(m)
         st.close()
-        check("srcdrop", ok, (conv, ch, ratio))
+        check("srcdrop", ok, (conv, ch, ratio, sizes, flush))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 5))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 48000 / 44100, 1.5, 0.3, 4 / 3, 0.75, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
@@ -211,13 +214,15 @@ while time.time() < t_end:
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 3)] + ([min(n, int(rng.integers(0, n + 1)) + 1)] if rng.integers(0, 2) else [])))
         ok = True
         dx = torch.from_numpy(x).cuda()
+        flush = bool(rng.integers(0, 2))
         for lo, hi in zip(cuts[:-1], cuts[1:]):
-            cap = int(ratio * (hi - lo) + 1.0)
-            a, used = plan.process(dx[:, lo:hi].contiguous(), ratio)
+            eoi = flush and hi == n
+            cap = int(ratio * (hi - lo) + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
+            a, used = plan.process(dx[:, lo:hi].contiguous(), ratio, output_frames=cap, end_of_input=eoi)
             a = a.cpu().numpy()
             for c in range(nch):
-                err, want, wused = refs[c].process(x[c, lo:hi], ratio, cap)
+                err, want, wused = refs[c].process(x[c, lo:hi], ratio, cap, eoi)
                 ok = ok and err == 0 and wused == used and a.shape[1] == len(want) and np.array_equal(bits(a[c]), bits(want))
-        check("src", ok, (nch, conv, ratio, n, cuts))
+        check("src", ok, (nch, conv, ratio, n, cuts, flush))
 print("runs", runs, "failures", fails)
 sys.exit(1 if fails else 0)
