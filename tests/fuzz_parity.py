@@ -197,6 +197,8 @@ while time.time() < t_end:
             m = int(rng.integers(1, 20000)) if rng.integers(0, 4) else int(rng.integers(1, 6))   # now and then a message of a few frames
             x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m * ch)
             eoi = int(flush and i + 1 == nmsg)                      # the last message may carry end_of_input: the converter drains its tail
+            if i and not rng.integers(0, 3):                        # a new ratio now and then: the library glides to it inside the message
+                ratio = float(np.clip(ratio * rng.uniform(0.5, 2.0), 0.01, 3.0))
             cap = int(ratio * m + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
             e1, a, u1 = st.process(x, ratio, cap, eoi)
             e2, b, u2 = ref.process(x, ratio, cap, bool(eoi))
