@@ -142,34 +142,37 @@ def test_exchange_through_the_c_abi_on_every_visible_device(gpu, redio, oracle):
     gpu.cuda.set_device(0)
 
 
-def test_bench_c4_launcher_correctness_half(gpu, redio):
-    """tools/bench_c4.py --check under torch.distributed.run, one rank per visible device (the launcher the 8-GPU node will use:
-    `python -m torch.distributed.run --nproc-per-node 8 tools/bench_c4.py --gpus 8`), exchange through the C ABI (RCCL)."""
+def _torchrun(script_args, ndev, port):
     import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ndev}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + [os.path.join(root, script_args[0])] + script_args[1:]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+
+
+def test_c4_launch_path_correctness_and_bench_tool(gpu, redio):
+    """The launch line the 8-GPU node uses (`python -m torch.distributed.run --nproc-per-node N ...`), one rank per visible device:
+    tests/rank_checks.py c4 compares every rank's regrouped rows (exchange through the C ABI, RCCL) with the oracle's channelizer of the
+    whole stream; then tools/bench_c4.py itself runs at a small size (the tool only measures; it does not know the oracle)."""
+    import os
     ndev = gpu.cuda.device_count()
     while 64 % ndev:
         ndev -= 1
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ndev}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "tools", "bench_c4.py"), "--gpus", str(ndev), "--check"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    out = _torchrun(["tests/rank_checks.py", "c4"], ndev, 29700 + os.getpid() % 200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert '"ok": true' in out.stdout
+    out = _torchrun(["tools/bench_c4.py", "--gpus", str(ndev), "--log2-samples", "22", "--steps", "2", "--warmup", "1"], ndev, 29450 + os.getpid() % 200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert '"analysis_plus_exchange_GSps"' in out.stdout
 
 
 @pytest.mark.parametrize("config", ["c3", "c5"])
-def test_bench_shards_launcher_correctness_half(gpu, redio, config):
-    """tools/bench_shards.py --check under torch.distributed.run, one rank per visible device: the independent-shard configs
+def test_shard_launch_paths_correctness(gpu, redio, config):
+    """tests/rank_checks.py c3 | c5 under torch.distributed.run, one rank per visible device: the independent-shard configs
     (BASELINE configs[2] resampler channels, configs[4] overlap-save blocks; no collective) against the oracle."""
-    import os, subprocess, sys
-    ndev = gpu.cuda.device_count()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ndev}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29900 + os.getpid() % 90 + (7 if config == "c3" else 0)), os.path.join(root, "tools", "bench_shards.py"), config,
-           "--gpus", str(ndev), "--check"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    import os
+    out = _torchrun(["tests/rank_checks.py", config], gpu.cuda.device_count(), 29900 + os.getpid() % 90 + (7 if config == "c3" else 0))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert '"ok": true' in out.stdout
 

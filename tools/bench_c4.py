@@ -6,7 +6,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_c4.py --gpus 8
 
 Prints one JSON line on rank 0: samples/s of the analysis alone and of analysis + exchange (MAX over ranks),
-and the exchange's egress rate per GPU.  Not the headline bench (bench.py is); same timing discipline."""
+and the exchange's egress rate per GPU.  Not the headline bench (bench.py is); same timing discipline.  The correctness half
+of this launch path (every rank's regrouped rows against the oracle) is tests/rank_checks.py c4."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -20,7 +21,6 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="cabi = redio_pfb_exchange (RCCL send/recv group through the C ABI); torch = all_to_all_single")
-    ap.add_argument("--check", action="store_true", help="compare this rank's regrouped rows with the oracle on a short stream and exit")
     ap.add_argument("--pieces", type=int, default=4, help="analyse the slice in this many pieces; the exchange of piece i runs on a second HIP stream "
                                                           "beside the analysis of piece i + 1 (C-ABI exchange only)")
     a = ap.parse_args()
@@ -63,23 +63,6 @@ def main():
     comm = R.Comm.from_torch_distributed() if use_cabi else None
     mine_buf = torch.empty((world * nrows, cpg), dtype=torch.complex64, device="cuda")
     exchange = (lambda g: comm.exchange(g, [nrows] * world, out=mine_buf)) if use_cabi else R.channelizer_all_to_all
-    if a.check:   # correctness half: a short stream, every rank against the oracle's channelizer of the WHOLE stream
-        import numpy as np
-        import oracle as O
-        total_rows = 2000 + 5 * world
-        xs = O.synth_iq(0x5EED0004, 0, M * total_rows)
-        want = O.pfb_channelizer(xs, h, M, P, True)
-        first, nout, nin = sharding.channelizer_time_shard(rank, world, total_rows, P)
-        g = plan(torch.from_numpy(xs[M * first: M * (first + nin)]).cuda(), ngroups=world).reshape(world, nout, cpg)
-        rows = [sharding.channelizer_time_shard(q, world, total_rows, P)[1] for q in range(world)]
-        got = (comm.exchange(g, rows) if use_cabi else R.channelizer_all_to_all(g)).cpu().numpy()
-        ok = np.array_equal(got.view(np.uint32), np.ascontiguousarray(want[:, rank * cpg:(rank + 1) * cpg]).view(np.uint32))
-        flag = torch.tensor([int(ok)], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if rank == 0:
-            print(json.dumps({"check": "channelizer exchange vs oracle", "n_gpus": world, "exchange": a.exchange, "ok": bool(flag.item())}))
-        dist.destroy_process_group()
-        sys.exit(0 if flag.item() else 1)
     # piece-wise pipeline: analysis of piece i + 1 on the compute stream while piece i is exchanged on the communication stream
     def pipelined(xs_all, rows_all, out_all, pieces):
         comm_s = pipelined.stream

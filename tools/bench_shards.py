@@ -5,11 +5,11 @@
 
     python tools/bench_shards.py c5                                                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_shards.py c5 --gpus 8
-    ... tools/bench_shards.py c3 --gpus 8 [--check]
+    ... tools/bench_shards.py c3 --gpus 8
 
 Weak scaling for C5 (every rank owns 2^28 samples of one ever-longer stream), strong for C3 (256 channels in all).  Prints one
-JSON line on rank 0: whole-job rate over the slowest rank's time.  --check: a short stream, every rank's shard compared with the
-oracle's result for the WHOLE stream / all channels, restricted to the shard.  bench.py stays the headline (configs[1])."""
+JSON line on rank 0: whole-job rate over the slowest rank's time.  The correctness half of this launch path (every rank's shard
+against the oracle's result for the whole stream / all channels) is tests/rank_checks.py c3 | c5.  bench.py stays the headline."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--check", action="store_true")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -59,19 +58,6 @@ def main():
         taps = R.dsputils.lpf_corrected(k, 0.02)
         hop = nfft - k + 1
         plan = R.OverlapSave(taps, nfft)
-        if a.check:
-            import oracle as O
-            total = nfft + hop * (3 * world + 1) + 777
-            first, n, first_out, n_out = sharding.overlap_save_shard(rank, world, total, k, nfft)
-            got = plan(R.synth_iq(0x5EED0005, first, n)).cpu().numpy() if n else np.zeros(0, np.complex64)
-            blocks = n_out // hop
-            ok = len(got) == n_out
-            for b in range(blocks):   # every block of this shard against the oracle on its own window of the WHOLE stream
-                want = O.overlap_save(O.synth_iq(0x5EED0005, first_out + hop * b, nfft), taps, nfft)
-                ok = ok and np.array_equal(got[hop * b: hop * (b + 1)].view(np.uint32), want.view(np.uint32))
-            ok = all_ok(ok)
-            if rank == 0: print(json.dumps({"check": "overlap-save shards vs oracle", "n_gpus": world, "ok": ok}))
-            dist.destroy_process_group(); sys.exit(0 if ok else 1)
         n = 1 << 28
         nblk = (n - nfft) // hop + 1
         x = R.synth_iq(0x5EED0005, rank * nblk * hop, n)          # consecutive shards of one ever-longer stream
@@ -86,22 +72,6 @@ def main():
     else:
         nch_all, ratio = 256, 0.02
         first_ch, nch = sharding.channel_shard(rank, world, nch_all)
-        if a.check:
-            import oracle as O
-            n = 60000
-            x = np.stack([O.synth_f32(0x5EED0003 + c, 0, n) for c in range(first_ch, first_ch + nch)]) if nch else np.zeros((0, n), np.float32)
-            ok = True
-            if nch:
-                plan = R.Src(nch, 1)
-                got = np.concatenate([plan.process(torch.from_numpy(x[:, lo:hi]).contiguous().cuda(), ratio)[0].cpu().numpy()
-                                      for lo, hi in ((0, 25001), (25001, n))], axis=1)
-                for c in range(0, nch, max(1, nch // 4)):
-                    ref = O.Resampler(1)
-                    want = np.concatenate([ref.block(x[c, lo:hi], ratio) for lo, hi in ((0, 25001), (25001, n))])
-                    ok = ok and np.array_equal(got[c].view(np.uint32), want.view(np.uint32))
-            ok = all_ok(ok)
-            if rank == 0: print(json.dumps({"check": "resampler channel shards vs oracle", "n_gpus": world, "ok": ok}))
-            dist.destroy_process_group(); sys.exit(0 if ok else 1)
         frames = 1 << 20
         x = torch.stack([R.synth_f32(0x5EED0003 + c, 0, frames) for c in range(first_ch, first_ch + nch)])
         plan = R.Src(nch, 1)
