@@ -7,7 +7,7 @@
 
 Prints one JSON line on rank 0: samples/s of the analysis alone and of analysis + exchange (MAX over ranks),
 and the exchange's egress rate per GPU.  Not the headline bench (bench.py is); same timing discipline.  The correctness half
-of this launch path (every rank's regrouped rows against the oracle) is tests/rank_checks.py c4."""
+of this launch path lives with the tests: tests/rank_checks.py c4."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

@@ -9,7 +9,7 @@
 
 Weak scaling for C5 (every rank owns 2^28 samples of one ever-longer stream), strong for C3 (256 channels in all).  Prints one
 JSON line on rank 0: whole-job rate over the slowest rank's time.  The correctness half of this launch path (every rank's shard
-against the oracle's result for the whole stream / all channels) is tests/rank_checks.py c3 | c5.  bench.py stays the headline."""
+against the CPU restatement's result for the whole stream / all channels) lives with the tests: tests/rank_checks.py c3 | c5.  bench.py stays the headline."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
