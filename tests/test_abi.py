@@ -100,3 +100,24 @@ def test_missing_library_fails_loudly(tmp_path):
         "sys.exit(7)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "LOUD" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_oracle_is_test_infrastructure_only():
+    """The CPU restatement under oracle/ is the checker, never the product: nothing in the package, the headers or the tools may
+    import, load or link it -- only tests/, __graft_entry__.smoke() / build() and bench.py's cpu_baseline leg do."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(import oracle|from oracle)\b|libredio_oracle|oracle/_build|orc_[a-z_]+\(", re.M)
+    offenders = []
+    for sub in ("libredio_amd", "include", "tools"):
+        for dirpath, dirnames, files in os.walk(os.path.join(root, sub)):
+            dirnames[:] = [d for d in dirnames if not d.startswith("_build") and d != "__pycache__" and d != "exp"]
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".sh")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    if pat.search(text):
+                        offenders.append(os.path.relpath(os.path.join(dirpath, f), root))
+    assert not offenders, offenders
+    bench = open(os.path.join(root, "bench.py")).read()
+    body = bench[bench.index("def cpu_baseline"): bench.index("def main")]
+    assert bench.count("import oracle") == 1 and "import oracle" in body      # bench.py: the cpu_baseline leg only
