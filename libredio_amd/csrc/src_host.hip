@@ -642,7 +642,7 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
     while (input_index < 1.0 && out_gen < out_count) {
         if (lin ? (samples(in_used) + chd * (1.0 + input_index) >= samples(in_count)) : (samples(in_used) + chd * input_index >= samples(in_count))) break;
         if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
-            src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
+            src_ratio = f->last_ratio + samples(out_gen) * (src_ratio_arg - f->last_ratio) / samples(out_count); // the library's out_gen / out_count count samples
         f->h_pos[(size_t)out_gen] = -1;
         f->h_scale[(size_t)out_gen] = input_index;
         ++out_gen;
@@ -653,7 +653,7 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
     input_index = rem;
     while (out_gen < out_count && (lin ? (samples(in_used) + chd * input_index < samples(in_count)) : (samples(in_used) + chd * input_index <= samples(in_count)))) {
         if (out_count > 0 && fabs(f->last_ratio - src_ratio_arg) > 1e-20)
-            src_ratio = f->last_ratio + out_gen * (src_ratio_arg - f->last_ratio) / out_count;
+            src_ratio = f->last_ratio + samples(out_gen) * (src_ratio_arg - f->last_ratio) / samples(out_count); // the library's out_gen / out_count count samples
         f->h_pos[(size_t)out_gen] = (int)(in_used - 1);
         f->h_scale[(size_t)out_gen] = input_index;
         ++out_gen;

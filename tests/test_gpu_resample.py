@@ -395,3 +395,26 @@ def test_batched_rows_zoh_linear_are_mono_streams(gpu, redio, oracle):
                     err, want, wused = refs[c].process(x[c], ratio, cap)
                     assert err == 0 and wused == used and a.shape[1] == len(want), (conv, nch, m, c)
                     assert np.array_equal(bits(a[c]), bits(want)), (conv, nch, m, c)
+
+
+@pytest.mark.gpu
+def test_linear_converter_three_channels_ratio_glide(gpu, redio, oracle):
+    """Found by tests/fuzz_parity.py (seed 20261003): when the ratio changes between messages the library glides to it inside the
+    message, src_ratio = last_ratio + out_gen * (new - last) / out_count with out_gen / out_count counted in SAMPLES; with three
+    interleaved channels the frame form of that quotient rounds differently.  The failing sequences of that run, converters 4 and 3."""
+    from libredio_amd import samplerate
+    cases = [([5675, 14488, 17186], [3.0, 3.0, 1.7]), ([15986, 2, 19949], [1.3503012770611056, 0.9, 1.3503012770611056]),
+             ([17927, 11446, 6927, 16542], [0.6108250699566179, 0.4, 1.1, 0.6108250699566179]),
+             ([8552, 17184, 17207, 7138], [1.4500575425380535, 2.2, 0.8, 1.4500575425380535]), ([10706, 3461, 1281, 11305], [3.0, 1.5, 3.0, 2.9])]
+    for conv in (4, 3):
+        for ch in (3, 5, 2):
+            for sizes, ratios in cases:
+                st, ref = samplerate.State(conv, ch), oracle.Resampler(conv, ch)
+                for m, ratio in zip(sizes, ratios):
+                    x = oracle.synth_f32(31 + m, 0, m * ch)
+                    cap = int(ratio * m + 1.0)
+                    e1, a, u1 = st.process(x, ratio, cap, 0)
+                    e2, b, u2 = ref.process(x, ratio, cap, False)
+                    assert (e1, u1, len(a)) == (e2, u2, len(b)), (conv, ch, sizes, m)
+                    assert np.array_equal(bits(a), bits(b)), (conv, ch, sizes, m)
+                st.close()
