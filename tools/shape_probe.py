@@ -13,7 +13,7 @@ import libredio_amd as R
 kind, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 26)
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
-x = R.synth_iq(1, 0, n) if kind != "src" else None
+x = R.synth_iq(1, 0, n) if kind not in ("src", "u8chain") else None
 if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference rounding (multiply and add rounded separately)
     cplx = kind in ("fir", "firx")
     if not cplx:
@@ -21,6 +21,12 @@ if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference r
     plan = R.Fir(R.dsputils.lpf_corrected(a, 0.4 / b if b > 1 else 0.2), b, complex_input=cplx, fused=kind in ("fir", "firr"))
     out = torch.empty(plan.nout(n), dtype=x.dtype, device="cuda")
     run = lambda: plan(x, out=out)
+elif kind == "u8chain":   # the north-star chain from u8 I/Q bytes (a, b ignored)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    raw = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    plan = R.Chain(R.dsputils.lpf_corrected(127, 0.08), 5, 1024, fused=True)
+    out = torch.empty((plan.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
+    run = lambda: plan.from_bytes(raw, out=out)
 elif kind == "src":   # a = channels, b = log2 frames per channel; ratio 1/50 (BASELINE.json configs[2])
     xr = torch.stack([R.synth_f32(100 + c, 0, 1 << b) for c in range(a)])
     plan = R.Src(a, 1)
