@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run of the device kernels against the CPU oracle (bit-exact), beyond the fixed cases
-of tests/: python tests/fuzz_parity.py [seconds] [seed].  Prints one line per failure and a summary."""
+of tests/: python tests/fuzz_parity.py [seconds] [seed]  (FUZZ_ONLY=5,9 restricts the run to those branches: here the two resampler ones).  Prints one line per failure and a summary."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 fails, runs = 0, {}
+ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]   # e.g. FUZZ_ONLY=5,9: the two resampler branches only
 
 
 def check(name, ok, detail):
@@ -23,7 +24,7 @@ def check(name, ok, detail):
 
 t_end = time.time() + budget
 while time.time() < t_end:
-    which = rng.integers(0, 12)
+    which = rng.integers(0, 12) if not ONLY else int(rng.choice(ONLY))
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000)), int(rng.integers(2000, 20000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
