@@ -13,7 +13,10 @@
  *   - libsamplerate (system -lsamplerate, src/samplerate/src/samplerate.rs:32, version unpinned).
  *                Restated from the published libsamplerate 0.1.8 src_sinc.c mono algorithm; its
  *                coefficient tables cannot be reproduced, so the table is a stated
- *                Kaiser-windowed sinc of the same shape (see orc_src_*).
+ *                Kaiser-windowed sinc of the same shape (see orc_src_*).  Converters 3 / 4 follow src_zoh.c / src_linear.c
+ *                (interleaved channels, the library's own sample-unit arithmetic); the one place where the published code reads
+ *                before its input array (a single-frame message, in_used == 0 in the main loop) is DEFINED here as the value
+ *                carried from the previous message.  Multi-channel sinc conversion is defined as one mono conversion per channel.
  * The oracle is pinned instead by (i) float64 numpy/scipy cross-checks and known-answer tests in
  * tests/test_oracle_*.py and (ii) the committed fixtures in tests/golden/.
  *
