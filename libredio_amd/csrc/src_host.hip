@@ -95,7 +95,7 @@ struct redio_src {
     // uniform-phase fast path: interpolated coefficients of the current increment, far end first
     std::vector<float> h_coeffs;
     int fast_inc;
-    double *d_cl, *d_cr;
+    double *d_cl, *d_cr, *d_tabs; // tables inside ONE guarded allocation (d_tabs)
     int ncl, ncr;
     float2 *d_T2; int nm; double fast_scale; // packed f32 tap pairs of the polyphase path
     // periodic-phase path (rational ratios): per-epoch tables [tap][phase] on the device, host copies kept until the call ends
@@ -158,7 +158,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->d_coeffs = nullptr; s->d_buf[0] = s->d_buf[1] = nullptr;
     s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
     s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0; s->host_stream = nullptr;
-    s->fast_inc = 0; s->d_cl = s->d_cr = nullptr; s->ncl = s->ncr = 0;
+    s->fast_inc = 0; s->d_cl = s->d_cr = s->d_tabs = nullptr; s->ncl = s->ncr = 0;
     s->d_pL = s->d_pR = nullptr; s->pL_cap = s->pR_cap = 0; s->d_pint = nullptr; s->period_hint = 0;
     s->h_pos = s->h_start = s->h_inc = nullptr; s->h_scale = nullptr; s->h_arena = nullptr; s->arena_cap = s->arena_used = 0;
     s->periodic_launches = s->general_launches = s->tile_launches = 0;
@@ -195,7 +195,7 @@ extern "C" int redio_src_destroy(redio_src *s)
     hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
     hipFree(s->d_stage_in); hipFree(s->d_stage_out);
     if (s->host_stream) hipStreamDestroy(s->host_stream);
-    hipFree(s->d_cl); hipFree(s->d_cr); hipFree(s->d_T2);
+    hipFree(s->d_tabs); hipFree(s->d_T2);
     hipFree(s->d_pL); hipFree(s->d_pR); hipFree(s->d_pint);
     hipFree(s->d_last); hipFree(s->d_rows_in); hipFree(s->d_rows_out);
     if (s->h_pos) hipHostFree(s->h_pos);
@@ -335,12 +335,21 @@ static int prepare_uniform(redio_src *f, int inc)
     };
     for (int t = 0; t <= cl; ++t) L[(size_t)t] = icoeff((cl - t) * inc);          // far end first
     for (int t = 0; t <= cr; ++t) R[(size_t)t] = icoeff((cr - t) * inc + inc);
-    hipFree(f->d_cl); hipFree(f->d_cr);
-    f->d_cl = f->d_cr = nullptr; f->fast_inc = 0;
-    SRC_TRY(hipMalloc((void **)&f->d_cl, L.size() * sizeof(double)));
-    SRC_TRY(hipMalloc((void **)&f->d_cr, R.size() * sizeof(double)));
-    SRC_TRY(hipMemcpy(f->d_cl, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
-    SRC_TRY(hipMemcpy(f->d_cr, R.data(), R.size() * sizeof(double), hipMemcpyHostToDevice));
+    // ONE allocation [guard | L | guard | R | guard] of zeros around the tables: the register-blocked kernel's ramp steps
+    // load coefficient runs that start up to 3*S + 16 entries before a table and end as far behind it (src_core.h)
+    const size_t guard = 4 * 256 + 32; // the uniform-phase paths take S <= 256
+    hipFree(f->d_tabs);
+    f->d_tabs = nullptr; f->d_cl = f->d_cr = nullptr; f->fast_inc = 0;
+    std::vector<double> all(3 * guard + L.size() + R.size(), 0.0);
+    std::copy(L.begin(), L.end(), all.begin() + (long)guard);
+    std::copy(R.begin(), R.end(), all.begin() + (long)(2 * guard + L.size()));
+    SRC_TRY(hipMalloc((void **)&f->d_tabs, all.size() * sizeof(double)));
+    SRC_TRY(hipMemcpy(f->d_tabs, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
+    f->d_cl = f->d_tabs + guard;
+    f->d_cr = f->d_tabs + 2 * guard + L.size();
+    // at zero phase the right wing starts one increment in and R[t] == L[t] bit for bit over its whole length: both wings
+    // then walk ONE table (half the scalar-cache footprint, and the wavefronts of a workgroup share every line they load)
+    if (R.size() + 1 == L.size() && memcmp(R.data(), L.data(), R.size() * sizeof(double)) == 0 && !getenv("REDIO_SRC_TWO_TABLES")) f->d_cr = f->d_cl;
     f->ncl = cl + 1; f->ncr = cr + 1; f->fast_inc = inc;
     hipFree(f->d_T2); f->d_T2 = nullptr; f->nm = 0; // rebuilt on demand for the new increment
     return REDIO_OK;

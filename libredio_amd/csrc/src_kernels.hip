@@ -15,6 +15,7 @@
 // Bound: VALU (about 91 multiply-adds plus two table reads and a lerp per input sample at ratio
 // 1/50); the window and table reads are served by L1/L2.
 #include "redio_internal.h"
+#include "src_core.h"
 
 namespace redio {
 
@@ -568,6 +569,109 @@ __global__ __launch_bounds__(NT) void src_window_exact_kernel(SrcWindow w, const
     out[(long)ch * out_stride + k0 + tid] = (float)(scale * (left + right));
 }
 
+// Tile loader of the register-blocked kernel: sample n of the tile goes to xs[n + P*(n / B)] (PAD) or xs[n].  The
+// window [old image | new input] changes its source at ONE tile index, so the tile is three runs -- old image, new
+// input, zeros behind `need` (samples that belong to no valid output and may not exist) -- each walked with a
+// wave-uniform base pointer and a 32-bit lane index: per sample one address add, one coalesced load, one LDS store
+// (src_tile_load pays a 64-bit pointer select, a clamp and a pad cursor per sample: 12 % of the kernel's vector
+// instructions at 1/50).  U loads per thread are in flight before the first store.
+template <int NT, int U, bool PAD>
+__device__ __forceinline__ void src_rb_tile_load(float *xs, const SrcWindow &w, int ch, long tile_base, int span, int need, int B, int P)
+{
+    const int tid = threadIdx.x;
+    const long ns = w.a_in0 - tile_base;
+    const int nsplit = ns < 0 ? 0 : (ns < need ? (int)ns : need);
+    const float *src[2] = {w.old_img + (long)ch * w.old_stride + tile_base, w.input + (long)ch * w.in_stride + (tile_base - w.a_in0)};
+    const int lo[3] = {0, nsplit, need}, hi[3] = {nsplit, need, span};
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const int n1 = hi[part];
+        int n = lo[part] + tid;
+        int q = PAD ? n / B : 0, r = PAD ? n - q * B : 0; // n = q*B + r
+        const int dq = PAD ? NT / B : 0, dr = PAD ? NT - dq * B : 0;
+        const float *base = src[part < 2 ? part : 0];
+        auto step_pad = [&]() { if (PAD) { q += dq; r += dr; if (r >= B) { r -= B; ++q; } } };
+        for (; n + (U - 1) * NT < n1; n += NT * U) { // whole rounds: U loads in flight, no per-sample bound check
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = part < 2 ? base[n + u * NT] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xs[n + u * NT + (PAD ? P * q : 0)] = v[u]; step_pad(); }
+        }
+        for (; n < n1; n += NT) { xs[n + (PAD ? P * q : 0)] = part < 2 ? base[n] : 0.0f; step_pad(); }
+    }
+}
+
+// ---- register-blocked single-launch uniform-phase kernel (round 3) -------------------------------------------------
+// src_window_exact_kernel gives a lane ONE output: every tap pays its own ds_read_b32 and its own v_cvt_f64_f32 although
+// neighbouring outputs share all but S samples of their windows, and the lane stride S (50 floats) puts pairs of lanes
+// on one bank.  Here a lane owns ONE WING of R consecutive outputs (src_core.h): one ds_read_b128 and four conversions
+// feed 4*R taps.  The LDS holds about 730 outputs' worth of samples per CU whatever the lane assignment, so R outputs
+// per lane would leave 1/R of the waves; the two wings of an output are independent sums (they meet only in
+// scale * (left + right)), so they go to two lanes and the wave count stays: LW lanes per wing, tile of LW*R outputs,
+// waves [0, LW/64) run left wings, the rest right wings, the right sums cross through LDS.  Bit-identical to
+// src_window_exact_kernel and to oracle/oracle_src.c (tests/test_gpu_resample.py; lane program on the CPU:
+// tests/test_emu_lane_programs.py).
+template <int R, int U, int LW>
+__global__ __launch_bounds__(2 * LW) void src_window_rb_kernel(SrcWindow w, const double *__restrict__ Lt, int ncl,
+                                                               const double *__restrict__ Rt, int ncr, long a0, int S, double scale,
+                                                               float *__restrict__ out, long out_stride, long nout)
+{
+    constexpr int NO = LW * R, NT = 2 * LW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *rsum = reinterpret_cast<double *>(smem);             // [NO] right-wing sums
+    float *xs = reinterpret_cast<float *>(smem + NO * sizeof(double));
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const long k0 = (long)blockIdx.x * NO;
+    const int cl = ncl - 1, cr = ncr - 1;
+    const int B = R * S, P = src_rb_pad(B);
+    const long tile_base = a0 + (long)S * k0 - cl;
+    const int span = (NO - 1) * S + cl + cr + 2;
+    const long nvalid = (nout - k0 < NO) ? nout - k0 : NO;
+    const int need = (int)((nvalid - 1) * S) + cl + cr + 2;
+    if (P) src_rb_tile_load<NT, 8, true>(xs, w, ch, tile_base, span, need, B, P);
+    else src_rb_tile_load<NT, 8, false>(xs, w, ch, tile_base, span, need, B, P);
+    __syncthreads();
+    const bool right = tid >= LW; // wave-uniform
+    const int q = right ? tid - LW : tid;
+    const float *lane_xs = xs + q * (B + P);
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    if ((long)(q & ~63) * R < nvalid) { // a wave whose outputs all lie past the end has nothing to do
+        if (right) src_rb_wing<R, U, -1>(lane_xs, B, P, (R - 1) * S + cl + 1 + cr, Rt, ncr, S, acc);
+        else src_rb_wing<R, U, +1>(lane_xs, B, P, 0, Lt, ncl, S, acc);
+    }
+    if (right) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rsum[q * R + (R - 1 - r)] = acc[r];
+    }
+    __syncthreads();
+    if (!right) {
+        float *o = out + (long)ch * out_stride + k0 + (long)q * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((long)q * R + r < nvalid) o[r] = (float)(scale * (acc[r] + rsum[q * R + r]));
+    }
+}
+
+// which register blocking serves (S, taps): 0 = none (the one-output-per-lane kernel runs)
+int src_rb_choose(int S, int ncl, int ncr)
+{
+    const int forced = getenv("REDIO_SRC_RB") ? atoi(getenv("REDIO_SRC_RB")) : -1; // measurement only: 0 = off, 2 / 4 = that blocking
+    if (forced == 0) return 0;
+    const int nmin = ncl < ncr ? ncl : ncr;
+    const int cand[2] = {forced == 4 ? 4 : 2, forced == 2 ? 2 : 4};
+    for (int i = 0; i < 2; ++i) {
+        const int R = cand[i];
+        if ((R * S) % 4 != 0) continue;
+        if ((R - 1) * S + 24 > nmin) continue; // the ramps must be short next to the wing
+        if ((size_t)src_rb_tile_floats(256, R, S, ncl - 1, ncr - 1) * sizeof(float) + 256 * sizeof(double) > 78 * 1024) continue; // two tiles per CU
+        return R;
+    }
+    return 0;
+}
+
 typedef float src_v2f __attribute__((ext_vector_type(2))); // one 64-bit register pair (v_pk_fma_f32 operand)
 
 // ---- f32 polyphase decimator (REDIO_SRC_FAST): the same uniform-phase filter as ONE real FIR
@@ -693,6 +797,21 @@ hipError_t launch_src_window(const float *old_img, long old_stride, const float 
     }
             if (padded) LAUNCH_F(true) else LAUNCH_F(false)
 #undef LAUNCH_F
+        } else if (const int RB = src_rb_choose(S, ncl, ncr)) {
+            const bool wide = RB == 2 && getenv("REDIO_SRC_RB_WIDE") && atoi(getenv("REDIO_SRC_RB_WIDE")) &&
+                              (size_t)src_rb_tile_floats(640, 2, S, cl, cr) * sizeof(float) + 640 * sizeof(double) <= 160 * 1024; // measurement only
+            const int NOt = wide ? 640 : 256;
+            const size_t b = (size_t)src_rb_tile_floats(NOt, RB, S, cl, cr) * sizeof(float) + NOt * sizeof(double);
+            dim3 grid((unsigned)((nout + NOt - 1) / NOt), (unsigned)nchan);
+#define LAUNCH_RB(R, U, LW)                                                                                                       \
+    {                                                                                                                             \
+        auto kern = src_window_rb_kernel<R, U, LW>;                                                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b); \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(2 * LW), b, s, w, cl_rev, ncl, cr_rev, ncr, a0, S, scale, out, out_stride, nout);     \
+    }
+            if (RB == 2 && wide) LAUNCH_RB(2, 8, 320) else if (RB == 2) LAUNCH_RB(2, 8, 128) else LAUNCH_RB(4, 4, 64)
+#undef LAUNCH_RB
         } else {
             const int cand[3] = {256, 128, 64};
             bool done = false;

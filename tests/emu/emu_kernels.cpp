@@ -336,3 +336,55 @@ extern "C" long emu_src_advance_mismatches(const double *x, const double *step, 
     }
     return bad;
 }
+
+// the register-blocked uniform-phase resampler lane program (libredio_amd/csrc/src_core.h): one tile, every lane of both
+// wings, on an LDS image built as the kernel builds it -- slack floats and table guard zones filled with NaN, so a
+// sample or coefficient that belongs to no tap of an output cannot reach it unnoticed.  out_ref: the plain per-output
+// sums in the order calc_output_single (libsamplerate 0.1.8) runs them.
+#include "../../libredio_amd/csrc/src_core.h"
+template <int R, int U>
+static void emu_src_rb_t(const float *xt, const double *L, int ncl, const double *Rt, int ncr, int S, int NO, double scale, float *out)
+{
+    const int cl = ncl - 1, cr = ncr - 1, c = cl + 1 + cr, B = R * S, P = redio::src_rb_pad(B), LW = NO / R;
+    const long span = (long)(NO - 1) * S + cl + cr + 2;
+    const double qnan = nan("");
+    std::vector<float> xs((size_t)redio::src_rb_tile_floats(NO, R, S, cl, cr), nanf(""));
+    for (long n = 0; n < span; ++n) xs[(size_t)(n + P * (n / B))] = xt[n];
+    const int guard = (R - 1) * S + 2 * U;
+    std::vector<double> Lg((size_t)(ncl + 2 * guard), qnan), Rg((size_t)(ncr + 2 * guard), qnan);
+    memcpy(Lg.data() + guard, L, sizeof(double) * (size_t)ncl);
+    memcpy(Rg.data() + guard, Rt, sizeof(double) * (size_t)ncr);
+    std::vector<double> rsum((size_t)NO);
+    for (int q = 0; q < LW; ++q) {
+        double acc[R];
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        redio::src_rb_wing<R, U, -1>(xs.data() + (size_t)q * (B + P), B, P, (R - 1) * S + c, Rg.data() + guard, ncr, S, acc);
+        for (int r = 0; r < R; ++r) rsum[(size_t)(q * R + (R - 1 - r))] = acc[r];
+    }
+    for (int q = 0; q < LW; ++q) {
+        double acc[R];
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        redio::src_rb_wing<R, U, +1>(xs.data() + (size_t)q * (B + P), B, P, 0, Lg.data() + guard, ncl, S, acc);
+        for (int r = 0; r < R; ++r) out[q * R + r] = (float)(scale * (acc[r] + rsum[(size_t)(q * R + r)]));
+    }
+}
+
+extern "C" int emu_src_rb(const float *xt, const double *L, int ncl, const double *Rt, int ncr, int S, int R, int U, int NO, double scale,
+                          float *out, float *out_ref)
+{
+    const int cl = ncl - 1, cr = ncr - 1, c = cl + 1 + cr;
+    for (int o = 0; o < NO; ++o) {
+        double left = 0.0, right = 0.0;
+        for (int t = 0; t <= cl; ++t) left += L[t] * (double)xt[(long)S * o + t];
+        for (int t = 0; t <= cr; ++t) right += Rt[t] * (double)xt[(long)S * o + c - t];
+        out_ref[o] = (float)(scale * (left + right));
+    }
+    if ((R * S) % 4 != 0 || NO % R != 0) return -1;
+    if (R == 2 && U == 8) emu_src_rb_t<2, 8>(xt, L, ncl, Rt, ncr, S, NO, scale, out);
+    else if (R == 2 && U == 4) emu_src_rb_t<2, 4>(xt, L, ncl, Rt, ncr, S, NO, scale, out);
+    else if (R == 4 && U == 4) emu_src_rb_t<4, 4>(xt, L, ncl, Rt, ncr, S, NO, scale, out);
+    else if (R == 4 && U == 8) emu_src_rb_t<4, 8>(xt, L, ncl, Rt, ncr, S, NO, scale, out);
+    else if (R == 8 && U == 4) emu_src_rb_t<8, 4>(xt, L, ncl, Rt, ncr, S, NO, scale, out);
+    else return -1;
+    return 0;
+}

@@ -91,3 +91,36 @@ def test_resampler_position_recurrence_short_form(emu):
     ratios = np.array([48000 / 44100, 2.0, 1.5, 4 / 3, 1.0884, 2 ** 0.5, 3.7, 256.0, 1.0, 0.3, 0.02, 0.0213], dtype=np.float64)
     x0 = np.zeros(len(ratios))
     assert emu.emu_src_advance_mismatches(x0.ctypes.data, (1.0 / ratios).ctypes.data, len(ratios), 2000000) == 0
+
+
+@pytest.mark.parametrize("R,U", [(2, 8), (2, 4), (4, 4), (4, 8), (8, 4)])
+@pytest.mark.parametrize("S,ncl,ncr", [(50, 2285, 2284), (2, 93, 92), (4, 184, 183), (8, 367, 366), (16, 733, 732), (3, 139, 138), (1, 47, 46),
+                                      (6, 97, 91), (50, 970, 969), (10, 458, 458)])
+def test_resampler_register_blocked_wings(emu, R, U, S, ncl, ncr):
+    """src_core.h: a lane owns one wing of R consecutive outputs and walks the union of their windows once; every
+    accumulator must still receive exactly its own products in the library's order (libsamplerate 0.1.8
+    calc_output_single, behind samplerate.rs:59-87).  Compared bit for bit with the plain per-output sums, with NaN in
+    every slack float and guard entry, and with Inf / NaN samples in the stream: an output whose window does not
+    contain them must not see them."""
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+    emu.emu_src_rb.argtypes = [f32p, f64p, C.c_int, f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, f32p]
+    emu.emu_src_rb.restype = C.c_int
+    if (R * S) % 4 or (R - 1) * S + U + 8 > min(ncl, ncr):
+        pytest.skip("shape not served by the register-blocked kernel")
+    NO = 64 * R if S <= 16 else 8 * R
+    rng = np.random.default_rng(S * 131 + R * 7 + U)
+    span = (NO - 1) * S + ncl + ncr
+    L = rng.standard_normal(ncl)
+    Rt = rng.standard_normal(ncr)
+    for poison in (False, True):
+        x = rng.standard_normal(span).astype(np.float32)
+        if poison:
+            x[rng.integers(0, S)] = np.inf          # inside the window of the first output only
+            x[span - 1 - rng.integers(0, S)] = np.nan  # inside the window of the last output only
+        out = np.zeros(NO, np.float32)
+        ref = np.zeros(NO, np.float32)
+        assert emu.emu_src_rb(x, L, ncl, Rt, ncr, S, R, U, NO, 0.02, out, ref) == 0
+        assert np.array_equal(bits(out), bits(ref)), (R, U, S, poison, np.flatnonzero(bits(out) != bits(ref))[:8])
+        if poison:
+            assert not np.isfinite(ref[0]) and not np.isfinite(ref[-1]) and np.isfinite(ref[1:-1]).all()
