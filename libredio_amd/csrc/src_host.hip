@@ -98,6 +98,7 @@ struct redio_src {
     double *d_cl, *d_cr, *d_tabs; // tables inside ONE guarded allocation (d_tabs)
     int ncl, ncr;
     float2 *d_T2; int nm; double fast_scale; // packed f32 tap pairs of the polyphase path
+    float *d_Hp; int fastp_nc;               // the same taps per phase, [S][src_fastp_row(fastp_nc)]; fastp_nc = tap pairs per phase of the kernel instantiation
     // periodic-phase path (rational ratios): per-epoch tables [tap][phase] on the device, host copies kept until the call ends
     double *d_pL, *d_pR; size_t pL_cap, pR_cap;
     int *d_pint; // dpos | skipL | skipR, 256 each
@@ -162,7 +163,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->d_pL = s->d_pR = nullptr; s->pL_cap = s->pR_cap = 0; s->d_pint = nullptr; s->period_hint = 0;
     s->h_pos = s->h_start = s->h_inc = nullptr; s->h_scale = nullptr; s->h_arena = nullptr; s->arena_cap = s->arena_used = 0;
     s->periodic_launches = s->general_launches = s->tile_launches = 0;
-    s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1; s->zl_channels = 1;
+    s->d_T2 = nullptr; s->nm = 0; s->fast_scale = 0.0; s->d_Hp = nullptr; s->fastp_nc = 0; s->mode = REDIO_SRC_EXACT; s->window_ok = 1; s->zl_channels = 1;
     s->h_coeffs = coeffs;
     if (zl) {
         s->b_len = 0; s->buf_stride = 0;
@@ -195,7 +196,7 @@ extern "C" int redio_src_destroy(redio_src *s)
     hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
     hipFree(s->d_stage_in); hipFree(s->d_stage_out);
     if (s->host_stream) hipStreamDestroy(s->host_stream);
-    hipFree(s->d_tabs); hipFree(s->d_T2);
+    hipFree(s->d_tabs); hipFree(s->d_T2); hipFree(s->d_Hp);
     hipFree(s->d_pL); hipFree(s->d_pR); hipFree(s->d_pint);
     hipFree(s->d_last); hipFree(s->d_rows_in); hipFree(s->d_rows_out);
     if (s->h_pos) hipHostFree(s->h_pos);
@@ -352,6 +353,7 @@ static int prepare_uniform(redio_src *f, int inc)
     if (R.size() + 1 == L.size() && memcmp(R.data(), L.data(), R.size() * sizeof(double)) == 0 && !getenv("REDIO_SRC_TWO_TABLES")) f->d_cr = f->d_cl;
     f->ncl = cl + 1; f->ncr = cr + 1; f->fast_inc = inc;
     hipFree(f->d_T2); f->d_T2 = nullptr; f->nm = 0; // rebuilt on demand for the new increment
+    hipFree(f->d_Hp); f->d_Hp = nullptr; f->fastp_nc = 0;
     return REDIO_OK;
 }
 
@@ -375,6 +377,16 @@ static int prepare_fast_taps(redio_src *f, int S, double scale)
     SRC_TRY(hipMalloc((void **)&f->d_T2, T.size() * sizeof(float2)));
     SRC_TRY(hipMemcpy(f->d_T2, T.data(), T.size() * sizeof(float2), hipMemcpyHostToDevice));
     f->nm = nm; f->fast_scale = scale;
+    // the same taps by phase for the phase-split kernel: Hp[p][j] = H[S*j + p], zero filled to whole chunks of 32 taps
+    hipFree(f->d_Hp); f->d_Hp = nullptr;
+    f->fastp_nc = src_fastp_pairs(S, KH);
+    if (f->fastp_nc > 0) {
+        const int ntap = src_fastp_row(f->fastp_nc);
+        std::vector<float> P((size_t)S * ntap, 0.0f);
+        for (int m = 0; m < KH; ++m) P[(size_t)(m % S) * ntap + m / S] = H[(size_t)m];
+        SRC_TRY(hipMalloc((void **)&f->d_Hp, P.size() * sizeof(float)));
+        SRC_TRY(hipMemcpy(f->d_Hp, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return REDIO_OK;
 }
 
@@ -611,7 +623,7 @@ static int try_uniform_window(redio_src *f, const SrcInput &in, long in_count, f
     long j0 = (long)b_current - half, j1 = b_end;
     if (j0 < 0) j0 = 0;
     hipError_t e = launch_src_window(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, f->d_cl, f->ncl, f->d_cr, f->ncr,
-                                     f->d_T2, f->nm, fast, a_first < 0 ? 0 : a_first, S, scale, d_out, out_stride, out_gen, f->nchan,
+                                     f->d_T2, f->nm, f->d_Hp, f->fastp_nc, fast, a_first < 0 ? 0 : a_first, S, scale, d_out, out_stride, out_gen, f->nchan,
                                      A0, j0, j1, f->d_buf[other], st);
     if (e == hipErrorNotSupported) return 0;
     if (e != hipSuccess) return hip_rc(e);

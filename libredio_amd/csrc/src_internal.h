@@ -22,9 +22,12 @@ hipError_t launch_src_tile(const float *old_img, long old_stride, const float *i
 hipError_t launch_src_window_image(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0, long A0f, long j0, long j1,
                                    float *new_img, int nchan, hipStream_t s);
 hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,
-                             const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, bool fast,
-                             long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,
+                             const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, const float *Hp, int fastp_nc,
+                             bool fast, long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,
                              long A0f, long j0, long j1, float *new_img, hipStream_t s);
+// f32 polyphase path, phase-split kernel: tap pairs per phase of the instantiation that serves the shape (0: none), floats per table row
+int src_fastp_pairs(int S, int KH);
+int src_fastp_row(int npair);
 hipError_t launch_src_copy_rows(const float *src, long src_stride, long src_off, float *dst, long dst_stride, long dst_off,
                                 long n, int nchan, hipStream_t s);
 hipError_t launch_src_fill_rows(float *dst, long dst_stride, long dst_off, long n, int nchan, float v, hipStream_t s);

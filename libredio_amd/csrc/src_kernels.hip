@@ -754,6 +754,206 @@ __global__ __launch_bounds__(64 * SRC_FAST_WAVES) void src_window_fast_kernel(Sr
     }
 }
 
+// ---- f32 polyphase decimator, phase-split (round 3; REDIO_SRC_FAST, tolerance-tested, NOT bit-identical) ------------
+// out[o] = sum_m H[m] * x[S*o + m] with m = S*j + p is, for every phase p, a NON-decimating FIR over the phase's own
+// sample stream X_p[n] = x[S*n + p] with the taps H_p[j] = H[S*j + p] (about 92 of them at any S: the filter stretches
+// with S).  The sum over the S phases is order-free here, so the K-split goes over PHASES: the W wavefronts of a
+// workgroup share one tile of 512 outputs and take the phases p = w, w + W, ... each; no wavefront has a ramp, none
+// reads a tap that is not its own.  A lane owns R = 8 consecutive outputs.  Per phase it reads the 8 + taps samples its
+// outputs see into registers ONCE and runs the taps as v_pk_fma_f32 with the tap as a wave-uniform SGPR operand
+// broadcast to both halves: one scalar register feeds 8 multiply-adds (the tap-range K-split of
+// src_window_fast_kernel needs a scalar register PAIR per packed multiply-add and is bound by scalar-load latency).
+// Packed operands must be even-aligned register pairs E[a] = (X[2a], X[2a+1]): even taps run on the output pairs
+// (0,1) .. (6,7) (accA), odd taps on the pairs (-1,0) .. (7,8) (accB, whose two outer halves are discarded): 9 packed
+// instructions per 16 multiply-adds.
+// A workgroup is persistent over TPW consecutive tiles of one channel: the NEXT tile's samples are requested into registers
+// (PF per thread) before the current tile's arithmetic and stored to the LDS image after it, so the HBM time of a tile --
+// 120 KB at the 10 B/clk a CU gets, as long as half the arithmetic -- runs under the arithmetic of the tile before it (the
+// image fills the LDS: a second workgroup per CU cannot provide that overlap).  Eight wavefronts = two per SIMD.
+// LDS image: tile sample n = (8*q + k)*S + p (k < 8) sits in float cell 2*(((k/2)*S + p)*NCOL + q) + k%2: the samples
+// X_p[8*q + i], X_p[8*q + i + 1] (i even) a lane multiplies as one packed operand are ONE aligned 8-byte cell, column
+// q + i/8 of row (i%8/2)*S + p -- four row bases per phase, the column step an immediate, consecutive lanes on consecutive
+// bank pairs: conflict-free ds_read_b64, no pad, no per-read address arithmetic.
+template <int NPAIR> // tap pairs per phase (the table rows are zero filled to whole chunks of 16 pairs)
+struct SrcFastP {
+    static constexpr int R = 8, W = 8, PF = 64, NC = (NPAIR + 15) / 16, NTAP = 32 * NC, NE = NPAIR + R / 2, NI = 2 * NE; // NE packed pairs = NI window samples per lane and phase
+    static constexpr int NCOL = 64 + (NI + R - 1) / R;                                                // columns of the image
+    static constexpr int NGROUPS = 63 * R + NI;                                                       // groups of S samples (n = g*S + p, g = 8*q + k) a lane can read from
+    static size_t lds_bytes(int S) { return ((size_t)R * S * NCOL + (size_t)W * 64 * R + 4) * sizeof(float); } // image, partial sums, a spare cell
+    static bool fits(int S) { return S >= 2 && S <= 64 * W && (NGROUPS + (64 * W) / S - 1) / ((64 * W) / S) <= PF && lds_bytes(S) <= 160 * 1024; }
+};
+
+template <int NPAIR>
+__global__ __launch_bounds__(64 * SrcFastP<NPAIR>::W) void src_window_fastp_kernel(SrcWindow w, const float *__restrict__ Hp, int KH, int cl, long a0, int S,
+                                                                               float *__restrict__ out, long out_stride, long nout, int TPW)
+{
+    using G = SrcFastP<NPAIR>;
+    constexpr int R = G::R, W = G::W, PF = G::PF, NC = G::NC, NO = 64 * R, NT = 64 * W, NTAP = G::NTAP, NE = G::NE, NCOL = G::NCOL, NGROUPS = G::NGROUPS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);   // [4*S rows][NCOL] cells of two floats
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    float *red = xs + R * S * NCOL;                // [W][NO] partial sums
+    const src_v2f *xs2 = reinterpret_cast<const src_v2f *>(xs);
+    const long ntiles = (nout + NO - 1) / NO;
+    const long t0 = (long)blockIdx.x * TPW;
+    const int ntile = (int)(ntiles - t0 < TPW ? ntiles - t0 : TPW);
+    // loader mapping: a thread keeps ONE phase.  With GI = NT / S groups per round, thread t < GI*S holds sample pl = t % S of
+    // group g = t / S + GI*round, round < PF: n and the cell advance by constants, (q, k) = (g / 8, g % 8) by (GI / 8, GI % 8)
+    const int GI = NT / S, pl = tid % S, g0 = tid / S;
+    const bool active = tid < GI * S;
+    float pf[PF];
+    // Requests go through buffer descriptors whose range check returns 0.0f for everything at or behind `need` (samples that
+    // belong to no valid output and may not exist), for the other source of a tile that straddles [old image | new input], and
+    // for the rounds past the image: no per-sample branch, one 32-bit offset per request.
+    auto prefetch = [&](long tile) {
+        const long k0 = tile * NO, tile_base = a0 + (long)S * k0 - cl;
+        const long nvalid = (nout - k0 < NO) ? nout - k0 : NO;
+        const int need = (int)((nvalid - 1) * S) + KH;
+        const long ns = w.a_in0 - tile_base;
+        const int nsplit = ns < 0 ? 0 : (ns < need ? (int)ns : need); // [0, nsplit): old image, [nsplit, need): new input
+        const float *src_old = w.old_img + (long)ch * w.old_stride + tile_base, *src_new = w.input + (long)ch * w.in_stride + (tile_base - w.a_in0) + nsplit;
+        const auto r_old = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src_old), 0, nsplit * 4, 0x00020000);
+        const auto r_new = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src_new), 0, (need - nsplit) * 4, 0x00020000);
+        unsigned off0 = active ? 4u * (unsigned)(g0 * S + pl) : 0x80000000u;
+        const unsigned doff = 4u * (unsigned)(GI * S), split4 = 4u * (unsigned)nsplit;
+        int gl = g0;
+        asm volatile("" : "+v"(off0), "+v"(gl)); // per tile: the 64 request offsets are recomputed from this one, not kept alive across the tile loop
+        if (nsplit == 0 || nsplit >= need) { // ONE source
+            const auto r = nsplit == 0 ? r_new : r_old;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const unsigned off = gl + GI * u < NGROUPS ? off0 + doff * u : 0x80000000u;
+                pf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+            }
+        } else { // the one tile of a call that straddles the two sources: both descriptors, eight samples at a time
+#pragma unroll
+            for (int u0 = 0; u0 < PF; u0 += 8) {
+                unsigned a_[8], b_[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned off = gl + GI * (u0 + u) < NGROUPS ? off0 + doff * (u0 + u) : 0x80000000u;
+                    a_[u] = __builtin_amdgcn_raw_buffer_load_b32(r_old, off, 0, 0);
+                    b_[u] = __builtin_amdgcn_raw_buffer_load_b32(r_new, off - split4, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pf[u0 + u] = __builtin_bit_cast(float, a_[u] | b_[u]); // one of the two is out of its range: +0.0f
+                RD_SCHED_BARRIER();
+            }
+        }
+    };
+    auto store_image = [&]() { // the requested samples -> the LDS image (waits for them)
+        if (!active) return;
+        // group g = 8*q + k -> byte address 8*(((k/2)*S + pl)*NCOL + q) + 4*(k%2).  g advances by GI per round, so k returns after
+        // eight rounds with q advanced by GI: eight addresses from g alone (24-bit multiply-add, shifts), then one add per store;
+        // a round past the image stores into the spare cell behind the partial sums
+        unsigned gg = (unsigned)g0;
+        asm volatile("" : "+v"(gg)); // per tile: the addresses are recomputed from this, not kept alive across the tile loop
+        const unsigned rowbytes = 8u * (unsigned)(S * NCOL), base = 8u * (unsigned)(pl * NCOL), spare = (unsigned)((R * S * NCOL + W * NO) * sizeof(float));
+        unsigned a8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned g = gg + (unsigned)(GI * u);
+            a8[u] = __umul24((g >> 1) & 3u, rowbytes) + base + ((g >> 3) << 3) + ((g & 1u) << 2);
+        }
+        char *lds = smem;
+        const unsigned step = 8u * (unsigned)GI, glimit = (unsigned)NGROUPS - gg; // store u is inside the image iff GI*u < glimit
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const unsigned addr = (unsigned)(GI * u) < glimit ? a8[u % 8] + step * (unsigned)(u / 8) : spare;
+            *reinterpret_cast<float *>(lds + addr) = pf[u];
+        }
+    };
+    if (ntile > 0) { prefetch(t0); store_image(); }
+    __syncthreads();
+    for (int ti = 0; ti < ntile; ++ti) {
+        const long k0 = (t0 + ti) * NO;
+        const long nvalid = (nout - k0 < NO) ? nout - k0 : NO;
+        if (ti + 1 < ntile) prefetch(t0 + ti + 1); // in flight during this tile's arithmetic
+        src_v2f accA[R / 2], accB[R / 2 + 1];
+#pragma unroll
+        for (int c = 0; c < R / 2; ++c) accA[c] = src_v2f{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c <= R / 2; ++c) accB[c] = src_v2f{0.f, 0.f};
+        // One software pipeline over all (phase, chunk of 32 taps) steps of the wavefront: the next step's 16 tap pairs are
+        // requested (scalar loads) before the current step's 144 packed multiply-adds and land after them; a window register is
+        // dead once the tap pair with its own index has run, and is refilled on the spot with the NEXT phase's sample pair, so
+        // the LDS reads of a phase travel under the arithmetic of the phase before it at no cost in registers.
+        if (wave < S) {
+            src_v2f E[NE], hc[16];
+            {
+                const src_v2f *hp = reinterpret_cast<const src_v2f *>(Hp + (long)wave * NTAP);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) hc[m] = hp[m];
+#pragma unroll
+                for (int a = 0; a < NE; ++a) E[a] = xs2[((a % (R / 2)) * S + wave) * NCOL + lane + a / (R / 2)];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) asm volatile("" : "+s"(hc[m]));
+            }
+            for (int p = wave; p < S; p += W) {
+                const int pn = p + W < S ? p + W : p; // the phase after this one (the last refills with itself: never used)
+                const src_v2f *rown[R / 2];           // (X_pn[8*q + i], X_pn[8*q + i + 1]) = rown[i % 8 / 2][i / 8], i even
+#pragma unroll
+                for (int kk = 0; kk < R / 2; ++kk) rown[kk] = xs2 + (kk * S + pn) * NCOL + lane;
+                const src_v2f *hp = reinterpret_cast<const src_v2f *>(Hp + (long)p * NTAP), *hpn = reinterpret_cast<const src_v2f *>(Hp + (long)pn * NTAP);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    src_v2f hn[16];
+                    const src_v2f *nextc = c + 1 < NC ? hp + 16 * (c + 1) : hpn;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) hn[m] = nextc[m];
+                    RD_SCHED_BARRIER();
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int a0i = 16 * c + m; // index of the tap pair (2*a0i, 2*a0i + 1) and of the window pair its first output pair reads
+                        if (a0i >= NPAIR) continue; // zero fill of the table row
+                        const src_v2f he = __builtin_shufflevector(hc[m], hc[m], 0, 0), ho = __builtin_shufflevector(hc[m], hc[m], 1, 1);
+#pragma unroll
+                        for (int ca = 0; ca < R / 2; ++ca) accA[ca] = __builtin_elementwise_fma(E[ca + a0i], he, accA[ca]);
+#pragma unroll
+                        for (int cb = 0; cb <= R / 2; ++cb) accB[cb] = __builtin_elementwise_fma(E[cb + a0i], ho, accB[cb]);
+                        E[a0i] = rown[a0i % (R / 2)][a0i / (R / 2)];
+                        if (a0i == NPAIR - 1) {
+#pragma unroll
+                            for (int a = NPAIR; a < NE; ++a) E[a] = rown[a % (R / 2)][a / (R / 2)];
+                        }
+                        if (m % 4 == 3) RD_SCHED_BARRIER();
+                    }
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) { asm volatile("" : "+s"(hn[m])); hc[m] = hn[m]; }
+                }
+            }
+        }
+        float *myred = red + wave * NO + lane * R;
+#pragma unroll
+        for (int c = 0; c < R / 2; ++c) {
+            myred[2 * c] = accA[c].x + accB[c].y;
+            myred[2 * c + 1] = accA[c].y + accB[c + 1].x;
+        }
+        __syncthreads(); // every wavefront is done with this tile's image; the partial sums are complete
+        for (int t = tid; t < NO; t += NT) {
+            float sum = red[t];
+            for (int q = 1; q < W; ++q) sum = add_rn(sum, red[q * NO + t]);
+            if (t < nvalid) out[(long)ch * out_stride + k0 + t] = sum;
+        }
+        if (ti + 1 < ntile) store_image();
+        __syncthreads(); // the next tile's image is in place; the partial sums are free
+    }
+}
+
+// tap pairs per phase the f32 polyphase phase-split kernel is built for (>= the shape's); 0: the kernel does not serve the shape
+#define REDIO_FASTP_SHAPES(X) X(16) X(20) X(24) X(32) X(40) X(46) X(48)
+int src_fastp_pairs(int S, int KH)
+{
+    if (getenv("REDIO_SRC_FASTP") && !atoi(getenv("REDIO_SRC_FASTP"))) return 0; // measurement only
+    const int npair = ((KH + S - 1) / S + 1) / 2;
+#define X(N) if (npair <= N) return SrcFastP<N>::fits(S) ? N : 0;
+    REDIO_FASTP_SHAPES(X)
+#undef X
+    return 0;
+}
+int src_fastp_row(int npair) { return 32 * ((npair + 15) / 16); } // floats per phase row of the tap table
+
 // rebuild the library's buffer image after a single-launch call: dst[j] = window(A0 + j), j in [j0, j1)
 __global__ __launch_bounds__(256) void src_window_image_kernel(SrcWindow w, long A0, long j0, long j1, float *__restrict__ dst, long dst_stride)
 {
@@ -772,14 +972,32 @@ hipError_t launch_src_window_image(const float *old_img, long old_stride, const 
 }
 
 hipError_t launch_src_window(const float *old_img, long old_stride, const float *input, long in_stride, long a_in0,
-                             const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, bool fast,
-                             long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,
+                             const double *cl_rev, int ncl, const double *cr_rev, int ncr, const float2 *T2, int nm, const float *Hp, int fastp_nc,
+                             bool fast, long a0, int S, double scale, float *out, long out_stride, long nout, int nchan,
                              long A0f, long j0, long j1, float *new_img, hipStream_t s)
 {
     SrcWindow w = {old_img, old_stride, input, in_stride, a_in0};
     const int cl = ncl - 1, cr = ncr - 1;
     if (nout > 0) {
-        if (fast) {
+        if (fast && Hp && fastp_nc > 0) {
+            const int KH = ncl + ncr;
+            // tiles per (persistent) workgroup: a channel's tiles in equal runs, about two workgroups per CU in all (one is resident)
+            const long ntiles = (nout + 511) / 512;
+            long splits = 512 / nchan;
+            splits = splits < 1 ? 1 : (splits > ntiles ? ntiles : splits);
+            const long tpw = (ntiles + splits - 1) / splits;
+            dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), (unsigned)nchan);
+#define LAUNCH_FP(N)                                                                                                              \
+    if (fastp_nc == N) {                                                                                                          \
+        auto kern = src_window_fastp_kernel<N>;                                                                                   \
+        const size_t lds = SrcFastP<N>::lds_bytes(S);                                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * SrcFastP<N>::W), lds, s, w, Hp, KH, cl, a0, S, out, out_stride, nout, (int)tpw); \
+    }
+            REDIO_FASTP_SHAPES(LAUNCH_FP)
+#undef LAUNCH_FP
+        } else if (fast) {
             const int KH = ncl + ncr;
             const bool padded = (S % 2) == 0;
             const long span = 126L * S + nm;

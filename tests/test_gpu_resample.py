@@ -216,6 +216,35 @@ def test_fast_mode_error_bound_and_state(gpu, redio, oracle):
     assert np.array_equal(bits(a.cpu().numpy()), bits(b.cpu().numpy()))
 
 
+@pytest.mark.parametrize("S", [2, 3, 4, 5, 7, 8, 10, 16, 25, 32, 50, 53, 64])
+@pytest.mark.parametrize("conv,nch", [(1, 1), (1, 3), (2, 2)])
+def test_fast_mode_phase_split_kernel_over_decimations(gpu, redio, oracle, S, conv, nch):
+    """REDIO_SRC_FAST at ratio 1/S through the phase-split polyphase kernel (src_window_fastp_kernel: persistent tiles of 512
+    outputs, eight phase groups, packed f32 multiply-adds) and, for the shapes it does not serve, the tap-range kernel:
+    same frame counts as EXACT (samplerate.rs:59-87 drives both), values inside the f32 bound, across messages whose
+    seams fall inside a tile, for one and several channels and two converters."""
+    ratio = 1.0 / S
+    n = 300 * S * 7 + 4001
+    x = np.stack([oracle.synth_f32(700 + 13 * S + c, 0, n) for c in range(nch)])
+    d = gpu.from_numpy(x).cuda()
+    exact, fast = redio.Src(nch, conv), redio.Src(nch, conv, mode=redio.Src.FAST)
+    tab, half, inc = oracle.src_table(conv)
+    pos = np.arange(0.0, half, inc * ratio)
+    K = 2 * len(pos)
+    sum_h = 2 * ratio * np.abs(np.interp(pos, np.arange(half + 2), tab.astype(np.float64))).sum()
+    bound = (K + 1) * 2.0 ** -24 * max(sum_h, 1.0) * np.abs(x).max()
+    cuts = [0, 600 * S + 7, 600 * S + 8, n // 2 + 3, n]
+    total = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        a, ua = exact.process(d[:, lo:hi].contiguous(), ratio)
+        b, ub = fast.process(d[:, lo:hi].contiguous(), ratio)
+        assert ua == ub and a.shape == b.shape, (S, lo, hi)
+        total += a.shape[1]
+        if a.numel():
+            assert (a - b).abs().max().item() <= bound, (S, lo, hi)
+    assert total > 600
+
+
 def test_c3_256_channels_two_messages(gpu, redio, oracle):
     """BASELINE.json configs[2] at its channel count: 256 independent mono states (samplerate.rs:61), 2.4 MS/s -> 48 kS/s
     (ratio 0.02), 2^18 frames per channel in two messages of unequal length.  EXACT is bit-identical to the oracle on

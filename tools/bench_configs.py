@@ -82,9 +82,11 @@ if "c3" in which or "c3big" in which:
         tab_half, tab_inc = 22438 - 2, 491
         taps_per_out = 2 * int(tab_half / (tab_inc * 0.02)) + 1
         tap_waves = nch * frames * 0.02 * taps_per_out / 64
-        # EXACT: 13.3 cycle-equivalents per tap-wave measured for cvt + mul + add back to back (tools/valu_rate_f64.hip,
-        # profiles/r02_c3_experiments.txt; the three instructions issue in 4.3-5.7 cycles each); FAST: one 4-cycle v_pk_fma_f32 per two taps
-        cyc = 13.3 if mode != R.Src.FAST else 2
+        # EXACT: issue cost of the tap's instructions measured back to back at two waves per SIMD (tools/valu_rate_f64.hip,
+        # profiles/r02_c3_experiments.txt): v_cvt_f64_f32 6.2, v_mul_f64 5.0, v_add_f64 4.6 cycle-equivalents at 2.4 GHz.  The
+        # one-launch kernel shares a conversion between the two outputs of a lane (round 3): 6.2 / 2 + 5.0 + 4.6 = 12.7 per tap-wave;
+        # the per-refill kernel converts per tap: 13.3 (its measured three-instruction figure).  FAST: one 4-cycle v_pk_fma_f32 per two taps
+        cyc = 2 if mode == R.Src.FAST else (12.7 if mode == R.Src.EXACT else 13.3)
         t_valu = tap_waves * cyc / 1024 / 2.4e9
         t_hbm = b / 8e12
         bound = "VALU f64" if mode != R.Src.FAST else "VALU f32"

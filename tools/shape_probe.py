@@ -2,7 +2,7 @@
 """Run ONE plan shape a few times (for rocprofv3 passes on a secondary kernel):
     python3 tools/shape_probe.py fir|firr|firx|firrx K D [log2n] [launches]
     python3 tools/shape_probe.py pfb M P [log2n] [launches]
-    python3 tools/shape_probe.py src CHANNELS LOG2FRAMES
+    python3 tools/shape_probe.py src|srcfast CHANNELS LOG2FRAMES
     python3 tools/shape_probe.py fft N 0 [log2n] [launches]
 Prints the HIP-event mean per launch."""
 import sys, os
@@ -13,7 +13,7 @@ import libredio_amd as R
 kind, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 26)
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
-x = R.synth_iq(1, 0, n) if kind not in ("src", "u8chain") else None
+x = R.synth_iq(1, 0, n) if kind not in ("src", "srcfast", "u8chain") else None
 if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference rounding (multiply and add rounded separately)
     cplx = kind in ("fir", "firx")
     if not cplx:
@@ -27,9 +27,9 @@ elif kind == "u8chain":   # the north-star chain from u8 I/Q bytes (a, b ignored
     plan = R.Chain(R.dsputils.lpf_corrected(127, 0.08), 5, 1024, fused=True)
     out = torch.empty((plan.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
     run = lambda: plan.from_bytes(raw, out=out)
-elif kind == "src":   # a = channels, b = log2 frames per channel; ratio 1/50 (BASELINE.json configs[2])
+elif kind in ("src", "srcfast"):   # a = channels, b = log2 frames per channel; ratio 1/50 (BASELINE.json configs[2]); srcfast: REDIO_SRC_FAST
     xr = torch.stack([R.synth_f32(100 + c, 0, 1 << b) for c in range(a)])
-    plan = R.Src(a, 1)
+    plan = R.Src(a, 1, mode=R.Src.FAST if kind == "srcfast" else R.Src.EXACT)
     n = a << b
     def run():
         plan.reset(); plan.process(xr, 0.02)
