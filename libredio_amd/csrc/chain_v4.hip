@@ -5,6 +5,9 @@
 //     640 x 16 B = 10 loads per lane of NEW samples;
 //   * the FIR results stay in registers in the operand layout of the one-wave 1024-point transform.
 // Bit-exact with the oracle (FIR fold order of dsputils.rs:30-32, kissfft butterfly order).
+#ifndef REDIO_EXP_CHAIN_NT
+#define REDIO_EXP_CHAIN_NT 3 // bit 0: non-temporal stream loads, bit 1: non-temporal spectrum stores (fft_wave.h)
+#endif
 #include "fir_core.h"
 #include "fft_wave.h"
 #include "redio_internal.h"
@@ -67,10 +70,22 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     pair_t pre[NLD];
     auto fetch = [&](long j) { // new samples of sub-tile j: [HALO + j*SUB_NEW, HALO + (j+1)*SUB_NEW)
         const pair_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
+        // the stream is read once: non-temporal loads (round 3: read streams run 5-9 % faster with them on this part,
+        // profiles/r03_stream_probe3.txt; -DREDIO_EXP_CHAIN_NT=0 builds the default-policy form for comparison)
+#if REDIO_EXP_CHAIN_NT & 1
+        static_for4<NLD>([&](auto I) { pre[I.value] = __builtin_nontemporal_load(src + 64 * I.value); });
+#else
         static_for4<NLD>([&](auto I) { pre[I.value] = src[64 * I.value]; });
+#endif
     };
     auto park = [&]() {
+#if REDIO_EXP_ABLATE == 3 // timing-only experiment (tools/chain_variants.sh; results WRONG): the loads stay, the ten ds_write_b128 that
+                          // park them in the image do not -- an upper bound on what staging by LDS-DMA instead of registers could buy
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) { pair_t keep = pre[i]; asm volatile("" : : "v"(keep)); }
+#else
         static_for4<NLD>([&](auto I) { xs4[G::lds_index(HALO + 2 * (lane + 64 * I.value)) / 2] = samples(pre[I.value]); });
+#endif
     };
 
     // prologue: the head (the only halo this wave ever fetches) and the first sub-tile
@@ -151,9 +166,15 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     // half empty, and the launch ends when the most crowded CU does (measured: wave lifetimes 320-570 us).
     constexpr size_t LDS = (160 * 1024 / (4 * WPS)) - 480 > LDS_NEED ? (160 * 1024 / (4 * WPS)) - 480 : LDS_NEED;
     static_assert((4 * WPS + 1) * LDS > 160 * 1024, "one more wave must not fit");
+    // Short runs in dispatch order, not one long run per residency slot: the wavefronts resident at any moment then read one
+    // compact window of the stream (2048 x 4 blocks = 335 MB apart at most, instead of 2048 places spread over all of it).
+    // Measured with non-temporal accesses 0.533 -> 0.517 ms per 2^28 samples (profiles/r03_chain_variants.txt); a run
+    // re-fetches its 122-sample head: 0.6 % more reads at four blocks per run.
     long waves = 4L * WPS * num_cus();
     if (waves > nblocks) waves = nblocks;
-    const long bpw = (nblocks + waves - 1) / waves;
+    long bpw = (nblocks + waves - 1) / waves;
+    if (bpw > 4) bpw = 4;
+    if (const char *e = getenv("REDIO_CHAIN_BPW")) { const long v = atol(e); if (v >= 1) bpw = v; } // measurement only: blocks per wavefront
     const long grid = (nblocks + bpw - 1) / bpw;
     if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
     else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);

@@ -103,7 +103,14 @@ __device__ __forceinline__ void fft1kn_wave_tw(float2 (&a)[16], float2 *ex, cons
 #pragma unroll
     for (int k0 = 0; k0 < 4; ++k0)
 #pragma unroll
+#if defined(REDIO_EXP_CHAIN_NT) && (REDIO_EXP_CHAIN_NT & 2) // the fused chain writes its spectra once (chain_v4.hip sets this before including the header)
+        for (int k1 = 0; k1 < 4; ++k1) {
+            typedef float nt_v2f __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(nt_v2f{a[k1 + 4 * k0].x, a[k1 + 4 * k0].y}, reinterpret_cast<nt_v2f *>(dst + ln + 64 * k1 + 256 * k0));
+        }
+#else
         for (int k1 = 0; k1 < 4; ++k1) dst[ln + 64 * k1 + 256 * k0] = a[k1 + 4 * k0];
+#endif
 }
 
 // the same with the 30 lane-dependent twiddles loaded here (callers that transform many blocks load them
