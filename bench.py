@@ -16,7 +16,9 @@ sample (8 B read + 8/5 B written) over the kernel's mean duration 
 events on the launch stream; `launch_ms_series` are those per-launch times.  The chip raises its clock over the first
 ~100 launches of a burst, so after the headline the same launch is repeated `--steady` more times (default 1000) and
 reported as `steady_state` with its own kernel time and fraction -- never as `value`.  `roofline.traffic` comes from
-the rocprofv3 PMC passes of a separate run (`traffic_source`).  `cpu_baseline` is the CPU oracle (oracle/, a port of
+the rocprofv3 PMC passes of a separate run (`traffic_source`); `roofline.valu` prices the same launch against the f32 vector peak
+(report min(HBM, VALU)); `stages` times the FIR alone and the transform alone; for N > 1 `ranks_seen` lists the
+world size and every rank's device as torch.distributed saw them.  `cpu_baseline` is the CPU oracle (oracle/, a port of
 the reference's algorithm) timed on this host on a bounded sample: all cores as independent replicas (`value`), one
 core, and the reference's own structure -- a thread per block with a heap Vec per message (`kpn_pipeline`).
 """
@@ -50,7 +52,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=23, help="slice per CPU thread")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
     return ap.parse_args()
 
 
@@ -262,6 +264,52 @@ def main():
         lib.redio_event_destroy(e1)
         del raw
 
+    # outside the timed region ("C2 also reported stage-by-stage"): the chain's two stages as kernels of their own --
+    # the decimating FIR alone (8 + 8/5 B per input sample) and the 1024-point transform alone on the decimated blocks (8 + 8 B per
+    # sample it transforms) -- 20 warm-up + 50 timed launches each
+    stages = None
+    if not a.exact and not a.unfused:
+        def timed(f, warm=20, reps=50):
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            R.check(lib.redio_event_create(C.byref(e0)))
+            R.check(lib.redio_event_create(C.byref(e1)))
+            for _ in range(warm):
+                f()
+            R.check(lib.redio_event_record(e0, stream))
+            for _ in range(reps):
+                f()
+            R.check(lib.redio_event_record(e1, stream))
+            torch.cuda.synchronize()
+            ms = C.c_float()
+            R.check(lib.redio_event_elapsed_ms(e0, e1, C.byref(ms)))
+            lib.redio_event_destroy(e0)
+            lib.redio_event_destroy(e1)
+            return ms.value / reps
+        fir = R.Fir(taps, DECIM, fused=True)
+        y = torch.empty(fir.nout(n), dtype=torch.complex64, device="cuda")
+        fir_ms = timed(lambda: fir(x, out=y))
+        fft = R.Fft(NFFT)
+        yb = y[: nblk * NFFT]
+        fft_ms = timed(lambda: fft(yb, out=out.view(-1)))
+        stages = {"fir_only_ms": fir_ms, "fir_only_frac": ALG_BYTES_PER_SAMPLE * n / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "fir_only_bytes_per_input_sample": ALG_BYTES_PER_SAMPLE,
+                  "fft_only_ms": fft_ms, "fft_only_frac": 16.0 * nblk * NFFT / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "fft_only_bytes_per_transformed_sample": 16.0,
+                  "note": "the two stages as kernels of their own on the same data (FIR 127 taps / 5 over the 2^%d input samples; forward 1024-point "
+                          "transform of its %d decimated blocks); as separate kernels the chain moves 12.8 B per input sample, fused 9.6" % (a.log2_samples, nblk)}
+        del y
+
+    ranks_seen = None
+    if dist is not None:
+        p = torch.cuda.get_device_properties(dev_index)
+        me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": p.name,
+              "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1) & 0xFF, getattr(p, "pci_device_id", 0)),
+              "uuid": str(getattr(p, "uuid", ""))}
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, me)
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": a.backend, "devices": seen,
+                      "distinct_devices": len({(d["pci"], d["uuid"]) for d in seen})}
+
     if rank == 0:
         kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
@@ -289,7 +337,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": kavg * 1e3,
-                         "frac_of_measured_copy_6290": ach / 6290.0},
+                         "frac_of_measured_copy_6290": ach / 6290.0,
+                         # "report min(HBM, VALU) honestly": 4K/D = 101.6 (FIR, complex samples x real taps) + 5 log2(1024) / 5 = 10
+                         # (transform on the decimated stream) flops per input sample against the 157.3 TFLOP/s f32 vector peak
+                         "valu": {"flops_per_sample": 4.0 * NTAPS / DECIM + 5.0 * 10 / DECIM, "tflops": (4.0 * NTAPS / DECIM + 10.0) * used / kavg / 1e12,
+                                  "peak_tflops": 157.3, "frac_of_157": (4.0 * NTAPS / DECIM + 10.0) * used / kavg / 1e12 / 157.3},
+                         "binding": "hbm" if ach / HBM_PEAK_GBS >= (4.0 * NTAPS / DECIM + 10.0) * used / kavg / 1e12 / 157.3 else "valu"},
             "launch_ms_series": [round(v, 4) for v in (kms if len(kms) <= 128 else kms[:32] + kms[32::max(1, len(kms) // 96)])],
         }
         if steady is not None:
@@ -311,10 +364,12 @@ def main():
                                     "note": "the same chain from interleaved u8 I/Q bytes (rtlsdr::data_to_samples folded into the kernel's "
                                             "loader, redio_chain_enqueue_u8): 2 + 1.6 bytes per sample, VALU-bound; a different input "
                                             "format from BASELINE.json configs[1] (f32 IQ), so beside value, never as value"}
-        if not a.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(a.cpu_log2_samples)
-        else:
-            rec["cpu_baseline"] = None
+        if stages is not None:
+            rec["stages"] = stages
+        if ranks_seen is not None:
+            rec["ranks_seen"] = ranks_seen
+        # rank 0 only, also at N > 1 (the other ranks have nothing left to do; they wait in destroy_process_group)
+        rec["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline(a.cpu_log2_samples)
         print(json.dumps(rec))
     if dist is not None:
         dist.destroy_process_group()

@@ -10,8 +10,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libredio_oracle.so")
-_KPN_SO = os.path.join(_HERE, "_build", "libredio_kpn_baseline.so")
+# REDIO_ORACLE_SAN=1: the AddressSanitizer + UBSan build (make -C oracle SAN=1; the process needs libasan preloaded: tests/san_check.sh)
+_SAN = os.environ.get("REDIO_ORACLE_SAN") == "1"
+_BUILD = os.path.join(_HERE, "_build_san" if _SAN else "_build")
+_SO = os.path.join(_BUILD, "libredio_oracle.so")
+_KPN_SO = os.path.join(_BUILD, "libredio_kpn_baseline.so")
 
 
 def build(force=False):
@@ -19,7 +22,7 @@ def build(force=False):
     if (not force and os.path.exists(_SO) and os.path.exists(_KPN_SO) and os.path.getmtime(_KPN_SO) >= os.path.getmtime(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
-    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["SAN=1"] if _SAN else []))
     return _SO
 
 

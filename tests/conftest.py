@@ -23,8 +23,9 @@ def oracle():
 @pytest.fixture(scope="session")
 def emu():
     import ctypes as C
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-s"])
-    return C.CDLL(os.path.join(ROOT, "tests", "_build", "libemu.so"))
+    san = os.environ.get("REDIO_ORACLE_SAN") == "1"  # tests/san_check.sh: the AddressSanitizer + UBSan build of the lane programs
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-s"] + (["SAN=1"] if san else []))
+    return C.CDLL(os.path.join(ROOT, "tests", "_build", "libemu_san.so" if san else "libemu.so"))
 
 
 @pytest.fixture(scope="session")

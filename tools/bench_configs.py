@@ -173,7 +173,12 @@ if "firshapes" in which:
         ms = timeit(lambda: plan(x, out=out), n=5, warm=2)
         b = (8 if cplx else 4) * (1 + 1 / d)
         fl = (4 if cplx else 2) * k / d
-        print(f"FIR K={k} D={d} {'cf32' if cplx else 'f32'}: {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  {b*m/ms/1e6/8000:.1%} of HBM roofline, {fl*m/ms/1e9:.1f} TFLOP/s")
+        # min(HBM, VALU) with the binding one named: the shape's floor is the larger of its HBM time (8 TB/s) and its
+        # multiply-add time (157.3 TFLOP/s f32 vector peak)
+        t_hbm, t_valu = b * m / 8e12 * 1e3, fl * m / 157.3e12 * 1e3
+        bind = "HBM" if t_hbm >= t_valu else "VALU"
+        print(f"FIR K={k} D={d} {'cf32' if cplx else 'f32'}: {ms:.3f} ms  {m/ms/1e6:.1f} GS/s  {b*m/ms/1e6/8000:.1%} of HBM roofline, {fl*m/ms/1e9:.1f} TFLOP/s "
+              f"({fl*m/ms/1e9/157.3:.1%} of 157.3) -> binding = {bind}, achieved {max(t_hbm, t_valu)/ms:.1%} of it")
 if "u8chain" in which:
     # the receiver's format in: u8 I/Q bytes -> data_to_samples -> 127-tap FIR / 5 -> 1024-point FFT, one kernel against two
     from libredio_amd import bitfount as B
