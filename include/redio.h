@@ -266,8 +266,12 @@ int redio_pfb_exchange_all(redio_comm *const *comms, int ndev, const void *const
  *     ovsave: block b -> hop outputs, blocks every hop samples from the stream start
  * enqueue() writes *nout (= redio_*_stream_nout(h, n_new), known before the call) output samples to d_out; the new
  * samples are read in place (only a seam of fewer than one window is staged through a plan-owned buffer).  It only
- * launches kernels and small device copies; host-side counters advance at call time, so feed one stream from one
- * thread in order.  Not graph-capturable (the split changes from call to call).  pending() = samples carried. */
+ * launches kernels and small device copies -- with one exception: a plan shape that runs as two kernels (redio_chain_is_fused() == 0,
+ * or a body that starts on an odd sample) keeps a plan-owned intermediate that *_stream_create sizes for the seam windows and
+ * that grows on a longer body: call redio_chain_reserve(plan, largest message) once to keep enqueue allocation-free.
+ * The host-side counters advance only when every kernel of the call has been launched (a failed call can be repeated); feed one
+ * stream from one thread in order -- a call that finds another thread inside enqueue() / reset() of the same handle returns
+ * REDIO_ERR_ARG.  Not graph-capturable (the split changes from call to call).  pending() = samples carried. */
 typedef struct redio_fir_stream redio_fir_stream;
 int redio_fir_stream_create(redio_fir_stream **h, redio_fir *plan);
 int redio_fir_stream_destroy(redio_fir_stream *h);

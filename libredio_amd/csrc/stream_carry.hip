@@ -20,6 +20,7 @@
 #include "../../include/redio.h"
 #include "redio_internal.h"
 #include "stream_split.h"
+#include <atomic>
 #include <new>
 
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : REDIO_ERR_HIP_BASE - (int)e; }
@@ -39,6 +40,13 @@ struct Carry {
     size_t hist = 0;                      // samples of the stream's tail held in d_s[cur]
     size_t skip = 0;                      // H > W only: samples still to be dropped before the next unit starts (then hist == 0)
     unsigned long long total_in = 0, total_units = 0;
+    std::atomic_flag busy = ATOMIC_FLAG_INIT; // one thread at a time inside enqueue / reset
+};
+struct Entered { // holds Carry::busy for the life of a call
+    std::atomic_flag *f;
+    explicit Entered(Carry *c) : f(c->busy.test_and_set(std::memory_order_acquire) ? nullptr : &c->busy) {}
+    ~Entered() { if (f) f->clear(std::memory_order_release); }
+    bool ok() const { return f != nullptr; }
 };
 
 // what a call with n new samples does, given c.hist carried ones (stream_split.h: pure host arithmetic, CPU-tested)
@@ -93,6 +101,8 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
 {
     if (nout) *nout = 0;
     if (!c) return REDIO_ERR_ARG;
+    const Entered guard(c);
+    if (!guard.ok()) return REDIO_ERR_ARG; // another thread is inside this stream: its counters are not ours to move
     if (n == 0) return REDIO_OK;
     if (!d_new) return REDIO_ERR_ARG;
     SC_TRY(hipSetDevice(c->device));
@@ -102,10 +112,10 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     const size_t drop = c->skip < n ? c->skip : n; // a hop longer than the window: the samples between two windows are never read
     src += drop * c->in_elem; n -= drop;
     const StreamSplit s = n ? split(*c, n) : StreamSplit{0, 0, 0, 0, 0};
-    if ((s.nh || s.nb) && !d_out) return REDIO_ERR_ARG; // nothing has been consumed yet: the call can be repeated
-    c->skip -= drop;
-    c->total_in += n_call;
-    if (n == 0) return REDIO_OK;
+    if ((s.nh || s.nb) && !d_out) return REDIO_ERR_ARG;
+    if (n == 0) { c->skip -= drop; c->total_in += n_call; return REDIO_OK; }
+    // Everything up to the last launch leaves the handle's state alone (the seam copy below only writes staging memory behind
+    // the carried tail, and writes the same bytes again if the call is repeated); the state is committed at the end.
     char *S = c->d_s[c->cur], *T = c->d_s[c->cur ^ 1];
     const size_t m = n < c->W - 1 ? n : c->W - 1;
     if (c->hist > 0 && m > 0) SC_TRY(hipMemcpyAsync(S + c->hist * c->in_elem, src, m * c->in_elem, hipMemcpyDeviceToDevice, st));
@@ -120,24 +130,34 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     }
     // the new tail: everything from the start of the first unit not yet produced
     const size_t consumed = (s.nh + s.nb) * c->H; // staging coordinates ([tail | new])
+    size_t new_hist = 0, new_skip = c->skip - drop;
+    bool flip = false;
     if (consumed >= c->hist + n) { // only when H > W: the next unit starts beyond what has arrived
-        c->skip = consumed - (c->hist + n);
-        c->hist = 0;
-        c->total_units += s.nh + s.nb;
-        if (nout) *nout = (s.nh + s.nb) * c->unit_out;
-        return REDIO_OK;
+        new_skip = consumed - (c->hist + n);
+    } else {
+        new_hist = c->hist + n - consumed;
+        if (consumed >= c->hist) { // lies entirely in the caller's buffer
+            if (new_hist) SC_TRY(hipMemcpyAsync(T, src + (consumed - c->hist) * c->in_elem, new_hist * c->in_elem, hipMemcpyDeviceToDevice, st));
+        } else { // starts inside the old tail: then n < W - 1 and the staging buffer holds all of [tail | new]
+            if (c->hist == 0) SC_TRY(hipMemcpyAsync(T, src, n * c->in_elem, hipMemcpyDeviceToDevice, st));
+            else SC_TRY(hipMemcpyAsync(T, S + consumed * c->in_elem, new_hist * c->in_elem, hipMemcpyDeviceToDevice, st));
+        }
+        flip = true;
     }
-    const size_t new_hist = c->hist + n - consumed;
-    if (consumed >= c->hist) { // lies entirely in the caller's buffer
-        if (new_hist) SC_TRY(hipMemcpyAsync(T, src + (consumed - c->hist) * c->in_elem, new_hist * c->in_elem, hipMemcpyDeviceToDevice, st));
-    } else { // starts inside the old tail: then n < W - 1 and the staging buffer holds all of [tail | new]
-        if (c->hist == 0) SC_TRY(hipMemcpyAsync(T, src, n * c->in_elem, hipMemcpyDeviceToDevice, st));
-        else SC_TRY(hipMemcpyAsync(T, S + consumed * c->in_elem, new_hist * c->in_elem, hipMemcpyDeviceToDevice, st));
-    }
-    c->cur ^= 1;
+    // commit
+    if (flip) c->cur ^= 1;
     c->hist = new_hist;
+    c->skip = new_skip;
+    c->total_in += n_call;
     c->total_units += s.nh + s.nb;
     if (nout) *nout = (s.nh + s.nb) * c->unit_out;
+    return REDIO_OK;
+}
+int carry_reset(Carry *c)
+{
+    const Entered guard(c);
+    if (!guard.ok()) return REDIO_ERR_ARG;
+    c->hist = 0; c->skip = 0; c->total_in = 0; c->total_units = 0;
     return REDIO_OK;
 }
 } // namespace
@@ -158,8 +178,7 @@ struct redio_ovsave_stream { Carry *c; };
     extern "C" int redio_##NAME##_stream_reset(redio_##NAME##_stream *h)                                                        \
     {                                                                                                                           \
         if (!h) return REDIO_ERR_ARG;                                                                                           \
-        h->c->hist = 0; h->c->skip = 0; h->c->total_in = 0; h->c->total_units = 0;                                                              \
-        return REDIO_OK;                                                                                                        \
+        return carry_reset(h->c);                                                                                               \
     }                                                                                                                           \
     extern "C" size_t redio_##NAME##_stream_nout(const redio_##NAME##_stream *h, size_t n_new) { return h ? carry_nout(h->c, n_new) : 0; } \
     extern "C" size_t redio_##NAME##_stream_pending(const redio_##NAME##_stream *h) { return h ? h->c->hist : 0; }              \
@@ -203,8 +222,13 @@ extern "C" int redio_chain_stream_create(redio_chain_stream **h, redio_chain *pl
     if (!plan) return REDIO_ERR_ARG;
     size_t K, D; int nfft, dev;
     redio_chain_shape(plan, &K, &D, &nfft, &dev);
-    // the two-kernel path of the plan (unfused shapes, odd sample offsets) sizes its intermediate on first use
-    return make(h, K_CHAIN, plan, dev, ((size_t)nfft - 1) * D + K, (size_t)nfft * D, 8, (size_t)nfft, 8);
+    // the two-kernel path of the plan (unfused shapes, odd sample offsets) needs a plan-owned intermediate: sized here for the seam
+    // windows (at most 2*W samples per head run); a body run longer than any earlier one on that path grows it at enqueue time
+    // (redio.h: reserve with redio_chain_reserve(plan, largest message) to keep enqueue allocation-free)
+    const size_t W = ((size_t)nfft - 1) * D + K;
+    const int rr = redio_chain_reserve(plan, 2 * W);
+    if (rr) return rr;
+    return make(h, K_CHAIN, plan, dev, W, (size_t)nfft * D, 8, (size_t)nfft, 8);
 }
 // the same streams fed with the receiver's u8 I/Q bytes (2 bytes per sample; n_new still counts SAMPLES): the history is carried
 // as bytes, and every window runs redio_chain_enqueue_u8 / redio_pfb_enqueue_u8
@@ -215,7 +239,10 @@ extern "C" int redio_chain_stream_create_u8(redio_chain_stream **h, redio_chain 
     if (!plan) return REDIO_ERR_ARG;
     size_t K, D; int nfft, dev;
     redio_chain_shape(plan, &K, &D, &nfft, &dev);
-    return make(h, K_CHAIN_U8, plan, dev, ((size_t)nfft - 1) * D + K, (size_t)nfft * D, 2, (size_t)nfft, 8);
+    const size_t W = ((size_t)nfft - 1) * D + K;
+    const int rr = redio_chain_reserve_u8(plan, 2 * (2 * W)); // seam windows; see redio_chain_stream_create
+    if (rr) return rr;
+    return make(h, K_CHAIN_U8, plan, dev, W, (size_t)nfft * D, 2, (size_t)nfft, 8);
 }
 extern "C" int redio_pfb_stream_create_u8(redio_pfb_stream **h, redio_pfb *plan)
 {

@@ -233,3 +233,36 @@ def test_channelizer_from_u8_bytes_full_size(gpu, redio):
     del x
     assert got.shape == want.shape
     assert gpu.equal(gpu.view_as_real(got).view(gpu.int32), gpu.view_as_real(want).view(gpu.int32))
+
+
+def _launch_two_ranks(script_args, timeout=900):
+    """python -m torch.distributed.run --nproc-per-node 2 <script> as a FRESH child process (the test process has initialised the
+    GPU: nothing is exec'ed from it); returns the JSON line rank 0 printed."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_two_gpu_launch_paths_report_who_took_part(gpu):
+    """Multi-GPU readiness: where two devices are visible, the driver's own launch line for bench.py and the
+    channelizer's N-GPU launcher run with two ranks over RCCL and say so in their record -- n_gpus, the world size
+    torch.distributed saw, two DISTINCT devices -- and the exchange reports its egress per xGMI link.  One device: skipped."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    rec = _launch_two_ranks(["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--steady", "0", "--no-u8-leg", "--no-cpu-baseline"])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"]["world_size"] == 2 and rec["ranks_seen"]["distinct_devices"] == 2, rec["ranks_seen"]
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+    c4 = _launch_two_ranks(["tools/bench_c4.py", "--gpus", "2", "--log2-samples", "26", "--steps", "5", "--warmup", "2"])
+    assert c4["n_gpus"] == 2 and c4["ranks_seen"]["world_size"] == 2 and c4["ranks_seen"]["distinct_devices"] == 2, c4["ranks_seen"]
+    assert c4["exchange_egress_GBps_per_link"] and c4["exchange_egress_GBps_per_link"] > 0

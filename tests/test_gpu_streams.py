@@ -190,3 +190,50 @@ def test_u8_byte_streams(gpu, redio, oracle, kind):
         outs = [st(draw[2 * lo: 2 * hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
         got = gpu.cat(outs).cpu().numpy()
         assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (kind, cuts)
+
+
+def test_stream_handle_refuses_concurrent_entry_and_keeps_its_state_on_a_failed_call(gpu, redio, oracle):
+    """One stream is fed from one thread (redio.h).  Two block threads that share a handle by mistake (the kpn twin spawns one
+    thread per block, src/ratpak.rs:60-185) must get REDIO_ERR_ARG from the call that finds the other inside, never a corrupted
+    count: every call that returned 0 consumed its samples exactly once, in some order.  And a call that fails before its
+    kernels are launched (no output buffer although outputs are due) leaves the stream where it was."""
+    import ctypes as C
+    import threading
+    import torch
+    import libredio_amd as R
+    L = R.lib()
+    k = 33
+    taps = oracle.synth_f32(5, 0, k)
+    plan = redio.Fir(taps, 1, complex_input=False, fused=False)
+    st = redio.Stream(plan)
+    x = gpu.from_numpy(oracle.synth_f32(11, 0, 4096)).cuda()
+    y = [torch.empty(4096, dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    stream = R.current_stream()
+    ok_samples, ok_out, refused = [0, 0], [0, 0], [0, 0]
+    go = threading.Barrier(2)
+
+    def work(t):
+        go.wait()
+        for _ in range(3000):
+            got = C.c_size_t(0)
+            rc = L.redio_fir_stream_enqueue(st._h, C.c_void_p(x.data_ptr()), 64, C.c_void_p(y[t].data_ptr()), C.byref(got), stream)
+            if rc == 0:
+                ok_samples[t] += 64; ok_out[t] += got.value
+            else:
+                assert rc == -1, rc
+                refused[t] += 1
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    torch.cuda.synchronize()
+    total = sum(ok_samples)
+    assert total > 0 and sum(ok_out) == total - (k - 1), (ok_samples, ok_out, refused)
+    assert st.pending == k - 1
+    # a failed call changes nothing: outputs are due, no output buffer
+    before = st.pending
+    got = C.c_size_t(0)
+    assert L.redio_fir_stream_enqueue(st._h, C.c_void_p(x.data_ptr()), 100, None, C.byref(got), stream) == -1
+    assert st.pending == before and st.nout(100) == 100
+    out = st(x[:100])
+    assert out.numel() == 100

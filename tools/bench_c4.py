@@ -99,6 +99,13 @@ def main():
         if not torch.equal(pipe_buf, mine):
             bad = (torch.view_as_real(pipe_buf) != torch.view_as_real(mine)).any(dim=2).any(dim=1).nonzero().flatten()
             raise AssertionError(f"piece-wise pipeline differs from the one-shot exchange: {bad.numel()} rows, first {bad[:8].tolist()}, last {bad[-4:].tolist()} of {mine.shape[0]}")
+    # who took part: the world size torch.distributed reports and every rank's device (a launch that landed all ranks on one
+    # device, or fewer ranks than asked for, must be impossible to miss)
+    pr = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "device": local, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+          "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0))}
+    seen = [None] * dist.get_world_size()
+    dist.all_gather_object(seen, me)
     if rank == 0:
         egress = nrows * (M - cpg) * 8                  # bytes this GPU sends to its peers per step
         print(json.dumps({"workload": "BASELINE.json configs[3]: 64-channel polyphase channelizer, P=16, channels sharded over the GPUs",
@@ -108,6 +115,9 @@ def main():
                           "ms_pipelined": None if t_pipe is None else t_pipe * 1e3, "pieces": a.pieces,
                           "pipelined_GSps": None if t_pipe is None else world * n / t_pipe / 1e9,
                           "exchange_egress_GBps_per_gpu": (egress / max(t_both - t_analysis, 1e-9) / 1e9) if world > 1 else None,
+                          # xGMI is point to point: a rank's world - 1 transfers of a step each have a link of their own
+                          "exchange_egress_GBps_per_link": (egress / (world - 1) / max(t_both - t_analysis, 1e-9) / 1e9) if world > 1 else None,
+                          "ranks_seen": {"world_size": dist.get_world_size(), "devices": seen, "distinct_devices": len({(d["pci"], d["uuid"]) for d in seen})},
                           "scaling": "weak",
                           "collective": "redio_pfb_exchange: RCCL ncclSend/ncclRecv group (C ABI)" if use_cabi else "all_to_all_single (%s)" % a.backend}))
     dist.destroy_process_group()
