@@ -13,7 +13,13 @@
  * hold, linear) and channels >= 1 (interleaved frames, each channel converted as a mono stream) are built;
  * a converter above 4 or a channel count below 1 returns NULL with the library's error code.  Deviation stated in DESIGN.md: the coefficient tables are not the
  * library's (they cannot be reproduced here), so sample values differ from the real library within
- * its quality class; control flow and frame counts follow the published 0.1.8 algorithm.
+ * its quality class; control flow and frame counts follow the published 0.1.8 algorithm for ONE channel (what the
+ * reference uses).  Two stated definitions beyond it: (i) with channels > 1 and a sinc converter every channel runs through
+ * its own mono state, so the frame count of the LAST message of a stream (end_of_input = 1) is the mono loop's: the library's
+ * multi-channel loops test their end-of-input condition in sample units with >= where the mono loop has >, and can differ from
+ * this by one frame there; (ii) a message of a single frame through the zero-order-hold / linear converters interpolates from
+ * the frame carried from the previous message (the published loop reads data_in[-channels] at that point); known answers:
+ * tests/test_src_single_frame_kat.py.
  */
 #ifndef SAMPLERATE_H
 #define SAMPLERATE_H

@@ -36,6 +36,7 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_once;
 thread_local char g_last_error[256] = ""; // per calling thread: one block thread per GPU may fail independently
+char g_load_error[256] = "";              // why librccl.so could not be used: written once (under g_once), read by every thread after
 
 void load_rccl()
 {
@@ -45,10 +46,10 @@ void load_rccl()
         g_rccl.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.so) break;
     }
-    if (!g_rccl.so) { snprintf(g_last_error, sizeof g_last_error, "librccl.so not loadable: %s", dlerror()); return; }
+    if (!g_rccl.so) { snprintf(g_load_error, sizeof g_load_error, "librccl.so not loadable: %s", dlerror()); return; }
 #define RD_SYM(field, name) \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.so, name)); \
-    if (!g_rccl.field) { snprintf(g_last_error, sizeof g_last_error, "librccl.so lacks %s", name); return; }
+    if (!g_rccl.field) { snprintf(g_load_error, sizeof g_load_error, "librccl.so lacks %s", name); return; }
     RD_SYM(GetUniqueId, "ncclGetUniqueId")
     RD_SYM(CommInitRank, "ncclCommInitRank")
     RD_SYM(CommInitAll, "ncclCommInitAll")
@@ -64,8 +65,22 @@ void load_rccl()
 const Rccl *rccl()
 {
     std::call_once(g_once, load_rccl);
-    return g_rccl.ok ? &g_rccl : nullptr;
+    if (g_rccl.ok) return &g_rccl;
+    snprintf(g_last_error, sizeof g_last_error, "%s", g_load_error); // every failing caller gets the text, not only the first thread
+    return nullptr;
 }
+// makes `device` current for the life of a call and puts the caller's device back (the device is per-thread state: a block
+// thread that drives several GPUs must not find it changed by an exchange)
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = hipSetDevice(device);
+    }
+    ~DeviceScope() { if (prev >= 0) hipSetDevice(prev); }
+};
 int nccl_rc(const Rccl *r, ncclResult_t e, const char *what)
 {
     if (e == ncclSuccess) return REDIO_OK;
@@ -155,7 +170,7 @@ extern "C" int redio_comm_size(const redio_comm *c) { return c ? c->nranks : 0; 
 // One rank's transfers of an exchange: to every peer q `sendn[q]` floats from `sendp[q]`, from every peer `recvn[q]` floats into
 // `recvp[q]`.  Messages are cut into pieces of at most 2^27 floats (512 MiB), one RCCL group per piece index: a single
 // ncclSend / ncclRecv pair above 1 GiB was measured to deliver only its first gigabyte (RCCL 2.26.6, send to self on one MI355X;
-// tools/exp has the probe), and smaller pieces also let the fabric interleave the peers.
+// tools/rccl_self_probe.py is the probe), and smaller pieces also let the fabric interleave the peers.
 constexpr size_t COMM_PIECE = (size_t)1 << 27;
 struct PeerXfer { const float *sendp; size_t sendn; float *recvp; size_t recvn; };
 static int xfer_group(const Rccl *r, redio_comm *c, const PeerXfer *x, size_t piece, hipStream_t st, bool &any)
@@ -222,8 +237,8 @@ extern "C" int redio_pfb_exchange_at(redio_comm *c, const void *d_grouped, void 
     size_t total = 0;
     for (int q = 0; q < c->nranks; ++q) total += rows_per_rank[q];
     if ((mine && !d_grouped) || (total && !d_out)) return REDIO_ERR_ARG;
-    hipError_t he = hipSetDevice(c->device);
-    if (he != hipSuccess) return REDIO_ERR_HIP_BASE - (int)he;
+    const DeviceScope dev_scope(c->device); // the caller's current device is left as it was
+    if (dev_scope.err != hipSuccess) return REDIO_ERR_HIP_BASE - (int)dev_scope.err;
     const size_t fl = 2 * chans_per_rank;
     std::vector<PeerXfer> x((size_t)c->nranks);
     for (int q = 0; q < c->nranks; ++q)
@@ -240,8 +255,8 @@ extern "C" int redio_pfb_exchange(redio_comm *c, const void *d_grouped, void *d_
     const size_t total = row_offsets(rows_per_rank, c->nranks, off);
     const size_t mine = rows_per_rank[c->rank];
     if ((mine && !d_grouped) || (total && !d_out)) return REDIO_ERR_ARG;
-    hipError_t he = hipSetDevice(c->device);
-    if (he != hipSuccess) return REDIO_ERR_HIP_BASE - (int)he;
+    const DeviceScope dev_scope(c->device); // the caller's current device is left as it was
+    if (dev_scope.err != hipSuccess) return REDIO_ERR_HIP_BASE - (int)dev_scope.err;
     const size_t fl = 2 * chans_per_rank; // floats per row of one group
     std::vector<PeerXfer> x((size_t)c->nranks);
     for (int q = 0; q < c->nranks; ++q) // to rank q: my rows of q's channels (group q of my layout); from rank q: its rows of my channels

@@ -395,6 +395,19 @@ static int prepare_fast_taps(redio_src *f, int S, double scale)
 // exactly periodic; builds the P sets of interpolated coefficients with the expression of calc_output_single (in
 // double) as tables [tap][phase]; launches src_sinc_periodic_kernel.  Returns 1 when it handled the epoch, 0 when the
 // epoch is not eligible (the general kernel then runs), an error code otherwise.
+// ONE eligibility rule for the periodic-phase kernel, shared by the epoch path (which applies it to the epoch it is about to run)
+// and by the single-launch window path's probe (which applies it to the epoch size it expects): P phases per Q input samples,
+// NL + NR taps per phase, an epoch of `count` outputs.  The tables are rebuilt for every epoch (its first output may sit at any
+// phase): only worth it while they are small next to the epoch's own work (0.0213 = 213 / 10000 is periodic too, but 213 phases
+// x 4300 taps is not a table), and a tile of the kernel must fit the LDS.
+static bool periodic_epoch_eligible(int P, int Q, int NL, int NR, int dpos_max, long count)
+{
+    if (count < 128 || P < 1) return false;
+    int NT = 0; size_t lds = 0;
+    if (!src_periodic_shape(P, Q, NL, NR, dpos_max, 1, &NT, &lds)) return false;
+    return (long)P * (NL + NR) <= 65536 && (long)P * (NL + NR) <= 8 * count;
+}
+
 static int try_periodic_epoch(redio_src *f, long first, long count, float *d_out, long out_stride, hipStream_t st)
 {
     if (count < 128) return 0;
@@ -445,11 +458,7 @@ static int try_periodic_epoch(redio_src *f, long first, long count, float *d_out
         NR = NR > (int)Rf[(size_t)p].size() ? NR : (int)Rf[(size_t)p].size();
     }
     const int dpos_max = pos[P - 1] - pos[0];
-    int NT = 0; size_t lds = 0;
-    if (!src_periodic_shape(P, Q, NL, NR, dpos_max, 1, &NT, &lds)) return 0;
-    // the tables are rebuilt for every epoch (its first output may sit at any phase): only worth it while they are small
-    // next to the epoch's own work (0.0213 = 213 / 10000 is periodic too, but 213 phases x 4300 taps is not a table)
-    if ((long)P * (NL + NR) > 65536 || (long)P * (NL + NR) > 8 * count) return 0;
+    if (!periodic_epoch_eligible(P, Q, NL, NR, dpos_max, count)) return 0;
     // this epoch's tables in the pinned arena (kept until the call's final synchronisation: the uploads are asynchronous)
     const size_t nLd = (size_t)NL * P, nRd = (size_t)NR * P, need = (nLd + nRd) * sizeof(double) + 3 * 256 * sizeof(int);
     if (!f->h_arena) {
@@ -701,8 +710,11 @@ static int zoh_linear_impl(redio_src *f, const float *d_in, long in_stride, long
 }
 
 // Would the refill epochs of this call run the periodic-phase kernel (small per-phase tables, no per-tap interpolation: the faster
-// form where it applies)?  Same period test and table-size rule as try_periodic_epoch, on the first n outputs of the dry run.
-static bool window_prefers_periodic(const redio_src *f, long n, int inc)
+// form where it applies)?  The period test of try_periodic_epoch on the first n outputs of the dry run, then the SAME eligibility
+// rule (periodic_epoch_eligible) on the epoch the library's refill logic would produce: about `epoch_outputs` outputs per refill.
+// (Round 2 tested the table size only: a ratio whose epochs the periodic rule then declined lost the single-launch window and ran
+// one small launch per refill.)
+static bool window_prefers_periodic(const redio_src *f, long n, int inc, long epoch_outputs)
 {
     const int *pos = f->h_pos, *start = f->h_start;
     for (int P = 1; P <= 256 && 2L * P <= n; ++P) {
@@ -711,8 +723,8 @@ static bool window_prefers_periodic(const redio_src *f, long n, int inc)
         bool ok = true;
         for (long k = 0; ok && k + P < n; ++k) ok = start[k + P] == start[k] && pos[k + P] - pos[k] == Q;
         if (!ok) continue;
-        const long taps = 2L * ((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 2;
-        return (long)P * taps <= 65536;
+        const int wing = (int)((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 1; // taps of one wing, at most
+        return periodic_epoch_eligible(P, Q, wing, wing, pos[P - 1] - pos[0], epoch_outputs);
     }
     return false;
 }
@@ -743,6 +755,8 @@ static int try_general_window(redio_src *f, const SrcInput &in, long in_count, f
     constexpr int NT = 128;          // outputs per workgroup of the tile kernel
     constexpr long CHUNK = 16384;    // outputs per launch: the host's recurrence for the next chunk runs beside the kernel of this one
     constexpr long PROBE = 1024;     // outputs looked at before the first launch to choose between this path and periodic epochs
+    // outputs between two refills of the library's buffer: a refill brings in at most b_len - 2*half frames, ratio outputs per frame
+    const long epoch_outputs = (long)((double)(f->b_len - 2 * half) * src_ratio);
     if ((double)NT * step + 2.0 * (double)((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 16.0 > 15000.0) return 0; // no LDS tile holds it
     int rc = ensure_scratch(f, (size_t)out_count);
     if (rc) return rc;
@@ -813,7 +827,7 @@ static int try_general_window(redio_src *f, const SrcInput &in, long in_count, f
         ++out_gen;
         if (!probed && out_gen == PROBE) {
             probed = true;
-            if (window_prefers_periodic(f, out_gen, inc)) return 0;
+            if (window_prefers_periodic(f, out_gen, inc, epoch_outputs)) return 0;
         }
         if (out_gen - launched >= CHUNK) {
             const int r = launch_chunk(launched, out_gen - launched);
@@ -822,7 +836,7 @@ static int try_general_window(redio_src *f, const SrcInput &in, long in_count, f
         }
         b_current = wrap(b_current + src_advance(input_index, step));
     }
-    if (!probed && window_prefers_periodic(f, out_gen, inc)) return 0;
+    if (!probed && window_prefers_periodic(f, out_gen, inc, epoch_outputs)) return 0;
     {
         const int r = launch_chunk(launched, out_gen - launched);
         if (r != 1) return give_back(r);
