@@ -898,6 +898,50 @@ __device__ __forceinline__ void f64w_exchange(float2 (&a)[4][16], float2 (&b)[4]
     }
 }
 
+// A launch of these tile passes is ONE round: every wavefront of the chip takes one tile, so all of them load together, then all
+// compute (memory idle), then all store.  Delaying half of the wavefronts of every workgroup by about the length of a load phase
+// lets one half compute while the other half moves data (MI355X_MICROARCH.md, two waves per SIMD, item 9).  REDIO_EXP_BIG_STAGGER:
+// the delay in units of s_sleep 127 (127 x 64 cycles, about 4 us); 0 = none.
+#ifndef REDIO_EXP_BIG_STAGGER
+#define REDIO_EXP_BIG_STAGGER 0
+#endif
+__device__ __forceinline__ void big_stagger(int w)
+{
+#if REDIO_EXP_BIG_STAGGER > 0
+    if (w >= 2) {
+#pragma unroll
+        for (int i = 0; i < REDIO_EXP_BIG_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#else
+    (void)w;
+#endif
+}
+
+// data that a multi-pass transform touches ONCE (the caller's input in the gather pass, the caller's output in the last pass):
+// non-temporal accesses, so that the 64 MiB intermediates the passes hand to each other keep the caches (round 3;
+// -DREDIO_EXP_BIG_NT=0 builds the default-policy form for comparison)
+#ifndef REDIO_EXP_BIG_NT
+#define REDIO_EXP_BIG_NT 3
+#endif
+typedef float big_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 big_ld_once(const float2 *p)
+{
+#if REDIO_EXP_BIG_NT & 1
+    const big_v2f v = __builtin_nontemporal_load(reinterpret_cast<const big_v2f *>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void big_st_once(float2 *p, float2 v)
+{
+#if REDIO_EXP_BIG_NT & 2
+    __builtin_nontemporal_store(big_v2f{v.x, v.y}, reinterpret_cast<big_v2f *>(p));
+#else
+    *p = v;
+#endif
+}
+
 // overlap-save middle pass: forward pass 1, spectrum product, inverse pass 0 on the same tile.  After the forward
 // stages lane (col, q) holds rows s + 16 j, s = q + 4 x: in the inverse transform's digit-reversed order that IS
 // group 4 q + x with rows in rev2 order, so the inverse starts from registers without another exchange.
@@ -949,6 +993,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile() + w;
     if (tile >= ntiles) return;
+    big_stagger(w);
     const long xf = tile >> 4;
     ovsave64k_mid_tile(a_in + xf * F64K_N, b_out + xf * F64K_N, Tf, tw_i, Hc, (int)(tile & 15), lane, Ls + w * F64W_REGION);
 }
@@ -975,7 +1020,7 @@ __device__ __forceinline__ void ovsave64k_last_tile(const float2 *__restrict__ b
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            if (256 * (4 * x + 16 * j) < lim) (dst + 256 * (4 * x + 16 * j))[lo_q1] = make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale));
+            if (256 * (4 * x + 16 * j) < lim) big_st_once((dst + 256 * (4 * x + 16 * j)) + lo_q1, make_float2(mul_rn(b[x][j].x, scale), mul_rn(b[x][j].y, scale)));
 }
 
 __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
@@ -1431,7 +1476,7 @@ __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[i][j] = (src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i))[lo_src]; // source row rev4(16 (4i + q) + j)
+        for (int j = 0; j < 16; ++j) a[i][j] = big_ld_once((src + (long)S * (16 * (((j & 3) << 2) | (j >> 2)) + i)) + lo_src); // source row rev4(16 (4i + q) + j)
     if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
         const float2 *hsrc = mulH + 16 * c;
 #pragma unroll

@@ -262,23 +262,26 @@ static hipError_t launch_fir_t(const T *x, long n_in, const float *taps, int K, 
     return hipGetLastError();
 }
 
-hipError_t launch_fir_v4_127_5(const float2 *x, const float *taps, float2 *y, long nblocks, bool fused, hipStream_t s); // chain_v4.hip
+hipError_t launch_fir_v4(int K, int D, const float2 *x, const float *taps, float2 *y, long nblocks, bool fused, hipStream_t s); // chain_v4.hip
 
 hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D, void *y, long n_out,
                       bool cplx, bool fused, hipStream_t s)
 {
-    // the north-star shape runs on the chain kernel's data path (wave-private images, halo carried in
-    // LDS, register prefetch): whole 1024-output blocks there, the remainder on the tiled kernel
-    if (cplx && K == 127 && D == 5 && n_out >= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    // the shapes the chain kernel is built for (127 / 63 taps, decimation 5 / 3 / 1) run on its data path (wave-private images,
+    // halo carried in LDS, register prefetch): whole 1024-output blocks there, the remainder on the tiled kernel
+    if (cplx && n_out >= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && !getenv("REDIO_FIR_NO_V4")) {
         const long nblocks = n_out / 1024;
-        hipError_t e = launch_fir_v4_127_5((const float2 *)x, taps, (float2 *)y, nblocks, fused, s);
-        if (e != hipSuccess) return e;
-        const long done = nblocks * 1024;
-        if (done == n_out) return hipSuccess;
-        x = (const float2 *)x + done * 5;
-        y = (float2 *)y + done;
-        n_in -= done * 5;
-        n_out -= done;
+        hipError_t e = launch_fir_v4(K, (int)(D <= 5 ? D : 0), (const float2 *)x, taps, (float2 *)y, nblocks, fused, s);
+        if (e == hipSuccess) {
+            const long done = nblocks * 1024;
+            if (done == n_out) return hipSuccess;
+            x = (const float2 *)x + done * D;
+            y = (float2 *)y + done;
+            n_in -= done * D;
+            n_out -= done;
+        } else if (e != hipErrorNotSupported) {
+            return e;
+        }
     }
     if (cplx) {
         if (fused) return launch_fir_t<float2, true>((const float2 *)x, n_in, taps, K, D, (float2 *)y, n_out, s);

@@ -165,7 +165,7 @@ if "firshapes" in which:
     # generality of the FIR: specialised shapes vs the direct kernel (any K, D)
     m = 1 << 26
     xc = R.synth_iq(1, 0, m); xr = R.synth_f32(1, 0, m)
-    for (k, d, cplx) in ((127, 5, True), (127, 1, True), (63, 5, True), (63, 5, False), (127, 1, False), (63, 1, False), (63, 1, True), (64, 1, True), (101, 3, True), (31, 2, True), (255, 10, True), (1023, 1, True), (8193, 1, True)):
+    for (k, d, cplx) in ((127, 5, True), (127, 1, True), (127, 3, True), (63, 5, True), (63, 5, False), (127, 1, False), (63, 1, False), (63, 1, True), (64, 1, True), (101, 3, True), (31, 2, True), (255, 10, True), (1023, 1, True), (8193, 1, True)):
         taps = R.dsputils.lpf_corrected(k, 0.4 / d if d > 1 else 0.2)
         plan = R.Fir(taps, d, complex_input=cplx, fused=True)
         x = xc if cplx else xr
