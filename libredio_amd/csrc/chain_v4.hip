@@ -184,9 +184,8 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
 hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                            hipStream_t s, unsigned long long *dbg)
 {
-    if (const char *e = getenv("REDIO_CHAIN_WPS")) { // measurement only: three wavefronts per SIMD
-        if (atoi(e) == 3) return launch_v4_t<127, 5, 3, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg);
-    }
+    // (three wavefronts per SIMD were measured again in round 3 with the new access policy: the transform's registers spill at
+    // 168 per lane, 0.56-0.60 against 0.517 ms)
     return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg); // last-stage twiddles resident
 }
 
