@@ -70,7 +70,9 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     const bool one_kernel = nfft == 1024 || nfft == 2048 || nfft == 4096 || nfft == 8192 || nfft == 16384;
     // 64 MiB per buffer: swept 16 ... 128 MiB at 65536 points in round 2 (profiles/r02_c5_team_experiment.txt): 64 is best, 128 -- past the
     // Infinity Cache -- costs 6 %
-    p->chunk_blocks = ((size_t)64 << 20) / ((size_t)nfft * sizeof(float2)); // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
+    size_t chunk_mib = 64; // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
+    if (const char *e = getenv("REDIO_OVS_CHUNK_MIB")) { const long v = atol(e); if (v >= 1) chunk_mib = (size_t)v; } // measurement only
+    p->chunk_blocks = (chunk_mib << 20) / ((size_t)nfft * sizeof(float2));
     if (p->chunk_blocks < 1) p->chunk_blocks = 1;
     int rc = redio_fft_create(&p->fw, nfft, 0);
     if (rc == REDIO_OK) rc = redio_fft_create(&p->bw, nfft, 1);

@@ -57,6 +57,39 @@ __global__ void k_copy(const v4f *__restrict__ x, v4f *__restrict__ y, long n)
     for (; i < n; i += stride) st<NT>(y + i, ld<NT>(x + i));
 }
 
+// the same copy with 8-byte lanes (float2): what the transform kernels' accesses look like to the memory system
+template <int U>
+__global__ void k_copy8(const float2 *__restrict__ x, float2 *__restrict__ y, long n)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = x[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) y[i + u * stride] = v[u];
+    }
+    for (; i < n; i += stride) y[i] = x[i];
+}
+
+// the tile passes' pattern: one wavefront moves a 256-row x 16-column tile of float2 (rows 2 KiB apart, 128-byte row segments,
+// four segments per wave instruction, 64 loads in flight, then 64 stores), tiles handed out in dispatch order, four per workgroup
+__global__ __launch_bounds__(256, 2) void k_tile(const float2 *__restrict__ x, float2 *__restrict__ y, long ntiles)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+    const long tile = (long)blockIdx.x * 4 + w;
+    if (tile >= ntiles) return;
+    const long blk = tile >> 4, c = tile & 15;
+    const float2 *src = x + blk * 65536 + 16 * c + col + 4096 * q;
+    float2 *dst = y + blk * 65536 + 16 * c + col + 4096 * q;
+    float2 v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = src[256 * ((i >> 4) * 64 + (i & 15))];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) dst[256 * ((i >> 4) * 64 + (i & 15))] = v[i];
+}
+
 // five loads per store: thread t of a workgroup-tile reads x[5*tile*T + t + T*k], k < 5, stores y[tile*T + t]
 template <bool NT>
 __global__ void k_mix5(const v4f *__restrict__ x, v4f *__restrict__ y, long ntiles)
@@ -125,6 +158,21 @@ int main(int argc, char **argv)
     RUN((k_copy<false, 1>), 256, 524288, 2 * rd, "copy  plain, one float4 per thread");
     RUN((k_copy<true, 1>), 256, 524288, 2 * rd, "copy  nt,    one float4 per thread");
     RUN((k_copy<false, 8>), 256, 4096, 2 * rd, "copy  plain, 8 in flight");
+    {
+        const long n2 = n * 2; // float2 elements of the same buffers
+        for (int G : {4096, 16384, 65536}) {
+            snprintf(nm, 128, "copy  8-byte lanes, 4 in flight, 256 threads, grid %d", G);
+            timeit([&] { hipLaunchKernelGGL((k_copy8<4>), dim3(G), dim3(256), 0, 0, (const float2 *)x, (float2 *)y, n2); }, 2 * rd, nm);
+        }
+        snprintf(nm, 128, "copy  8-byte lanes, one float2 per thread, 256 threads, grid %ld", n2 / 256);
+        timeit([&] { hipLaunchKernelGGL((k_copy8<1>), dim3((unsigned)(n2 / 256)), dim3(256), 0, 0, (const float2 *)x, (float2 *)y, n2); }, 2 * rd, nm);
+        const long ntiles = n2 / 4096; // 256 x 16 tiles of 65536-point blocks
+        snprintf(nm, 128, "copy  tile pattern (256 rows x 128 B, 8-byte lanes, 64 in flight), grid %ld", ntiles / 4);
+        timeit([&] { hipLaunchKernelGGL(k_tile, dim3((unsigned)(ntiles / 4)), dim3(256), 0, 0, (const float2 *)x, (float2 *)y, ntiles); }, 2 * rd, nm);
+        const long chunk_tiles = 2048; // one 64 MiB chunk per launch, as the overlap-save passes run
+        snprintf(nm, 128, "copy  tile pattern, ONE 64 MiB chunk per launch (2048 tiles), x%ld launches", ntiles / chunk_tiles);
+        timeit([&] { for (long t0 = 0; t0 < ntiles; t0 += chunk_tiles) hipLaunchKernelGGL(k_tile, dim3((unsigned)(chunk_tiles / 4)), dim3(256), 0, 0, (const float2 *)x + t0 * 4096, (float2 *)y + t0 * 4096, chunk_tiles); }, 2 * rd, nm);
+    }
     {
         for (int T : {256, 512}) for (int G : {2048, 4096, 16384}) {
             const long ntiles = n / (5L * T);
