@@ -62,20 +62,44 @@ __global__ __launch_bounds__(NT) void fir_tiled_kernel(const T *__restrict__ x, 
 // reference fold.  The K % 16 taps behind the last whole chunk run as chunks of 8, 4, 2 and 1 taps (the binary
 // digits of the remainder): the same straight-line code at smaller sizes, no per-tap guard (a guarded 16-tap
 // chunk compiled to a select per product and cost as much as three whole chunks).
-template <typename T, int D, int R, bool FUSED, int CH>
+// ALIGNED: j0 is a multiple of the lane stride R*D (whole chunks whose size is one), so the pad element count of window sample i
+// is j0 / LSTR + i / LSTR with a compile-time second term: one scalar base per chunk and immediate offsets.  Round 3: before, every
+// one of the window reads paid a wave-uniform division by LSTR (SQ counters of 255 taps / 10: 9.0e7 scalar against 6.7e7 vector
+// instructions per launch).
+template <typename T, int D, int R, bool FUSED, int CH, bool ALIGNED = false>
 __device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, const float *__restrict__ taps, T (&acc)[R])
 {
     constexpr int WIN = CH + (R - 1) * D, LSTR = R * D;
     constexpr bool PAD = (LSTR % 2) == 0;
     T xv[WIN];
-#pragma unroll
-    for (int i = 0; i < WIN; ++i) {
-        const int m = j0 + i; // wave-uniform
-        xv[i] = xs[base + (PAD ? m + m / LSTR : m)];
-    }
+    const int cb = base + (PAD ? j0 + j0 / LSTR : j0); // ALIGNED: the window's first sample in the image
     float h[CH];
+    if constexpr (ALIGNED && sizeof(T) == 8) {
+        // One ds_read_b64 per sample, spelled out: from base + immediate the compiler pairs them into ds_read2_b64, which the LDS
+        // serves at half the bytes per clock (MI355X_MICROARCH.md, LDS table: 8 cycles against 2 x 2; SQ_LDS_IDX_ACTIVE of this
+        // kernel rose by half when the offsets became immediates).  The reads land in order behind the taps' scalar load.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f q[WIN];
+        const unsigned a = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)(xs + cb);
 #pragma unroll
-    for (int j = 0; j < CH; ++j) h[j] = taps[j0 + j];
+        for (int i = 0; i < WIN; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[i]) : "v"(a), "n"((PAD ? i + i / LSTR : i) * 8));
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = taps[j0 + j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            asm volatile("" : "+v"(q[i])); // uses stay behind the wait
+            xv[i] = T{q[i].x, q[i].y};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const int m = j0 + i; // wave-uniform
+            xv[i] = ALIGNED ? xs[cb + (PAD ? i + i / LSTR : i)] : xs[base + (PAD ? m + m / LSTR : m)];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) h[j] = taps[j0 + j];
+    }
 #pragma unroll
     for (int i = 0; i < WIN; ++i)
 #pragma unroll
@@ -85,19 +109,25 @@ __device__ __forceinline__ void fir_chunk(const T *xs, int base, int j0, const f
         }
 }
 
+// A two-stage form of the whole chunks (window reads and taps of chunk c + 1 in flight into a second register set during the
+// multiply-adds of chunk c, chunks of one lane stride) was built and measured slower on all ten shapes tried (255 taps / 10: 0.192 ms
+// against 0.178; 101 / 3: 0.188 against 0.154): 100-190 VGPRs instead of 50-110, and the occupancy they cost hid more latency than
+// the second register set did.  profiles/r03_fir_chunked.txt.
 // all K taps of the R outputs of a lane: whole chunks, then the remainder's binary digits
 template <typename T, int D, int R, bool FUSED, int CH = 16>
 __device__ __forceinline__ void fir_chunks(const T *xs, int base, int K, const float *__restrict__ taps, T (&acc)[R])
 {
-    static_assert(CH == 16 || CH == 32, "whole-chunk size");
+    constexpr bool ALIGNED = CH % (R * D) == 0;
     const int nfull = K / CH;
-    for (int c = 0; c < nfull; ++c) fir_chunk<T, D, R, FUSED, CH>(xs, base, c * CH, taps, acc);
+    for (int c = 0; c < nfull; ++c) fir_chunk<T, D, R, FUSED, CH, ALIGNED>(xs, base, c * CH, taps, acc);
     int j0 = nfull * CH;
-    if (CH == 32 && (K & 16)) { fir_chunk<T, D, R, FUSED, 16>(xs, base, j0, taps, acc); j0 += 16; }
-    if (K & 8) { fir_chunk<T, D, R, FUSED, 8>(xs, base, j0, taps, acc); j0 += 8; }
-    if (K & 4) { fir_chunk<T, D, R, FUSED, 4>(xs, base, j0, taps, acc); j0 += 4; }
-    if (K & 2) { fir_chunk<T, D, R, FUSED, 2>(xs, base, j0, taps, acc); j0 += 2; }
-    if (K & 1) fir_chunk<T, D, R, FUSED, 1>(xs, base, j0, taps, acc);
+    const int rest = K - j0; // < CH: its binary digits as chunks of 32, 16, 8, 4, 2, 1 taps
+    if (CH > 32 && (rest & 32)) { fir_chunk<T, D, R, FUSED, 32>(xs, base, j0, taps, acc); j0 += 32; }
+    if (CH > 16 && (rest & 16)) { fir_chunk<T, D, R, FUSED, 16>(xs, base, j0, taps, acc); j0 += 16; }
+    if (rest & 8) { fir_chunk<T, D, R, FUSED, 8>(xs, base, j0, taps, acc); j0 += 8; }
+    if (rest & 4) { fir_chunk<T, D, R, FUSED, 4>(xs, base, j0, taps, acc); j0 += 4; }
+    if (rest & 2) { fir_chunk<T, D, R, FUSED, 2>(xs, base, j0, taps, acc); j0 += 2; }
+    if (rest & 1) fir_chunk<T, D, R, FUSED, 1>(xs, base, j0, taps, acc);
 }
 
 // Memory side (round 2; the skeleton alone -- tile in, tile out, no arithmetic -- ran at 2.9 TB/s with 8-byte loads and each lane
@@ -107,77 +137,110 @@ __device__ __forceinline__ void fir_chunks(const T *xs, int base, int K, const f
 // next tile's loads in flight during the arithmetic) was built and measured slower -- at 64 taps / 1 the tile's LDS traffic
 // (237 KB: window reads, tile, transpose) and its multiply-adds each fill most of the time on their own, and fewer resident waves
 // hide less of it: profiles/r02_fir_generic_experiments.txt.
+// Round 3, again for the shapes HBM binds (decimation >= 3): a resident grid, each workgroup walking tiles with the first rounds of the
+// NEXT tile's 16-byte loads issued right after the current tile's image is complete (in flight during its arithmetic and stores):
+// slower on 7 of 8 shapes (101 taps / 3: 0.197 ms against 0.154; 255 / 10: 0.185 against 0.178).  profiles/r03_fir_chunked.txt.
 template <typename T, int D, int R, bool FUSED, int CHW>
 __global__ __launch_bounds__(256) void fir_chunked_kernel(const T *__restrict__ x, long n_in, const float *__restrict__ taps, int K,
                                                           T *__restrict__ y, long n_out, int vec_in, int vec_out)
 {
     constexpr int NT = 256, CH = 16, TILE_OUT = NT * R, LSTR = R * D, VEC = 16 / (int)sizeof(T);
     constexpr bool PAD = (LSTR % 2) == 0;
+    constexpr bool BATCH = !PAD || LSTR % VEC == 0; // all VEC elements of a 16-byte load share one pad count
     static_assert((R & (R - 1)) == 0, "R is a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *xs = reinterpret_cast<T *>(smem);
     const int tid = threadIdx.x;
     const int kc = (K + CH - 1) / CH * CH;
     const int tile_in = (TILE_OUT - 1) * D + kc;
-    const long in0 = (long)blockIdx.x * TILE_OUT * D;
+    const int nv = (tile_in + VEC - 1) / VEC;
     auto put = [&](int n, T v) { xs[PAD ? n + n / LSTR : n] = v; };
-    if (vec_in) { // x is 16-byte aligned (in0 * sizeof(T) always is)
-        const float4 *x4 = reinterpret_cast<const float4 *>(x + in0);
-        const int nv = (tile_in + VEC - 1) / VEC;
-#pragma unroll 4
-        for (int v = tid; v < nv; v += NT) {
-            const int n = v * VEC;
-            if (in0 + n + VEC <= n_in) {
-                const float4 q = x4[v];
-                if constexpr (sizeof(T) == 8) {
-                    put(n, T{q.x, q.y}); put(n + 1, T{q.z, q.w});
-                } else {
-                    put(n, q.x); put(n + 1, q.y); put(n + 2, q.z); put(n + 3, q.w);
-                }
-            } else {
+    auto put16 = [&](int v, const float4 &q) { // load v of the tile: VEC elements from n = v * VEC
+        const int n = v * VEC;
+        T *d = xs + (PAD ? n + n / LSTR : n);
+        if constexpr (sizeof(T) == 8) {
+            d[0] = T{q.x, q.y}; d[1] = T{q.z, q.w};
+        } else {
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        }
+    };
+    const long t = blockIdx.x; // the tile
+    {
+        const long in0 = t * TILE_OUT * D;
+        if (vec_in) { // x is 16-byte aligned (in0 * sizeof(T) always is)
+            const float4 *x4 = reinterpret_cast<const float4 *>(x + in0);
+            int vfirst = tid;
+            if (BATCH && in0 + (long)nv * VEC <= n_in) {
+                // the whole tile exists (workgroup-uniform): LB loads in flight per lane, no bound checks.  Round 3: the guarded loop
+                // below keeps four loads in flight and waits three times for a 43 KB tile (255 taps / 10); here every wait covers eight.
+                constexpr int LB = 8;
+                for (; vfirst < nv; vfirst += LB * NT) {
+                    float4 q[LB];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    T v1{};
-                    if (in0 + n + e < n_in) v1 = x[in0 + n + e];
-                    put(n + e, v1); // at most VEC - 1 elements past tile_in: inside the allocation (launch_chunked)
+                    for (int b = 0; b < LB; ++b) {
+                        const int v = vfirst + b * NT;
+                        q[b] = x4[v < nv ? v : nv - 1];
+                    }
+#pragma unroll
+                    for (int b = 0; b < LB; ++b)
+                        if (vfirst + b * NT < nv) put16(vfirst + b * NT, q[b]);
                 }
             }
-        }
-    } else {
 #pragma unroll 4
-        for (int n = tid; n < tile_in; n += NT) {
-            T v{};
-            if (in0 + n < n_in) v = x[in0 + n];
-            put(n, v);
-        }
-    }
-    __syncthreads();
-    T acc[R];
+            for (int v = vfirst; v < nv; v += NT) {
+                const int n = v * VEC;
+                if (in0 + n + VEC <= n_in) {
+                    const float4 q = x4[v];
+                    if constexpr (sizeof(T) == 8) {
+                        put(n, T{q.x, q.y}); put(n + 1, T{q.z, q.w});
+                    } else {
+                        put(n, q.x); put(n + 1, q.y); put(n + 2, q.z); put(n + 3, q.w);
+                    }
+                } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = T{};
-    const int base = tid * (LSTR + (PAD ? 1 : 0));
-    fir_chunks<T, D, R, FUSED, CHW>(xs, base, K, taps, acc);
-    const long o0 = (long)blockIdx.x * TILE_OUT;
-    // outputs through LDS: element e of the tile sits at ys[(e / R) * (R + 1) + e % R]
-    __syncthreads(); // every wave is done with the input tile
-    T *ys = xs;
-#pragma unroll
-    for (int r = 0; r < R; ++r) ys[tid * (R + 1) + r] = acc[r];
-    __syncthreads();
-    const long left = n_out - o0; // outputs of this tile that exist
-#pragma unroll
-    for (int v = tid; v < TILE_OUT / VEC; v += NT) {
-        const int e0 = v * VEC;
-        T o[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] = ys[((e0 + e) / R) * (R + 1) + ((e0 + e) & (R - 1))];
-        if (vec_out && e0 + VEC <= left) {
-            const float *f = reinterpret_cast<const float *>(o);
-            reinterpret_cast<float4 *>(y + o0)[v] = make_float4(f[0], f[1], f[2], f[3]);
+                    for (int e = 0; e < VEC; ++e) {
+                        T v1{};
+                        if (in0 + n + e < n_in) v1 = x[in0 + n + e];
+                        put(n + e, v1); // at most VEC - 1 elements past tile_in: inside the allocation (launch_chunked)
+                    }
+                }
+            }
         } else {
+#pragma unroll 4
+            for (int n = tid; n < tile_in; n += NT) {
+                T v{};
+                if (in0 + n < n_in) v = x[in0 + n];
+                put(n, v);
+            }
+        }
+        __syncthreads();
+        T acc[R];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                if (e0 + e < left) y[o0 + e0 + e] = o[e];
+        for (int r = 0; r < R; ++r) acc[r] = T{};
+        const int base = tid * (LSTR + (PAD ? 1 : 0));
+        fir_chunks<T, D, R, FUSED, CHW>(xs, base, K, taps, acc);
+        const long o0 = t * TILE_OUT;
+        // outputs through LDS: element e of the tile sits at ys[(e / R) * (R + 1) + e % R]
+        __syncthreads(); // every wave is done with the input tile
+        T *ys = xs;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ys[tid * (R + 1) + r] = acc[r];
+        __syncthreads();
+        const long left = n_out - o0; // outputs of this tile that exist
+#pragma unroll
+        for (int v = tid; v < TILE_OUT / VEC; v += NT) {
+            const int e0 = v * VEC;
+            T o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = ys[((e0 + e) / R) * (R + 1) + ((e0 + e) & (R - 1))];
+            if (vec_out && e0 + VEC <= left) {
+                const float *f = reinterpret_cast<const float *>(o);
+                reinterpret_cast<float4 *>(y + o0)[v] = make_float4(f[0], f[1], f[2], f[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (e0 + e < left) y[o0 + e0 + e] = o[e];
+            }
         }
     }
 }
@@ -246,13 +309,14 @@ static hipError_t launch_fir_t(const T *x, long n_in, const float *taps, int K, 
     {   // any tap count with a common decimation: the chunked tiled kernel (falls through if the tile cannot fit LDS)
         hipError_t e = hipErrorNotSupported;
         switch (D) {
-        case 1: e = launch_chunked<T, 1, 8, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 2: e = launch_chunked<T, 2, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 3: e = launch_chunked<T, 3, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 4: e = launch_chunked<T, 4, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 5: e = launch_chunked<T, 5, 4, FUSED, 32>(x, n_in, taps, K, y, n_out, s); break; // 32-tap chunks: +7 % at this decimation
-        case 8: e = launch_chunked<T, 8, 2, FUSED>(x, n_in, taps, K, y, n_out, s); break;
-        case 10: e = launch_chunked<T, 10, 2, FUSED, 32>(x, n_in, taps, K, y, n_out, s); break; // +10 %
+        // whole-chunk sizes: a multiple of the lane stride R*D wherever the image is padded (immediate window offsets, fir_chunk)
+        case 1: e = launch_chunked<T, 1, 8, FUSED>(x, n_in, taps, K, y, n_out, s); break;          // lane stride 8, chunks of 16
+        case 2: e = launch_chunked<T, 2, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;          // 8, 16
+        case 3: e = launch_chunked<T, 3, 4, FUSED, 24>(x, n_in, taps, K, y, n_out, s); break;      // 12, 24
+        case 4: e = launch_chunked<T, 4, 4, FUSED>(x, n_in, taps, K, y, n_out, s); break;          // 16, 16
+        case 5: e = launch_chunked<T, 5, 4, FUSED, 40>(x, n_in, taps, K, y, n_out, s); break;      // 20, 40
+        case 8: e = launch_chunked<T, 8, 2, FUSED>(x, n_in, taps, K, y, n_out, s); break;          // 16, 16
+        case 10: e = launch_chunked<T, 10, 2, FUSED, 40>(x, n_in, taps, K, y, n_out, s); break;    // 20, 40 (1 or 4 outputs per lane: 0.267 / 0.304 ms against 0.197)
         default: break;
         }
         if (e != hipErrorNotSupported) return e;
@@ -267,7 +331,7 @@ hipError_t launch_fir_v4(int K, int D, const float2 *x, const float *taps, float
 hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D, void *y, long n_out,
                       bool cplx, bool fused, hipStream_t s)
 {
-    // the shapes the chain kernel is built for (127 / 63 taps, decimation 5 / 3 / 1) run on its data path (wave-private images,
+    // the shapes the chain kernel is built for (127 / 63 taps / 5, 63 taps / 1) run on its data path (wave-private images,
     // halo carried in LDS, register prefetch): whole 1024-output blocks there, the remainder on the tiled kernel
     if (cplx && n_out >= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && !getenv("REDIO_FIR_NO_V4")) {
         const long nblocks = n_out / 1024;
