@@ -820,11 +820,19 @@ __global__ __launch_bounds__(64 * SrcFastP<NPAIR>::W) void src_window_fastp_kern
         int gl = g0;
         asm volatile("" : "+v"(off0), "+v"(gl)); // per tile: the 64 request offsets are recomputed from this one, not kept alive across the tile loop
         if (nsplit == 0 || nsplit >= need) { // ONE source
-            const auto r = nsplit == 0 ? r_new : r_old;
+            // round u reads doff*u bytes further on: the advance goes into the descriptor (scalar arithmetic: base + doff*u, range - doff*u),
+            // every round uses the lane's one offset register -- no vector instruction per request.  A round past the image reads
+            // behind `need` (+0.0f) or a sample nobody uses; its store goes to the spare cell either way.
+            const char *srcp = reinterpret_cast<const char *>(nsplit == 0 ? src_new : src_old);
+            const int range = 4 * need;
+            int dstep = (int)doff;
+            asm volatile("" : "+s"(dstep)); // per tile: the 64 advances are recomputed, not kept in 64 scalar registers across the tile loop
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const unsigned off = gl + GI * u < NGROUPS ? off0 + doff * u : 0x80000000u;
-                pf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+                const int adv = dstep * u, rem = range - adv;
+                const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(srcp + adv), 0, rem > 0 ? rem : 0, 0x00020000);
+                pf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off0, 0, 0));
+                RD_SCHED_BARRIER(); // a descriptor is built where it is used (hoisted together the 64 of them spill)
             }
         } else { // the one tile of a call that straddles the two sources: both descriptors, eight samples at a time
 #pragma unroll
@@ -858,10 +866,20 @@ __global__ __launch_bounds__(64 * SrcFastP<NPAIR>::W) void src_window_fastp_kern
         }
         char *lds = smem;
         const unsigned step = 8u * (unsigned)GI, glimit = (unsigned)NGROUPS - gg; // store u is inside the image iff GI*u < glimit
+        // rounds u0 .. u0+7 are inside the image for every active lane (gg < GI) if GI*(u0+8) <= NGROUPS: a wave-uniform test per eight
+        // stores, and one vector add per store; only the last rounds pay the per-lane test and the select
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const unsigned addr = (unsigned)(GI * u) < glimit ? a8[u % 8] + step * (unsigned)(u / 8) : spare;
-            *reinterpret_cast<float *>(lds + addr) = pf[u];
+        for (int u0 = 0; u0 < PF; u0 += 8) {
+            if (GI * (u0 + 8) <= NGROUPS) {
+#pragma unroll
+                for (int u = u0; u < u0 + 8; ++u) *reinterpret_cast<float *>(lds + (a8[u % 8] + step * (unsigned)(u / 8))) = pf[u];
+            } else {
+#pragma unroll
+                for (int u = u0; u < u0 + 8; ++u) {
+                    const unsigned addr = (unsigned)(GI * u) < glimit ? a8[u % 8] + step * (unsigned)(u / 8) : spare;
+                    *reinterpret_cast<float *>(lds + addr) = pf[u];
+                }
+            }
         }
     };
     if (ntile > 0) { prefetch(t0); store_image(); }
