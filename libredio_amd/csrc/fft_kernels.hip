@@ -799,6 +799,9 @@ struct TwOrdered {
 // (the fourth slot pads the entry to 32 bytes).  A butterfly's three twiddles are then one 16-byte and one 8-byte load from one
 // 32-byte entry instead of three 8-byte loads from three planes m entries apart -- measured on the access pattern alone: the
 // in-place pass of 65536 points 283 -> 233 us per 2^26 points, of 2^24 points 318 -> 254 (profiles/r02_fft_pass_times.txt).
+// Round 3: a tile reads 43 KB of these entries for its 32 KB of samples, all from L2 -- and a timing-only build in which every lane reads
+// entry k mod 16 runs the in-place pass of 65536 points in 253 us against 246, the overlap-save passes in 32.1 / 46.0 us against 33.6 / 47.2:
+// the twiddle traffic is not what holds the passes at 4.2-5.5 TB/s, so a workgroup-resident LDS copy of them was not built.
 struct TwInter {
     const float2 *T;
     __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[4 * k + (n - 1)]; }
