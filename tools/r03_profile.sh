@@ -25,7 +25,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INS
 cd $R
 {
   echo "# chain_v4_kernel (fmaf build), mean per launch (bench.py --steps 20 --warmup 5 --steady 0, rocprofv3 --pmc, one pass per line group)"
-  python3 profiles/pmc_summary.py "chain_v4_kernel<127, 5, true" $O/${TAG}_p_fetch $O/${TAG}_p_write $O/${TAG}_p_sq1 $O/${TAG}_p_sq2 $O/${TAG}_p_sq3
+  python3 profiles/pmc_summary.py "chain_v4_kernel<127, 5, true, 2, 8, false, true, false>" $O/${TAG}_p_fetch $O/${TAG}_p_write $O/${TAG}_p_sq1 $O/${TAG}_p_sq2 $O/${TAG}_p_sq3
 } > $O/${TAG}_chain_pmc_summary.txt 2>&1
 cat $O/${TAG}_chain_pmc_summary.txt
 find $O/${TAG}_p_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_chain_v4_kernel_stats.csv
