@@ -2241,14 +2241,72 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_first_kernel(const floa
     }
 }
 
+// Round 3: one launch per chunk step with all THREE tile programs interleaved -- the middle pass of chunk k (a[k & 1] -> b[k & 1]), the last
+// pass of chunk k - 1 (b[(k - 1) & 1] -> out) and the gather pass of chunk k + 1 (x -> a[(k + 1) & 1]); the three are independent once the
+// work buffers are doubled.  A 64 MiB chunk is exactly one resident set of wavefronts per pass: launched alone, the middle pass has every
+// wave of the chip in its load phase, then its arithmetic, then its store phase at the same time; mixed with the other two programs the
+// phases of different waves overlap.
+struct Ovs64kStep {
+    const float2 *a_in; float2 *b_out; long nt_mid;                 // middle pass
+    const float2 *b_in; float2 *out; long nt_last;                  // last pass
+    const float2 *x_next; float2 *a_out; long nt_first;             // gather pass
+};
+__global__ __launch_bounds__(256, 2) void ovsave64k_step_kernel(Ovs64kStep st, const float2 *__restrict__ Tf, const float2 *__restrict__ Ti,
+                                                             const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
+                                                             const float2 *__restrict__ Hc, const float2 *__restrict__ T1, long hop, float scale)
+{
+    __shared__ float2 Ls[4 * F64W_REGION];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *Lw = Ls + w * F64W_REGION;
+    // workgroup b -> (kind, workgroup of that kind): round r hands one workgroup to every kind that still has more than r
+    const long n[3] = {(st.nt_mid + 3) / 4, (st.nt_last + 3) / 4, (st.nt_first + 3) / 4};
+    long lo = n[0] < n[1] ? n[0] : n[1]; lo = lo < n[2] ? lo : n[2];
+    long hi = n[0] > n[1] ? n[0] : n[1]; hi = hi > n[2] ? hi : n[2];
+    const long md = n[0] + n[1] + n[2] - lo - hi;
+    long b = blockIdx.x, r;
+    int kind = 0, skip;
+    if (b < 3 * lo) { r = b / 3; skip = (int)(b - 3 * r); for (kind = 0; skip > 0; ++kind) --skip; }
+    else if ((b -= 3 * lo) < 2 * (md - lo)) {
+        r = lo + b / 2; skip = (int)(b & 1);
+        for (kind = 0; kind < 3; ++kind) if (n[kind] > lo && skip-- == 0) break;
+    } else {
+        r = md + (b - 2 * (md - lo));
+        for (kind = 0; kind < 3; ++kind) if (n[kind] > md) break;
+    }
+    const long tile = r * 4 + w;
+    if (kind == 0) {
+        if (tile >= st.nt_mid) return;
+        ovsave64k_mid_tile(st.a_in + (tile >> 4) * F64K_N, st.b_out + (tile >> 4) * F64K_N, Tf, tw_i, Hc, (int)(tile & 15), lane, Lw);
+    } else if (kind == 1) {
+        if (tile >= st.nt_last) return;
+        ovsave64k_last_tile(st.b_in + (tile >> 4) * (long)F64K_N, st.out + (tile >> 4) * hop, Ti, hop, scale, (int)(tile & 15), lane, Lw);
+    } else {
+        if (tile >= st.nt_first) return;
+        fftbig_first_tile<false>(st.x_next + (tile >> 4) * hop, st.a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr, T1);
+    }
+}
+
 // nblk blocks in chunks of `chunk` blocks (the work buffers a, b hold one chunk each)
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
-                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, long chunk, float scale, hipStream_t s)
+                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, long chunk, float scale, hipStream_t s, bool doubled)
 {
     if (!Tf || !Ti || chunk < 1) return hipErrorInvalidValue; // the plans' pass-ordered twiddle copies (fftbig_tables_build)
     auto tiles = [&](long b0) { const long nb = nblk - b0 < chunk ? nblk - b0 : chunk; return nb * 16; };
     const float2 *T1 = Tf + (fftbig_tables_elems(F64K_N) - fftbig_first_elems(16)); // the forward plan's gather-pass copy
     hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8, nullptr, T1);
+    static const bool fused3 = !getenv("REDIO_OVS_NO_STEP"); // measurement knob: the two-launch form below
+    if (fused3 && doubled) { // a, b hold TWO chunks each
+        const long nchunks = (nblk + chunk - 1) / chunk, half = chunk * (long)F64K_N;
+        for (long k = 0; k <= nchunks; ++k) {
+            Ovs64kStep st = {};
+            if (k < nchunks) { st.a_in = a + (k & 1) * half; st.b_out = b + (k & 1) * half; st.nt_mid = tiles(k * chunk); }
+            if (k >= 1) { st.b_in = b + ((k - 1) & 1) * half; st.out = out + (k - 1) * chunk * hop; st.nt_last = tiles((k - 1) * chunk); }
+            if (k + 1 < nchunks) { st.x_next = x + (k + 1) * chunk * hop; st.a_out = a + ((k + 1) & 1) * half; st.nt_first = tiles((k + 1) * chunk); }
+            const unsigned grid = (unsigned)((st.nt_mid + 3) / 4 + (st.nt_last + 3) / 4 + (st.nt_first + 3) / 4);
+            hipLaunchKernelGGL(ovsave64k_step_kernel, dim3(grid), dim3(256), 0, s, st, Tf, Ti, tw_f, tw_i, Hc, T1, hop, scale);
+        }
+        return hipGetLastError();
+    }
     for (long b0 = 0; b0 < nblk; b0 += chunk) {
         const long nt = tiles(b0), next = b0 + chunk;
         hipLaunchKernelGGL(ovsave64k_mid_wave_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, a, b, Tf, tw_i, Hc, nt);

@@ -70,7 +70,7 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     const bool one_kernel = nfft == 1024 || nfft == 2048 || nfft == 4096 || nfft == 8192 || nfft == 16384;
     // 64 MiB per buffer: swept 16 ... 128 MiB at 65536 points in round 2 (profiles/r02_c5_team_experiment.txt): 64 is best, 128 -- past the
     // Infinity Cache -- costs 6 %
-    size_t chunk_mib = 64; // at 65536 points: one resident set of waves per launch (32 and 96 MiB measured slower)
+    size_t chunk_mib = 64; // at 65536 points: one resident set of waves per pass, three per step launch (round 3: 21 / 56 / 64 MiB 2.76-2.80 ms, 42 / 80 / 96 MiB 2.97-3.05)
     if (const char *e = getenv("REDIO_OVS_CHUNK_MIB")) { const long v = atol(e); if (v >= 1) chunk_mib = (size_t)v; } // measurement only
     p->chunk_blocks = (chunk_mib << 20) / ((size_t)nfft * sizeof(float2));
     if (p->chunk_blocks < 1) p->chunk_blocks = 1;
@@ -80,8 +80,9 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     if (rc == REDIO_OK) {
         float2 *d_pad = nullptr; // the zero-padded taps, transformed once
         e = hipMalloc((void **)&p->d_Hc, (size_t)nfft * sizeof(float2));
-        if (e == hipSuccess && !one_kernel) e = hipMalloc((void **)&p->d_a, p->chunk_blocks * nfft * sizeof(float2));
-        if (e == hipSuccess && !one_kernel) e = hipMalloc((void **)&p->d_b, p->chunk_blocks * nfft * sizeof(float2));
+        const size_t nbuf = nfft == F64K_N ? 2 : 1; // 65536 points: two chunks per buffer (launch_ovsave64k's step launches)
+        if (e == hipSuccess && !one_kernel) e = hipMalloc((void **)&p->d_a, nbuf * p->chunk_blocks * nfft * sizeof(float2));
+        if (e == hipSuccess && !one_kernel) e = hipMalloc((void **)&p->d_b, nbuf * p->chunk_blocks * nfft * sizeof(float2));
         if (e == hipSuccess) {
             if (one_kernel) e = hipMalloc((void **)&d_pad, (size_t)nfft * sizeof(float2));
             else d_pad = p->d_a;
@@ -163,10 +164,10 @@ extern "C" int redio_ovsave_enqueue(redio_ovsave *h, const void *d_in, size_t n_
                                 (float2 *)d_out, (long)nblk, scale, st));
         return REDIO_OK;
     }
-    if (h->nfft == F64K_N) { // three fused passes per chunk, the last of a chunk sharing a launch with the first of the next (fft_kernels.hip)
+    if (h->nfft == F64K_N) { // three passes per chunk; one launch per step runs the middle pass of chunk k, the last of k - 1 and the first of k + 1 (fft_kernels.hip)
         OV_TRY(launch_ovsave64k((const float2 *)d_in, (long)h->hop, h->d_a, h->d_b, redio_fft_twiddles_dev(h->fw), redio_fft_twiddles_dev(h->bw),
                                 redio_fft_twiddles_pass_dev(h->fw), redio_fft_twiddles_pass_dev(h->bw), h->d_Hc, (float2 *)d_out, (long)nblk,
-                                (long)h->chunk_blocks, scale, st));
+                                (long)h->chunk_blocks, scale, st, true));
         return REDIO_OK;
     }
     for (size_t b0 = 0; b0 < nblk; b0 += h->chunk_blocks) {

@@ -45,9 +45,10 @@ hipError_t launch_ovsave4k(const float2 *x, long hop, const float2 *tw_f, const 
                            float scale, hipStream_t s);
 hipError_t launch_ovsave16k(const float2 *x, long hop, const float2 *tw_f, const float2 *tw_i, const float2 *Tf, const float2 *Ti, const float2 *Hc,
                             float2 *out, long nblk, float scale, hipStream_t s); // the same at nfft 16384
-// overlap-save at nfft 65536: x (block b at x + b*hop) -> out (hop valid samples per block), work buffers a, b
+// overlap-save at nfft 65536: x (block b at x + b*hop) -> out (hop valid samples per block), work buffers a, b of `chunk` blocks each
+// (doubled: two chunks each -- the three passes of consecutive chunks then share one launch per step)
 hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, const float2 *tw_f, const float2 *tw_i, const float2 *Tf,
-                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, long chunk, float scale, hipStream_t s);
+                            const float2 *Ti, const float2 *Hc, float2 *out, long nblk, long chunk, float scale, hipStream_t s, bool doubled);
 
 // chain_kernels.hip : FIR(K taps, decimate D) -> nfft-point forward transform, fused
 bool chain_supported(int K, long D, int nfft);
