@@ -2139,7 +2139,8 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
 // Consecutive passes walk the batch in opposite directions (round 3): a pass reads what the pass before it wrote, and starts with what that
 // pass wrote last -- the part of the intermediate the 256 MB Infinity Cache still holds.  65536 points, second pass alone: 247 -> 208 us per
 // 2^26 points; the transform 0.431 -> 0.392 ms (2^28 points: 1.559 -> 1.505).  Running the passes chunk by chunk instead (32 ... 1024 MiB
-// of output per chunk, so that the whole intermediate stays cached) was measured too: no better at any size, worse below 256 MiB (tails).
+// of output per chunk, so that the whole intermediate stays cached) was measured too: no better at any size, worse below 256 MiB (tails);
+// so were chunk steps with both passes' workgroups alternating in one launch (the overlap-save scheme below): 0.413 against 0.395 ms.
 template <bool INV>
 static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw, const float2 *tables, long nbatch, long in_stride, int lgN,
                                 hipStream_t s, const float2 *mulH = nullptr, float2 *vout = nullptr, long hop = 0, float scale = 1.0f)

@@ -165,6 +165,26 @@ def test_fft_large_global_path(gpu, redio, oracle, n):
     assert same_bits(d.cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_65536_large_batch(gpu, redio, oracle, inverse):
+    """A batch of 65536-point transforms well past the Infinity Cache (401 transforms, 210 MB each way): the second pass walks the batch
+    against the first (fft_kernels.hip launch_fftbig).  Transforms spread over the batch, the first and the last against the oracle; the
+    whole batch against the same transforms computed in two calls; in place."""
+    n, nb = 65536, 401
+    x = redio.synth_iq(0x5EED0016, 0, n * nb)
+    plan = redio.Fft(n, inverse)
+    y = plan(x)
+    for b in (0, 1, 127, 128, 129, 255, 256, 257, 383, 384, 385, nb - 1):
+        xw = oracle.synth_iq(0x5EED0016, n * b, n)
+        assert same_bits(y[n * b: n * (b + 1)].cpu().numpy(), oracle.fft(xw, n, inverse)), (inverse, b)
+    half = 200 * n
+    y2 = gpu.cat([plan(x[:half]), plan(x[half:])])
+    assert gpu.equal(y, y2)
+    z = x.clone()
+    plan(z, out=z)  # in place
+    assert gpu.equal(y, z)
+
+
 @pytest.mark.parametrize("n", [16875, 17280, 18000, 20000, 30000, 48000, 50000, 65610, 78125, 100000, 196608, 250000, 1000000, 1594323])
 def test_fft_large_mixed_radix_tile_passes(gpu, redio, oracle, n):
     # radix-2/3/4/5 sizes above 16384 that are not powers of two: one LDS tile pass per group of stages (fft_tile_pass_kernel)
