@@ -1907,6 +1907,54 @@ __global__ __launch_bounds__(256) void ovsave8k_wave_kernel(const float2 *__rest
 // source, 16 neighbouring source columns) and writes every column as one run of G positions of the working order; the later
 // groups work in place on rows m_lo apart.  One pass per group instead of one launch per stage.
 struct FtpMagic { unsigned ml[12]; unsigned g; }; // ceil(2^32 / d) of the group's sub-lengths in rows and of G: exact quotients of numbers below 2^16
+constexpr int FTP_MAX_POINTS = 4096; // points per tile (8192-point tiles with 512-byte row pieces were measured: slower, as were 2048 and 1024)
+// one stage of a tile pass for the radix P: a thread's butterflies (at most IT of them) in two sweeps -- first every butterfly's twiddle
+// loads (global memory, L2), then the butterflies -- so that a stage waits for its twiddles once, not once per butterfly (round 3; the
+// SQ counters of the one-sweep form: 73 % of the wave cycles waiting).  Requesting the first three stages' twiddles before the tile's
+// samples instead (they depend on the thread and the stage only) was measured as well: slower, 65 against 79 GS/s at 20000 points.
+// kbase < 0: the gather pass, whose columns are whole sub-transforms (the twiddle index has no column part).
+template <bool INV, int P>
+__device__ __forceinline__ void ftp_stage(float2 *L, int LD, int lcw, int CW, int ncol, int nb, int ml, unsigned magic_ml, int m, int m_lo, int kbase,
+                                          const float2 *__restrict__ T, float2 epi1, float2 epi2, int tid)
+{
+    constexpr int IT = (FTP_MAX_POINTS / P + 255) / 256;
+    float2 tw[IT][P - 1];
+    int off[IT];
+    const int rs = ml * LD;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int e = tid + 256 * it;
+        const int bf = e >> lcw, col = e & (CW - 1);
+        const bool on = e < nb * CW && col < ncol;
+        const int blk = ml == 1 ? bf : (int)__umulhi((unsigned)bf, magic_ml), kl = bf - blk * ml;
+        off[it] = on ? (blk * P * ml + kl) * LD + col : -1;
+        const int k = on ? (kbase < 0 ? 0 : kbase + col) + m_lo * kl : 0; // e mod m
+#pragma unroll
+        for (int n = 0; n < P - 1; ++n) tw[it][n] = T[n * m + k];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (off[it] < 0) continue;
+        float2 *q = L + off[it];
+        if constexpr (P == 2) {
+            float2 a0 = q[0], a1 = q[rs];
+            bfly2(a0, a1, tw[it][0]);
+            q[0] = a0; q[rs] = a1;
+        } else if constexpr (P == 3) {
+            float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs];
+            bfly3(a0, a1, a2, tw[it][0], tw[it][1], epi1);
+            q[0] = a0; q[rs] = a1; q[2 * rs] = a2;
+        } else if constexpr (P == 4) {
+            float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs];
+            bfly4<INV>(a0, a1, a2, a3, tw[it][0], tw[it][1], tw[it][2]);
+            q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3;
+        } else {
+            float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs], a4 = q[4 * rs];
+            bfly5(a0, a1, a2, a3, a4, tw[it][0], tw[it][1], tw[it][2], tw[it][3], epi1, epi2);
+            q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3; q[4 * rs] = a4;
+        }
+    }
+}
 template <bool INV>
 __global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const float2 *src, float2 *dst, int s_hi, int s_lo, int G, int m_lo,
                                                             int first, long in_stride, int tiles_per_xf, int lcw, FtpMagic mg, int rev)
@@ -1939,11 +1987,20 @@ __global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const 
         }
         __syncthreads();
     }
-    for (int e = tid; e < G * CW; e += 256) {
-        const int g = e >> lcw, col = e & (CW - 1);
-        if (col >= ncol) continue;
-        const int idx = first ? rowsrc[g] + CW * c + col : h * G * m_lo + g * m_lo + CW * c + col;
-        L[g * LD + col] = in[idx];
+    for (int e0 = tid; e0 < G * CW; e0 += 256 * 8) { // eight loads in flight per thread
+        float2 v[8];
+        int at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, g = e >> lcw, col = e & (CW - 1);
+            const bool on = e < G * CW && col < ncol;
+            at[u] = on ? g * LD + col : -1;
+            const int idx = !on ? 0 : first ? rowsrc[g] + CW * c + col : h * G * m_lo + g * m_lo + CW * c + col;
+            v[u] = in[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (at[u] >= 0) L[at[u]] = v[u];
     }
     __syncthreads();
     for (int s = s_hi; s >= s_lo; --s) { // innermost stage of the group first
@@ -1952,32 +2009,12 @@ __global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const 
         int toff = 0; // the stage's block of the stage-ordered twiddle copy: T[(n - 1) m + k] = tw[n k fstride]
         for (int u = 0; u < s; ++u) toff += (p.st[u].p - 1) * p.st[u].m;
         const float2 *__restrict__ T = p.tw_pass + toff;
-        for (int e = tid; e < nb * CW; e += 256) {
-            const int bf = e >> lcw, col = e & (CW - 1);
-            if (col >= ncol) continue;
-            const int blk = ml == 1 ? bf : (int)__umulhi((unsigned)bf, mg.ml[s_hi - s]), kl = bf - blk * ml;
-            const int row0 = blk * P * ml + kl;
-            const int k = (first ? 0 : CW * c + col) + m_lo * kl; // e mod m
-            float2 *q = L + row0 * LD + col;
-            const int rs = ml * LD;
-            if (P == 2) {
-                float2 a0 = q[0], a1 = q[rs];
-                bfly2(a0, a1, T[k]);
-                q[0] = a0; q[rs] = a1;
-            } else if (P == 3) {
-                float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs];
-                bfly3(a0, a1, a2, T[k], T[m + k], p.tw[fs * m]);
-                q[0] = a0; q[rs] = a1; q[2 * rs] = a2;
-            } else if (P == 4) {
-                float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs];
-                bfly4<INV>(a0, a1, a2, a3, T[k], T[m + k], T[2 * m + k]);
-                q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3;
-            } else {
-                float2 a0 = q[0], a1 = q[rs], a2 = q[2 * rs], a3 = q[3 * rs], a4 = q[4 * rs];
-                bfly5(a0, a1, a2, a3, a4, T[k], T[m + k], T[2 * m + k], T[3 * m + k], p.tw[fs * m], p.tw[fs * 2 * m]);
-                q[0] = a0; q[rs] = a1; q[2 * rs] = a2; q[3 * rs] = a3; q[4 * rs] = a4;
-            }
-        }
+        const int kbase = first ? -1 : CW * c;
+        const unsigned mgl = mg.ml[s_hi - s];
+        if (P == 2) ftp_stage<INV, 2>(L, LD, lcw, CW, ncol, nb, ml, mgl, m, m_lo, kbase, T, float2{}, float2{}, tid);
+        else if (P == 3) ftp_stage<INV, 3>(L, LD, lcw, CW, ncol, nb, ml, mgl, m, m_lo, kbase, T, p.tw[fs * m], float2{}, tid);
+        else if (P == 4) ftp_stage<INV, 4>(L, LD, lcw, CW, ncol, nb, ml, mgl, m, m_lo, kbase, T, float2{}, float2{}, tid);
+        else ftp_stage<INV, 5>(L, LD, lcw, CW, ncol, nb, ml, mgl, m, m_lo, kbase, T, p.tw[fs * m], p.tw[fs * 2 * m], tid);
         __syncthreads();
     }
     if (first) { // source column r -> column hh of the working order (the outer stages' digits), G contiguous positions each
@@ -1987,10 +2024,18 @@ __global__ __launch_bounds__(256) void fft_tile_pass_kernel(FftPlanDev p, const 
             out[(long)hcol[col] * G + g] = L[g * LD + col];
         }
     } else {
-        for (int e = tid; e < G * CW; e += 256) {
-            const int g = e >> lcw, col = e & (CW - 1);
-            if (col >= ncol) continue;
-            out[h * G * m_lo + g * m_lo + CW * c + col] = L[g * LD + col];
+        for (int e0 = tid; e0 < G * CW; e0 += 256 * 8) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u, g = e >> lcw, col = e & (CW - 1);
+                v[u] = e < G * CW ? L[g * LD + col] : float2{};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u, g = e >> lcw, col = e & (CW - 1);
+                if (e < G * CW && col < ncol) out[h * G * m_lo + g * m_lo + CW * c + col] = v[u];
+            }
         }
     }
 }
@@ -2024,7 +2069,7 @@ static hipError_t launch_fft_tile_passes(const FftPlanDev &p, const float2 *in, 
         int G = 1;
         for (int t = s_lo; t <= s_hi; ++t) G *= p.st[t].p;
         int lcw = 4; // columns per tile: 16 ... 256, about 4096 points per tile
-        while (lcw < 8 && (G << (lcw + 1)) <= 4096) ++lcw;
+        while (lcw < 8 && (G << (lcw + 1)) <= FTP_MAX_POINTS) ++lcw;
         const int CW = 1 << lcw, width = first ? p.nfft / G : m_lo;
         const int colblk = (width + CW - 1) / CW;
         const int tiles = first ? colblk : colblk * (p.nfft / (G * m_lo));
