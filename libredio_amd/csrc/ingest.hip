@@ -224,10 +224,11 @@ __global__ __launch_bounds__(256) void gather_blocks_kernel(const float *__restr
     for (int i = threadIdx.x; i < block; i += blockDim.x) d[i] = s[i];
 }
 
-static unsigned grid_for(long n, int per = 256)
+// `per` items per workgroup, at most `cap` workgroups (the kernels walk the rest with a grid stride)
+static unsigned grid_for(long n, int per = 256, long cap = 16384)
 {
     long g = (n + per - 1) / per;
-    return (unsigned)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
 } // namespace redio
@@ -242,7 +243,9 @@ extern "C" int redio_data_to_samples(const void *d_bytes, size_t nbytes, void *d
     if (nbytes == 0) return REDIO_OK;
     if (!d_bytes || !d_out) return REDIO_ERR_ARG;
     const long ns = (long)(nbytes / 2);
-    hipLaunchKernelGGL(data_to_samples_kernel, dim3(grid_for(ns)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float2 *)d_out, ns);
+    // four 4-byte loads (16-byte stores) per thread, workgroups in dispatch order: swept over 1 ... 128 per thread at 2^28 samples (round 3), 0.466 ms
+    // against 0.557 with the grid capped at 16384 workgroups and 0.607 with one load per thread
+    hipLaunchKernelGGL(data_to_samples_kernel, dim3(grid_for(ns / 2, 1024, 0x7fffffffL)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float2 *)d_out, ns);
     return hip_rc(hipGetLastError());
 }
 
