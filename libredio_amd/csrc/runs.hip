@@ -13,7 +13,9 @@
 
 namespace redio {
 
-constexpr int RUN_TILE = 2048; // elements per workgroup in the change-flag scan (8 per thread)
+constexpr int RUN_ROUND = 2048; // elements per workgroup round in the change-flag scan (8 consecutive per thread)
+constexpr int RUN_ROUNDS = 8;   // rounds per workgroup: 16384-element tiles, so that the one-workgroup scan of the tile counts stays short
+constexpr int RUN_TILE = RUN_ROUND * RUN_ROUNDS;
 
 __device__ __forceinline__ int is_change(const uint8_t *__restrict__ x, long i, int have_prev, uint8_t prev)
 {
@@ -23,12 +25,16 @@ __device__ __forceinline__ int is_change(const uint8_t *__restrict__ x, long i, 
 
 // change flags of the 8 consecutive elements i0 .. i0+7 as a bit mask (bit k: element i0+k differs from
 // its predecessor).  One 8-byte load when the group is whole and x + i0 is 8-byte aligned.
-__device__ __forceinline__ unsigned change_mask8(const uint8_t *__restrict__ x, long i0, long n, int have_prev, uint8_t prev, bool aligned)
+// before8 (optional): byte k = the value in front of element i0 + k, i.e. the value of the run that a change at i0 + k ends.
+__device__ __forceinline__ unsigned change_mask8(const uint8_t *__restrict__ x, long i0, long n, int have_prev, uint8_t prev, bool aligned,
+                                                 unsigned long long *before8 = nullptr)
 {
+    if (before8) *before8 = 0;
     if (i0 >= n) return 0;
     if (aligned && i0 + 8 <= n) {
         const unsigned long long w = *reinterpret_cast<const unsigned long long *>(x + i0);
         const unsigned long long before = i0 == 0 ? (have_prev ? prev : (w & 0xff)) : x[i0 - 1];
+        if (before8) *before8 = (w << 8) | before;
         const unsigned long long d = w ^ ((w << 8) | before);
         // byte k of d is non-zero  <=>  bit 7 of byte k of nz is set
         const unsigned long long nz = (((d & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | d) & 0x8080808080808080ull;
@@ -37,7 +43,10 @@ __device__ __forceinline__ unsigned change_mask8(const uint8_t *__restrict__ x, 
     }
     unsigned m = 0;
     for (int k = 0; k < 8; ++k)
-        if (i0 + k < n && is_change(x, i0 + k, have_prev, prev)) m |= 1u << k;
+        if (i0 + k < n && is_change(x, i0 + k, have_prev, prev)) {
+            m |= 1u << k;
+            if (before8) *before8 |= (unsigned long long)(i0 + k == 0 ? prev : x[i0 + k - 1]) << (8 * k);
+        }
     return m;
 }
 
@@ -45,9 +54,10 @@ __device__ __forceinline__ unsigned change_mask8(const uint8_t *__restrict__ x, 
 __global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t *__restrict__ x, long n, int have_prev, uint8_t prev,
                                                         unsigned *__restrict__ tile_counts)
 {
-    const long i0 = (long)blockIdx.x * RUN_TILE + (long)threadIdx.x * 8;
     const bool aligned = ((uintptr_t)x & 7) == 0;
-    int c = __popc(change_mask8(x, i0, n, have_prev, prev, aligned));
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < RUN_ROUNDS; ++r) c += __popc(change_mask8(x, (long)blockIdx.x * RUN_TILE + r * RUN_ROUND + (long)threadIdx.x * 8, n, have_prev, prev, aligned));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     __shared__ int ws[4];
@@ -56,16 +66,23 @@ __global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t *__restric
     if (threadIdx.x == 0) tile_counts[blockIdx.x] = (unsigned)(ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
-// pass 2: exclusive scan of the tile counts (one workgroup; tiles <= a few hundred thousand)
+// pass 2: exclusive scan of the tile counts (one workgroup; tiles <= a few hundred thousand).  A thread owns EIGHT consecutive counts per
+// round (round 3: with one count per thread the 131072 tiles of a 2^28-byte message took 128 rounds of three barriers each, 184 us --
+// as long as the pass over the bytes)
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(unsigned *__restrict__ counts, long ntiles, unsigned long long *__restrict__ total)
 {
+    constexpr int PER = 8;
     __shared__ unsigned long long carry;
     __shared__ unsigned long long ws[16];
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (long base = 0; base < ntiles; base += 1024) {
-        const long i = base + threadIdx.x;
-        unsigned long long v = i < ntiles ? counts[i] : 0, incl = v;
+    for (long base = 0; base < ntiles; base += 1024 * PER) {
+        const long i0 = base + (long)threadIdx.x * PER;
+        unsigned v[PER];
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { v[k] = i0 + k < ntiles ? counts[i0 + k] : 0u; sum += v[k]; }
+        unsigned long long incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             unsigned long long o = __shfl_up(incl, off);
@@ -75,10 +92,14 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(unsigned *__restrict__
         __syncthreads();
         unsigned long long wave_off = 0;
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += ws[w];
-        const unsigned long long excl = carry + wave_off + incl - v;
-        if (i < ntiles) counts[i] = (unsigned)excl; // the emitted-run count of a call is bounded by 2^32-1
+        unsigned long long excl = carry + wave_off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (i0 + k < ntiles) counts[i0 + k] = (unsigned)excl; // the emitted-run count of a call is bounded by 2^32-1
+            excl += v[k];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry = excl + v;
+        if (threadIdx.x == 1023) carry = excl;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
@@ -86,40 +107,49 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(unsigned *__restrict__
 
 // pass 3: position of every change, written at its rank (tile offset + rank inside the tile)
 __global__ __launch_bounds__(256) void rle_positions_kernel(const uint8_t *__restrict__ x, long n, int have_prev, uint8_t prev,
-                                                            const unsigned *__restrict__ tile_offsets, long *__restrict__ pos)
+                                                            const unsigned *__restrict__ tile_offsets, long *__restrict__ pos, uint8_t *__restrict__ vals)
 {
     __shared__ int wsum[4];
     const long base = (long)blockIdx.x * RUN_TILE;
-    // each thread owns 8 CONSECUTIVE elements so that ranks follow stream order
-    const long i0 = base + (long)threadIdx.x * 8;
-    const unsigned mask = change_mask8(x, i0, n, have_prev, prev, ((uintptr_t)x & 7) == 0);
-    const int c = __popc(mask);
-    int incl = c;
+    const bool aligned = ((uintptr_t)x & 7) == 0;
+    long tile_rank = (long)tile_offsets[blockIdx.x]; // rank of the first change of the current round
+    unsigned masks[RUN_ROUNDS];
+    unsigned long long befores[RUN_ROUNDS];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int o = __shfl_up(incl, off);
-        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    for (int r = 0; r < RUN_ROUNDS; ++r) masks[r] = change_mask8(x, base + r * RUN_ROUND + (long)threadIdx.x * 8, n, have_prev, prev, aligned, &befores[r]); // all loads first
+#pragma unroll
+    for (int r = 0; r < RUN_ROUNDS; ++r) {
+        // each thread owns 8 CONSECUTIVE elements of the round so that ranks follow stream order
+        const long i0 = base + r * RUN_ROUND + (long)threadIdx.x * 8;
+        const unsigned mask = masks[r];
+        const int c = __popc(mask);
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(incl, off);
+            if ((int)(threadIdx.x & 63) >= off) incl += o;
+        }
+        if (r) __syncthreads(); // the previous round's wave sums have been read
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        long rk = tile_rank + woff + incl - c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (mask & (1u << k)) { vals[rk] = (uint8_t)(befores[r] >> (8 * k)); pos[rk++] = i0 + k; } // the run's value here: pass 4 gathers nothing
+        tile_rank += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    long r = (long)tile_offsets[blockIdx.x] + woff + incl - c;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (mask & (1u << k)) pos[r++] = i0 + k;
 }
 
-// pass 4: run k = (value before change k, distance to the previous change); the carried run length of
+// pass 4: length of run k = distance of change k to the previous change (its value was written by pass 3); the carried run length of
 // earlier calls joins the first run
-__global__ __launch_bounds__(256) void rle_emit_kernel(const uint8_t *__restrict__ x, const long *__restrict__ pos, long nruns,
-                                                       uint8_t prev, unsigned long long carried, uint8_t *__restrict__ vals,
+__global__ __launch_bounds__(256) void rle_emit_kernel(const long *__restrict__ pos, long nruns, unsigned long long carried,
                                                        unsigned long long *__restrict__ counts)
 {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nruns) return;
     const long p = pos[k];
-    vals[k] = p == 0 ? prev : x[p - 1];
     counts[k] = k == 0 ? (unsigned long long)p + carried : (unsigned long long)(p - pos[k - 1]);
 }
 
@@ -264,9 +294,9 @@ extern "C" int redio_rle_feed(redio_rle *r, const void *d_in, size_t n, void *d_
             RN_TRY(hipMalloc((void **)&r->d_pos, (size_t)total * sizeof(long)));
             r->pos_cap = (size_t)total;
         }
-        hipLaunchKernelGGL(rle_positions_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, x, (long)n, r->have_prev, r->prev, r->d_tiles, r->d_pos);
-        hipLaunchKernelGGL(rle_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, r->d_pos, (long)total, r->prev, r->i,
-                           (uint8_t *)d_vals, (unsigned long long *)d_counts);
+        hipLaunchKernelGGL(rle_positions_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, x, (long)n, r->have_prev, r->prev, r->d_tiles, r->d_pos, (uint8_t *)d_vals);
+        hipLaunchKernelGGL(rle_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r->d_pos, (long)total, r->i,
+                           (unsigned long long *)d_counts);
         RN_TRY(hipMemcpyAsync(&last_change, r->d_pos + (total - 1), sizeof(long), hipMemcpyDeviceToHost, st));
         RN_TRY(hipStreamSynchronize(st));
     }
