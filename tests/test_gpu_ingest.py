@@ -61,6 +61,11 @@ def test_discretize_bit_exact(gpu, redio, oracle):
                 got = redio.bitfount.discretize(d[off:off + n]).cpu().numpy()
                 d[off + peak] = float(base[off + peak])
                 assert np.array_equal(got, oracle.discretize(x).astype(np.uint8)), (off, n, peak)
+    # a long stream with a ragged end: many workgroups of the four-step slicer, the scalar tail, the peak in the last workgroup
+    n = (1 << 22) + 4 * 1024 * 3 + 7
+    xl = redio.synth_f32(77, 0, n).abs()
+    xl[n - 5] = 9.0
+    assert np.array_equal(redio.bitfount.discretize(xl).cpu().numpy(), oracle.discretize(xl.cpu().numpy()).astype(np.uint8))
     # NaN is ignored by f32::max; all-negative input keeps max = 0.0 (the fold's seed)
     x = np.array([np.nan, -1.0, 0.5, 2.0, np.nan, 1.1], np.float32)
     assert redio.bitfount.discretize(gpu.from_numpy(x).cuda()).cpu().numpy().tolist() == oracle.discretize(x).tolist() == [0, 0, 0, 1, 0, 1]

@@ -100,3 +100,16 @@ def test_mul_vecs_sum_vecs_bit_exact(gpu, redio, oracle, n, cplx):
         assert len(got_m) == n and len(got_s) == n
         assert np.array_equal(got_m.view(np.uint32), want_m.view(np.uint32))
         assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_mul_vecs_sum_vecs_operands_beyond_the_caches(gpu, redio, oracle, cplx):
+    # 64 MB per operand and up takes the non-temporal instantiation, one 16-byte group per thread in dispatch order (elementwise.hip)
+    from libredio_amd import kpn_dev
+    n = (1 << 24) + 3 if not cplx else (1 << 23) + 1
+    x = redio.synth_iq(41, 0, n) if cplx else redio.synth_f32(41, 0, n)
+    c = redio.synth_iq(42, 0, n) if cplx else redio.synth_f32(42, 0, n)
+    xn, cn = x.cpu().numpy(), c.cpu().numpy()
+    for dev, add in ((kpn_dev.mul_vecs(x, c), False), (kpn_dev.sum_vecs(x, c), True)):
+        want = oracle.zip_vecs(xn, cn, add=add)
+        assert np.array_equal(dev.cpu().numpy().view(np.uint32), want.view(np.uint32)), (cplx, add)
