@@ -70,3 +70,26 @@ def test_overlap_save_65536_across_the_chunk_loop(gpu, redio, oracle, k):
     s1 = gpu.view_as_real(y).view(gpu.int32).sum(dtype=gpu.int64).item()
     y2 = plan(x)
     assert gpu.equal(y, y2) and s1 == gpu.view_as_real(y2).view(gpu.int32).sum(dtype=gpu.int64).item()
+
+
+@pytest.mark.parametrize("nblk", [1, 2, 127, 128, 129, 255, 256])
+def test_overlap_save_65536_step_launch_edges(gpu, redio, oracle, nblk):
+    """The chunk-step launches of the 65536-point scheme (fft_kernels.hip launch_ovsave64k: middle pass of chunk k, last pass of
+    chunk k - 1 and gather pass of chunk k + 1 in one launch, work buffers doubled) at the block counts where a program drops out of
+    a step: one block, one full 128-block chunk, a one-block second chunk, two full chunks.  First, last and seam blocks against the
+    oracle on their own windows; the rest through a second plan fed the same stream in two calls."""
+    nfft, k = 65536, 8193
+    taps = oracle.lpf_corrected(k, 0.03)
+    hop = nfft - k + 1
+    n = nfft + hop * (nblk - 1)
+    x = redio.synth_iq(0x5EED0035, 0, n)
+    plan = redio.OverlapSave(taps, nfft)
+    y = plan(x)
+    assert y.numel() == nblk * hop
+    for b in sorted({0, nblk // 2, max(nblk - 2, 0), nblk - 1, min(127, nblk - 1), min(128, nblk - 1)}):
+        want = oracle.overlap_save(oracle.synth_iq(0x5EED0035, hop * b, nfft), taps, nfft)
+        assert np.array_equal(bits(y[hop * b: hop * (b + 1)].cpu().numpy()), bits(want)), (nblk, b)
+    if nblk > 2:  # the same blocks as two shorter calls (other chunk boundaries) must give the same bits
+        cut = nblk // 3 + 1
+        y2 = gpu.cat([plan(x[: nfft + hop * (cut - 1)]), plan(x[hop * cut:])])
+        assert gpu.equal(y, y2)
