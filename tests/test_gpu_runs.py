@@ -32,6 +32,23 @@ def test_rle_large_and_multivalue(gpu, redio, oracle):
     assert np.array_equal(c.cpu().numpy(), np.array([w[1] for w in want], np.int64))
 
 
+@pytest.mark.parametrize("n", [16383, 16384, 16385, 3 * 16384 + 5, 20 * 16384])
+def test_rle_changes_at_round_and_tile_seams(gpu, redio, oracle, n):
+    # a workgroup walks a 16384-element tile in eight rounds of 2048 (runs.hip): value changes exactly at, just before and just after
+    # every round and tile seam, long constant stretches over whole rounds, and nothing else
+    x = np.zeros(n, np.uint8)
+    for seam in range(2048, n, 2048):
+        for d in (-1, 0, 1):
+            if 0 < seam + d < n and (seam // 2048 + d) % 3 != 0:
+                x[seam + d:] ^= 1
+    v, c = redio.kpn_dev.Rle().feed(gpu.from_numpy(x).cuda())
+    want = oracle.Rle().feed(x)
+    assert list(zip(v.cpu().tolist(), c.cpu().tolist())) == want
+    # one run spanning everything: no change at all
+    v, c = redio.kpn_dev.Rle().feed(gpu.zeros(n, dtype=gpu.uint8, device="cuda"))
+    assert v.numel() == 0
+
+
 @pytest.mark.parametrize("off", [1, 3, 7])
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 2047, 2048, 2049, 70001])
 def test_rle_views_off_the_8_byte_grid(gpu, redio, oracle, off, n):
