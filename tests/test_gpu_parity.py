@@ -73,6 +73,24 @@ def test_fir_bit_exact(gpu, redio, oracle, k, d, fused, cplx):
         assert same_bits(got, want), (k, d, fused, cplx, n)
 
 
+@pytest.mark.parametrize("d,chunk", [(3, 24), (5, 40), (10, 40), (4, 16), (8, 16), (2, 16)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_fir_chunked_whole_chunk_seams(gpu, redio, oracle, d, chunk, fused):
+    # the chunked kernel walks the taps in whole chunks of one lane stride (24 taps at / 3, 40 at / 5 and / 10) with immediate-offset window
+    # reads, then the remainder's binary digits: tap counts either side of one, two and five whole chunks, a remainder with every digit set,
+    # inputs that end inside a tile, exactly on one, and in the next; an unaligned view (scalar tile loads)
+    for k in (chunk - 1, chunk, chunk + 1, 2 * chunk - 1, 2 * chunk, 2 * chunk + 1, 5 * chunk + chunk - 1):
+        taps = oracle.synth_f32(100 + k, 0, k)
+        tile_out = 256 * (2 if d >= 8 else 4)
+        for n_out in (1, tile_out - 1, tile_out, tile_out + 1, 3 * tile_out + 17):
+            n = (n_out - 1) * d + k
+            x = oracle.synth_iq(7, 0, n + 1)
+            dx = gpu.from_numpy(x).cuda()
+            plan = redio.Fir(taps, d, complex_input=True, fused=fused)
+            assert same_bits(plan(dx[:n]).cpu().numpy(), oracle.fir(x[:n], taps, d, fused)), (k, d, fused, n_out)
+        assert same_bits(plan(dx[1:]).cpu().numpy(), oracle.fir(x[1:], taps, d, fused)), (k, d, fused, "view off the 16-byte grid")
+
+
 def test_fir_short_input_is_empty(gpu, redio, oracle):
     plan = redio.Fir(oracle.lpf_corrected(63, 0.1), 1)
     assert plan.nout(62) == 0 and plan.nout(63) == 1
