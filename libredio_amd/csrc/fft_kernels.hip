@@ -12,7 +12,8 @@
 
 namespace redio {
 
-constexpr int FFT1K_PER_WAVE = 8; // transforms per wavefront: the 27 lane-dependent twiddles are loaded once and reused
+constexpr int FFT1K_PER_WAVE = 8; // blocks per wavefront of the 1024-point overlap-save kernel: its 54 lane-dependent twiddles are loaded once and reused
+constexpr int FFT1K_RUN = 4;      // transforms per wavefront of the plain transform (27 twiddles; round 3: 2 / 4 / 8 / 16 per wave 0.808 / 0.757 / 0.782 / 0.797 ms per 2^28 points)
 template <bool INV>
 __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float2 *out,
                                                          const float2 *__restrict__ tw, long nbatch, long in_stride)
@@ -21,9 +22,9 @@ __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *ex = reinterpret_cast<float2 *>(smem) + wave * FFT1K_LDS;
-    const long b0 = ((long)blockIdx.x * 4 + wave) * FFT1K_PER_WAVE;
+    const long b0 = ((long)blockIdx.x * 4 + wave) * FFT1K_RUN;
     if (b0 >= nbatch) return; // wave-uniform
-    const long b1 = (b0 + FFT1K_PER_WAVE < nbatch) ? b0 + FFT1K_PER_WAVE : nbatch;
+    const long b1 = (b0 + FFT1K_RUN < nbatch) ? b0 + FFT1K_RUN : nbatch;
     Fft1kTw t;
     fft1k_load_tw(t, lane, tw);
     float2 v[16], nx[16];
@@ -2404,7 +2405,7 @@ hipError_t launch_fft(const FftPlanDev &p, const float2 *in, float2 *out, long n
     const bool inv = p.inverse != 0;
     if (p.nfft == 1024) {
         const size_t lds = 4 * FFT1K_LDS * sizeof(float2);
-        const unsigned grid = (unsigned)((nbatch + 4 * FFT1K_PER_WAVE - 1) / (4 * FFT1K_PER_WAVE));
+        const unsigned grid = (unsigned)((nbatch + 4 * FFT1K_RUN - 1) / (4 * FFT1K_RUN));
         if (inv) hipLaunchKernelGGL(fft1k_wave_kernel<true>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         else hipLaunchKernelGGL(fft1k_wave_kernel<false>, dim3(grid), dim3(256), lds, s, in, out, p.tw, nbatch, in_stride);
         return hipGetLastError();
