@@ -172,7 +172,10 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     // re-fetches its 122-sample head: 0.6 % more reads at four blocks per run.
     long waves = 4L * WPS * num_cus();
     if (waves > nblocks) waves = nblocks;
-    long bpw = (nblocks + waves - 1) / waves;
+    // ... and at least about six sets of wavefronts per launch: with fewer the last, partly filled set is most of a run's length of idle
+    // slots (2^26 samples, 127 taps / 5 alone: 0.153-0.159 ms at four blocks per run, 0.131-0.139 at one; 63 taps / 5: 0.137 -> 0.117)
+    long bpw = nblocks / (6 * waves);
+    if (bpw < 1) bpw = 1;
     if (bpw > 4) bpw = 4;
     if (const char *e = getenv("REDIO_CHAIN_BPW")) { const long v = atol(e); if (v >= 1) bpw = v; } // measurement only: blocks per wavefront
     const long grid = (nblocks + bpw - 1) / bpw;
