@@ -10,6 +10,12 @@ per GPU (torch.distributed.run); the stream is time-sliced, every rank owns its 
 (with the 126-sample FIR halo inside the slice), there is no data-path collective, and value is the
 samples of all ranks over the slowest rank's time ("weak" scaling).
 
+Clock pre-conditioning (disclosed in the line as `precondition`; `--no-precondition` turns it off and reproduces the cold figure):
+the chip raises its shader clock over the first ~100 launches of a burst (profiles/r02_clock_probe.txt), and SURVEY.md 8d asks for
+"timed repetitions after warm-up", so before the W warm-up launches every rank repeats the SAME launch on the SAME buffers until
+the per-launch HIP-event time has converged -- the medians of the last three windows of 20 launches within 1 % of each other -- or
+400 launches have run (~0.25 s).  Same kernel, same 2^28 samples, nothing skipped in the timed region; W and K keep their meaning.
+
 Rank 0 prints ONE JSON line.  `value` is exactly what the flags time (W warm-up launches, then K launches between
 two barriers).  `roofline` is for the dominant (only) kernel, chain_v4_kernel: algorithmic bytes = 9.6 B per input
 sample (8 B read + 8/5 B written) over the kernel's mean duration in the timed region, measured with HIP
@@ -52,7 +58,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=23, help="slice per CPU thread")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"), help="file with {'traffic': bytes_per_launch} from the PMC passes")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_traffic.json"), help="file with {'traffic': bytes_per_launch, 'kernel': name} from the PMC passes")
+    ap.add_argument("--no-precondition", action="store_true", help="skip the clock pre-conditioning launches (the cold-burst figure of rounds 1-3)")
+    ap.add_argument("--precondition-max", type=int, default=400, help="cap on the pre-conditioning launches")
     return ap.parse_args()
 
 
@@ -145,6 +153,25 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
+    # who takes part: every rank's device as torch.distributed sees it.  Under the nccl backend two ranks on one device would
+    # produce a "scaling curve" from ranks that shared a GPU: refuse (every rank exits non-zero, nothing is timed).
+    ranks_seen = None
+    if dist is not None:
+        p = torch.cuda.get_device_properties(dev_index)
+        me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": p.name,
+              "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1) & 0xFF, getattr(p, "pci_device_id", 0)),
+              "uuid": str(getattr(p, "uuid", ""))}
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, me)
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": a.backend, "devices": seen,
+                      "distinct_devices": len({(d["pci"], d["uuid"]) for d in seen})}
+        if a.backend == "nccl" and ranks_seen["distinct_devices"] != a.gpus:
+            if rank == 0:
+                print(f"bench.py --gpus {a.gpus}: the {world} ranks see only {ranks_seen['distinct_devices']} distinct devices "
+                      f"({[d['pci'] for d in seen]}); refusing to time ranks that share a GPU", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
+
     lib = R.lib()
     n = 1 << a.log2_samples
     taps = R.dsputils.lpf_corrected(NTAPS, FC)
@@ -165,6 +192,44 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def launches_ms(count):
+        """`count` launches with a HIP event after each, on the launch stream; per-launch ms (synchronises)."""
+        ev = []
+        for _ in range(count + 1):
+            e = C.c_void_p()
+            R.check(lib.redio_event_create(C.byref(e)))
+            ev.append(e)
+        R.check(lib.redio_event_record(ev[0], stream))
+        for k in range(count):
+            chain(x, out)
+            R.check(lib.redio_event_record(ev[k + 1], stream))
+        torch.cuda.synchronize()
+        res = []
+        for k in range(count):
+            ms = C.c_float()
+            R.check(lib.redio_event_elapsed_ms(ev[k], ev[k + 1], C.byref(ms)))
+            res.append(ms.value)
+        for e in ev:
+            lib.redio_event_destroy(e)
+        return res
+
+    # clock pre-conditioning (docstring): the same launch on the same buffers until its time has converged, on every rank
+    precondition = None
+    if not a.no_precondition:
+        WIN, TOL = 20, 0.01
+        series, meds = [], []
+        t_pc = time.perf_counter()
+        while len(series) < a.precondition_max:
+            w = launches_ms(min(WIN, a.precondition_max - len(series)))
+            series += w
+            meds.append(sorted(w)[len(w) // 2])
+            if len(meds) >= 3 and max(meds[-3:]) <= (1.0 + TOL) * min(meds[-3:]):
+                break
+        precondition = {"launches": len(series), "ms": (time.perf_counter() - t_pc) * 1e3,
+                        "criterion": f"medians of the last three windows of {WIN} launches within {TOL * 100:.0f} % of each other, at most {a.precondition_max} launches",
+                        "converged": len(meds) >= 3 and max(meds[-3:]) <= (1.0 + TOL) * min(meds[-3:]),
+                        "first_ms": series[0], "last_ms": series[-1], "window_medians_ms": [round(m, 4) for m in meds]}
 
     for _ in range(a.warmup):
         chain(x, out)
@@ -299,26 +364,23 @@ def main():
                           "transform of its %d decimated blocks); as separate kernels the chain moves 12.8 B per input sample, fused 9.6" % (a.log2_samples, nblk)}
         del y
 
-    ranks_seen = None
-    if dist is not None:
-        p = torch.cuda.get_device_properties(dev_index)
-        me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": p.name,
-              "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1) & 0xFF, getattr(p, "pci_device_id", 0)),
-              "uuid": str(getattr(p, "uuid", ""))}
-        seen = [None] * dist.get_world_size()
-        dist.all_gather_object(seen, me)
-        ranks_seen = {"world_size": dist.get_world_size(), "backend": a.backend, "devices": seen,
-                      "distinct_devices": len({(d["pci"], d["uuid"]) for d in seen})}
-
     if rank == 0:
         kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
         ach = alg_bytes / kavg / 1e9
         traffic, traffic_source = None, None
+        kernel_name = chain.kernel_name  # redio_chain_kernel_name: what this plan launches (None: two kernels)
         if a.traffic_json and os.path.exists(a.traffic_json) and not a.unfused and a.log2_samples == 28:
-            traffic = json.load(open(a.traffic_json)).get("traffic")
-            traffic_source = (os.path.relpath(a.traffic_json, ROOT) + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of a "
-                              "separate run of this command (FETCH_SIZE doubled, the gfx950 correction); not measured by this run")
+            tj = json.load(open(a.traffic_json))
+            if (tj.get("kernel") or "").replace(" ", "") != (kernel_name or ""):
+                # counters recorded for another kernel (a stale file after a kernel change) are not this launch's traffic
+                traffic_source = (f"{os.path.relpath(a.traffic_json, ROOT)} REFUSED: recorded for kernel {tj.get('kernel')!r}, "
+                                  f"this plan launches {kernel_name!r}")
+            else:
+                traffic = tj.get("traffic")
+                traffic_source = (os.path.relpath(a.traffic_json, ROOT) + f": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of a "
+                                  f"separate run of this command (FETCH_SIZE doubled, the gfx950 correction), recorded for {tj.get('kernel')} = the kernel "
+                                  f"this plan launches (redio_chain_kernel_name); not measured by this run")
         rec = {
             "metric": "MSamples/s through FIR+FFT+resample chain",
             "value": world * used * a.steps / dt / 1e6,
@@ -331,7 +393,7 @@ def main():
                                    "(input samples/s; the 5:1 resample step is the polyphase decimation of the FIR: only every "
                                    "fifth FIR output is computed, then consecutive 1024-sample blocks are transformed)",
                        "samples_per_gpu": n, "ntaps": NTAPS, "decim": DECIM, "nfft": NFFT,
-                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else "chain_v4_kernel (fused, wave per block run, halo carried in LDS)",
+                       "kernel": "two kernels (fir_tiled + fft1k_wave)" if a.unfused else f"{kernel_name} (fused, wave per block run, halo carried in LDS)",
                        "fir_rounding": "mul+add (reference)" if a.exact else "fmaf, reference order",
                        "parallelism": f"time-sliced replicas x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -344,6 +406,8 @@ def main():
                                   "peak_tflops": 157.3, "frac_of_157": (4.0 * NTAPS / DECIM + 10.0) * used / kavg / 1e12 / 157.3},
                          "binding": "hbm" if ach / HBM_PEAK_GBS >= (4.0 * NTAPS / DECIM + 10.0) * used / kavg / 1e12 / 157.3 else "valu"},
             "launch_ms_series": [round(v, 4) for v in (kms if len(kms) <= 128 else kms[:32] + kms[32::max(1, len(kms) // 96)])],
+            "launch_ms_max_over_min": max(kms) / min(kms),
+            "precondition": precondition,
         }
         if steady is not None:
             sk = steady["kernel_ms_mean"] * 1e-3

@@ -142,10 +142,20 @@ int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in, void *d_o
 int redio_chain_enqueue_u8(redio_chain *h, const void *d_bytes, size_t nbytes, void *d_out, void *stream);
 /* sizes that buffer (and the two-kernel path's intermediate) for messages of up to nbytes bytes, so that enqueue_u8 never allocates */
 int redio_chain_reserve_u8(redio_chain *h, size_t nbytes);
-/* diagnostic, per plan: while d_buf (4 x u64 per wave of the launch, device memory) is set, the fused kernel of THIS
- * plan writes {shader cycles, 100 MHz ticks, start tick, XCC/HW id} per wave into it (tools/clock_probe.py reads the
- * clock the chip holds from it).  NULL (default) turns it off.  Timings of stamped launches are never quoted. */
-int redio_chain_set_debug_stamps(redio_chain *h, void *d_buf);
+/* launch geometry of the fused kernel for a call that yields nblocks blocks (0 for a plan that runs as two kernels): a wavefront
+ * owns redio_chain_blocks_per_wave() consecutive blocks (the last one of the launch possibly fewer), the launch has
+ * redio_chain_launch_waves() = ceil(nblocks / blocks_per_wave) wavefronts.  Tests pick run boundaries from it, the probes size
+ * their stamp buffers from it. */
+size_t redio_chain_blocks_per_wave(const redio_chain *h, size_t nblocks);
+size_t redio_chain_launch_waves(const redio_chain *h, size_t nblocks);
+/* the fused kernel's name as rocprofv3 reports it, spaces removed (e.g. "chain_v4_kernel<127,5,true,2,8,false,true,false>"); NULL for a
+ * two-kernel plan.  bench.py refuses a counter file (profiles/rNN_traffic.json) recorded for another kernel.  Owned by the plan. */
+const char *redio_chain_kernel_name(redio_chain *h);
+/* diagnostic, per plan: while d_buf (device memory, capacity_waves records of 4 x u64) is set, wavefront w < capacity_waves of the
+ * fused kernel of THIS plan writes {shader cycles, 100 MHz ticks, start tick, XCC/HW id} into record w (tools/clock_probe.py reads
+ * the clock the chip holds from it); size it with redio_chain_launch_waves().  NULL (default) turns it off.  Timings of stamped
+ * launches are never quoted. */
+int redio_chain_set_debug_stamps(redio_chain *h, void *d_buf, size_t capacity_waves);
 
 /* ---- A9: the bit-exact ingest / slicing path of the shipped graph (src/ratpak.rs:60-76) ----
  * All device-resident; results are bit-identical to the reference arithmetic (oracle_bits.c). */

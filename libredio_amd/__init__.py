@@ -93,7 +93,10 @@ def lib():
     _sig(L.redio_chain_is_fused, i, vp)
     _sig(L.redio_chain_set_unfused, i, vp, i)
     _sig(L.redio_chain_reserve, i, vp, sz)
-    _sig(L.redio_chain_set_debug_stamps, i, vp, vp)
+    _sig(L.redio_chain_set_debug_stamps, i, vp, vp, sz)
+    _sig(L.redio_chain_blocks_per_wave, sz, vp, sz)
+    _sig(L.redio_chain_launch_waves, sz, vp, sz)
+    _sig(L.redio_chain_kernel_name, C.c_char_p, vp)
     _sig(L.redio_fft_reserve, i, vp, sz)
     _sig(L.redio_pfb_reserve, i, vp, sz, i)
     for n in ("fir", "chain", "pfb", "ovsave"):

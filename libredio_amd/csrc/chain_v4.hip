@@ -34,7 +34,7 @@ __device__ __forceinline__ void static_for4(F &&f)
 template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false>
 __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
                                                            const float2 *__restrict__ tw, float2 *__restrict__ out,
-                                                           long nblocks, long blocks_per_wave, unsigned long long *dbg)
+                                                           long nblocks, long blocks_per_wave, unsigned long long *dbg, long dbg_cap)
 {
     // diagnostic only (dbg != nullptr): shader-clock and 100 MHz real-time stamps around the wave's life,
     // written to a buffer of their own; run times of such launches are never quoted
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
         }
         wave_lds_fence();
     }
-    if (dbg && lane == 0) {
+    if (dbg && lane == 0 && (long)blockIdx.x < dbg_cap) { // the caller's buffer holds dbg_cap records: later waves leave no stamp
         dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
         dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
         dbg[4 * blockIdx.x + 2] = t0r; // absolute start (100 MHz ticks)
@@ -152,10 +152,31 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     }
 }
 
+// blocks per wavefront of a launch over nblocks blocks (every instantiation: WPS = 2)
+long chain_v4_blocks_per_wave(long nblocks)
+{
+    constexpr int WPS = 2;
+    // Short runs in dispatch order, not one long run per residency slot: the wavefronts resident at any moment then read one
+    // compact window of the stream (2048 x 4 blocks = 335 MB apart at most, instead of 2048 places spread over all of it).
+    // Measured with non-temporal accesses 0.533 -> 0.517 ms per 2^28 samples (profiles/r03_chain_variants.txt); a run
+    // re-fetches its 122-sample head: 0.6 % more reads at four blocks per run.
+    long waves = 4L * WPS * num_cus();
+    if (waves > nblocks) waves = nblocks;
+    if (waves < 1) waves = 1;
+    // ... and at least about six sets of wavefronts per launch: with fewer the last, partly filled set is most of a run's length of idle
+    // slots (2^26 samples, 127 taps / 5 alone: 0.153-0.159 ms at four blocks per run, 0.131-0.139 at one; 63 taps / 5: 0.137 -> 0.117)
+    long bpw = nblocks / (6 * waves);
+    if (bpw < 1) bpw = 1;
+    if (bpw > 4) bpw = 4;
+    if (const char *e = measure_env("REDIO_CHAIN_BPW")) { const long v = atol(e); if (v >= 1) bpw = v; } // -DREDIO_MEASURE builds only: blocks per wavefront
+    return bpw;
+}
+
 template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false>
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
-                              hipStream_t s, unsigned long long *dbg)
+                              hipStream_t s, unsigned long long *dbg, long dbg_cap = 0)
 {
+    static_assert(WPS == 2, "chain_v4_blocks_per_wave assumes two wavefronts per SIMD");
     using G = FirGeomV<K, D, 4>;
     constexpr int ELEMS = G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS;
     constexpr size_t LDS_NEED = (size_t)ELEMS * sizeof(float2);
@@ -166,30 +187,19 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     // half empty, and the launch ends when the most crowded CU does (measured: wave lifetimes 320-570 us).
     constexpr size_t LDS = (160 * 1024 / (4 * WPS)) - 480 > LDS_NEED ? (160 * 1024 / (4 * WPS)) - 480 : LDS_NEED;
     static_assert((4 * WPS + 1) * LDS > 160 * 1024, "one more wave must not fit");
-    // Short runs in dispatch order, not one long run per residency slot: the wavefronts resident at any moment then read one
-    // compact window of the stream (2048 x 4 blocks = 335 MB apart at most, instead of 2048 places spread over all of it).
-    // Measured with non-temporal accesses 0.533 -> 0.517 ms per 2^28 samples (profiles/r03_chain_variants.txt); a run
-    // re-fetches its 122-sample head: 0.6 % more reads at four blocks per run.
-    long waves = 4L * WPS * num_cus();
-    if (waves > nblocks) waves = nblocks;
-    // ... and at least about six sets of wavefronts per launch: with fewer the last, partly filled set is most of a run's length of idle
-    // slots (2^26 samples, 127 taps / 5 alone: 0.153-0.159 ms at four blocks per run, 0.131-0.139 at one; 63 taps / 5: 0.137 -> 0.117)
-    long bpw = nblocks / (6 * waves);
-    if (bpw < 1) bpw = 1;
-    if (bpw > 4) bpw = 4;
-    if (const char *e = getenv("REDIO_CHAIN_BPW")) { const long v = atol(e); if (v >= 1) bpw = v; } // measurement only: blocks per wavefront
+    const long bpw = chain_v4_blocks_per_wave(nblocks);
     const long grid = (nblocks + bpw - 1) / bpw;
-    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
-    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg);
+    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
+    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
     return hipGetLastError();
 }
 
 hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
-                           hipStream_t s, unsigned long long *dbg)
+                           hipStream_t s, unsigned long long *dbg, long dbg_cap)
 {
     // (three wavefronts per SIMD were measured again in round 3 with the new access policy: the transform's registers spill at
     // 168 per lane, 0.56-0.60 against 0.517 ms)
-    return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg); // last-stage twiddles resident
+    return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg, dbg_cap); // last-stage twiddles resident
 }
 
 // u8 I/Q bytes in (4-byte aligned), spectra out: data_to_samples -> 127-tap FIR / 5 -> 1024-point FFT in one kernel

@@ -84,7 +84,8 @@ static int zip_common(const void *a, const void *b, void *o, size_t n, size_t el
 }
 
 // One 16-byte group per thread, workgroups in dispatch order: 0.534 ms per 2^28 floats against 0.679 with the grid capped at 8192
-// workgroups and a grid-stride loop (round 3; the loop stays for inputs above 2^39 elements).
+// workgroups and a grid-stride loop (round 3).  HIP rejects a launch of 2^32 threads or more, so the grid stops at 2^24 - 1
+// workgroups of 256 and the kernels' grid-stride loop covers what is beyond (operands above 64 GiB).
 constexpr size_t ZIP_NT_BYTES = 64u << 20; // per operand: twice the eight L2s
 #define ZIP_ENTRY(name, T, kernel, OP)                                                                                         \
     extern "C" int name(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)                                 \
@@ -92,7 +93,7 @@ constexpr size_t ZIP_NT_BYTES = 64u << 20; // per operand: twice the eight L2s
         hipStream_t st = (hipStream_t)stream;                                                                                  \
         return zip_common(d_a, d_b, d_out, n, sizeof(T), [&](long nvec, size_t tail_at, long tail) {                            \
             long work = nvec > tail ? nvec : tail;                                                                             \
-            unsigned grid = (unsigned)((work + 255) / 256 > 0x7fffffffL ? 0x7fffffffL : (work + 255) / 256);                   \
+            unsigned grid = (unsigned)((work + 255) / 256 > 0xffffffL ? 0xffffffL : (work + 255) / 256);                       \
             if (grid < 1) grid = 1;                                                                                            \
             auto kern = n * sizeof(T) >= ZIP_NT_BYTES ? kernel<OP, true> : kernel<OP, false>;                                  \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, (const float4 *)d_a, (const float4 *)d_b,                   \

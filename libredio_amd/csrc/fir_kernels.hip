@@ -343,7 +343,7 @@ hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D
 {
     // the shapes the chain kernel is built for (127 / 63 taps / 5, 63 taps / 1) run on its data path (wave-private images,
     // halo carried in LDS, register prefetch): whole 1024-output blocks there, the remainder on the tiled kernel
-    if (cplx && n_out >= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && !getenv("REDIO_FIR_NO_V4")) {
+    if (cplx && n_out >= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && !measure_env("REDIO_FIR_NO_V4")) {
         const long nblocks = n_out / 1024;
         hipError_t e = launch_fir_v4(K, (int)(D <= 5 ? D : 0), (const float2 *)x, taps, (float2 *)y, nblocks, fused, s);
         if (e == hipSuccess) {

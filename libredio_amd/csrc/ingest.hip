@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void gather_blocks_kernel(const float *__restr
 }
 
 // `per` items per workgroup, at most `cap` workgroups (the kernels walk the rest with a grid stride)
+// (a launch of 2^32 threads or more is rejected: callers that want dispatch-order grids pass cap = 2^24 - 1 workgroups of 256 and
+// rely on their kernel's grid-stride loop beyond it)
 static unsigned grid_for(long n, int per = 256, long cap = 16384)
 {
     long g = (n + per - 1) / per;
@@ -251,7 +253,7 @@ extern "C" int redio_data_to_samples(const void *d_bytes, size_t nbytes, void *d
     const long ns = (long)(nbytes / 2);
     // four 4-byte loads (16-byte stores) per thread, workgroups in dispatch order: swept over 1 ... 128 per thread at 2^28 samples (round 3), 0.466 ms
     // against 0.557 with the grid capped at 16384 workgroups and 0.607 with one load per thread
-    hipLaunchKernelGGL(data_to_samples_kernel, dim3(grid_for(ns / 2, 1024, 0x7fffffffL)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float2 *)d_out, ns);
+    hipLaunchKernelGGL(data_to_samples_kernel, dim3(grid_for(ns / 2, 1024, 0xffffffL)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bytes, (float2 *)d_out, ns);
     return hip_rc(hipGetLastError());
 }
 
@@ -305,7 +307,7 @@ extern "C" int redio_discretize(const void *d_in, size_t n, void *d_out_u8, void
     hipStream_t st = (hipStream_t)stream;
     IN_TRY(hipMemsetAsync(d_scratch_u32, 0, sizeof(unsigned), st)); // fold starts at 0.0
     hipLaunchKernelGGL(max_kernel, dim3(grid_for((long)n, 1024) > 2048 ? 2048 : grid_for((long)n, 1024)), dim3(256), 0, st, (const float *)d_in, (long)n, (unsigned *)d_scratch_u32);
-    hipLaunchKernelGGL(slice_kernel, dim3(grid_for((long)n / 4, 1024, 0x7fffffffL)), dim3(256), 0, st, (const float *)d_in, (long)n, (const unsigned *)d_scratch_u32,
+    hipLaunchKernelGGL(slice_kernel, dim3(grid_for((long)n / 4, 1024, 0xffffffL)), dim3(256), 0, st, (const float *)d_in, (long)n, (const unsigned *)d_scratch_u32,
                        (uint8_t *)d_out_u8);
     return hip_rc(hipGetLastError());
 }

@@ -71,7 +71,7 @@ extern "C" int redio_ovsave_create(redio_ovsave **h, const float *taps, size_t n
     // 64 MiB per buffer: swept 16 ... 128 MiB at 65536 points in round 2 (profiles/r02_c5_team_experiment.txt): 64 is best, 128 -- past the
     // Infinity Cache -- costs 6 %
     size_t chunk_mib = 64; // at 65536 points: one resident set of waves per pass, three per step launch (round 3: 21 / 56 / 64 MiB 2.76-2.80 ms, 42 / 80 / 96 MiB 2.97-3.05)
-    if (const char *e = getenv("REDIO_OVS_CHUNK_MIB")) { const long v = atol(e); if (v >= 1) chunk_mib = (size_t)v; } // measurement only
+    if (const char *e = measure_env("REDIO_OVS_CHUNK_MIB")) { const long v = atol(e); if (v >= 1) chunk_mib = (size_t)v; } // measurement only
     p->chunk_blocks = (chunk_mib << 20) / ((size_t)nfft * sizeof(float2));
     if (p->chunk_blocks < 1) p->chunk_blocks = 1;
     int rc = redio_fft_create(&p->fw, nfft, 0);

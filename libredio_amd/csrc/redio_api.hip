@@ -479,6 +479,8 @@ struct redio_chain {
     float2 *d_mid; // intermediate for the two-kernel path (redio_chain_reserve)
     size_t mid_elems;
     unsigned long long *d_stamps; // diagnostic per-wave stamps of THIS plan's launches (redio_chain_set_debug_stamps), else null
+    size_t stamp_waves;           // records (4 x u64) that buffer holds: wavefronts beyond it leave no stamp
+    char kernel_name[96];         // redio_chain_kernel_name
     float2 *d_conv; // converted samples for redio_chain_enqueue_u8 on shapes / pointers without the one-kernel form (grown on first use)
     size_t conv_elems;
 };
@@ -520,11 +522,31 @@ extern "C" int redio_chain_set_unfused(redio_chain *h, int unfused)
     h->force_unfused = unfused ? 1 : 0;
     return REDIO_OK;
 }
-extern "C" int redio_chain_set_debug_stamps(redio_chain *h, void *d_buf)
+extern "C" int redio_chain_set_debug_stamps(redio_chain *h, void *d_buf, size_t capacity_waves)
 {
-    if (!h) return REDIO_ERR_ARG;
+    if (!h || (d_buf && capacity_waves == 0)) return REDIO_ERR_ARG;
     h->d_stamps = (unsigned long long *)d_buf;
+    h->stamp_waves = d_buf ? capacity_waves : 0;
     return REDIO_OK;
+}
+// launch geometry of the fused kernel for a call that yields nblocks blocks: consecutive blocks per wavefront, and the number of
+// wavefronts (= workgroups) of the launch; 0 when the plan runs as two kernels
+extern "C" size_t redio_chain_blocks_per_wave(const redio_chain *h, size_t nblocks)
+{
+    if (!redio_chain_is_fused(h) || nblocks == 0) return 0;
+    if (hipSetDevice(h->fir->device) != hipSuccess) return 0; // the rule depends on the device's CU count
+    return (size_t)chain_v4_blocks_per_wave((long)nblocks);
+}
+extern "C" size_t redio_chain_launch_waves(const redio_chain *h, size_t nblocks)
+{
+    const size_t bpw = redio_chain_blocks_per_wave(h, nblocks);
+    return bpw ? (nblocks + bpw - 1) / bpw : 0;
+}
+// name of the fused kernel this plan launches for cf32 input, as rocprofv3 reports it with the spaces removed; NULL for a two-kernel plan
+extern "C" const char *redio_chain_kernel_name(redio_chain *h)
+{
+    if (!redio_chain_is_fused(h)) return nullptr;
+    return chain_kernel_name((int)h->fir->ntaps, (long)h->fir->decim, (h->fir->flags & REDIO_FIR_FUSED) != 0, h->kernel_name, sizeof(h->kernel_name));
 }
 // sizes the two-kernel path's intermediate for inputs of up to n_in samples (allocation; may free a smaller one)
 extern "C" int redio_chain_reserve(redio_chain *h, size_t n_in)
@@ -554,7 +576,7 @@ extern "C" int redio_chain_enqueue(redio_chain *h, const void *d_in, size_t n_in
     const bool fused_math = (h->fir->flags & REDIO_FIR_FUSED) != 0;
     if (redio_chain_is_fused(h)) {
         hipError_t e = launch_chain(h->fft->dev, (const float2 *)d_in, (long)n_in, h->fir->d_taps, (int)h->fir->ntaps,
-                                    (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, (hipStream_t)stream, h->d_stamps);
+                                    (long)h->fir->decim, (float2 *)d_out, (long)nblk, fused_math, (hipStream_t)stream, h->d_stamps, (long)h->stamp_waves);
         if (e != hipErrorNotSupported) return hip_rc(e);
         // e.g. an input pointer the fused kernel cannot take: same results through the two kernels below
     }

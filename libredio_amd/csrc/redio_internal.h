@@ -3,9 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "fft_core.h"
 
 namespace redio {
+
+// Launch-geometry knobs for measurement (tools/ablate.sh, tools/chain_variants.py ...): read from the environment ONLY in a
+// -DREDIO_MEASURE build (make EXTRA=-DREDIO_MEASURE OUT=../_build_measure).  The shipped library reads no environment variable.
+#ifdef REDIO_MEASURE
+inline const char *measure_env(const char *name) { return getenv(name); }
+#else
+inline const char *measure_env(const char *) { return nullptr; }
+#endif
 
 // fir_kernels.hip
 hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D, void *y, long n_out,
@@ -55,7 +64,10 @@ bool chain_supported(int K, long D, int nfft);
 hipError_t launch_chain_u8(const FftPlanDev &p, const void *bytes, const float *taps, int K, long D, float2 *out, long nblocks, bool fused,
                            hipStream_t s);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
-                        float2 *out, long nblocks, bool fused, hipStream_t s, unsigned long long *dbg = nullptr);
+                        float2 *out, long nblocks, bool fused, hipStream_t s, unsigned long long *dbg = nullptr, long dbg_cap = 0);
+long chain_v4_blocks_per_wave(long nblocks); // chain_v4.hip: consecutive blocks one wavefront of the fused kernel owns
+// the fused kernel's name as rocprofv3 prints it (spaces removed), so that a counter file can be tied to the kernel a plan launches
+const char *chain_kernel_name(int K, long D, bool fused_math, char *buf, size_t cap);
 
 // misc_kernels.hip
 hipError_t launch_synth_iq(float2 *out, uint32_t seed, uint64_t first, long n, hipStream_t s);

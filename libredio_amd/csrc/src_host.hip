@@ -350,7 +350,7 @@ static int prepare_uniform(redio_src *f, int inc)
     f->d_cr = f->d_tabs + 2 * guard + L.size();
     // at zero phase the right wing starts one increment in and R[t] == L[t] bit for bit over its whole length: both wings
     // then walk ONE table (half the scalar-cache footprint, and the wavefronts of a workgroup share every line they load)
-    if (R.size() + 1 == L.size() && memcmp(R.data(), L.data(), R.size() * sizeof(double)) == 0 && !getenv("REDIO_SRC_TWO_TABLES")) f->d_cr = f->d_cl;
+    if (R.size() + 1 == L.size() && memcmp(R.data(), L.data(), R.size() * sizeof(double)) == 0 && !measure_env("REDIO_SRC_TWO_TABLES")) f->d_cr = f->d_cl;
     f->ncl = cl + 1; f->ncr = cr + 1; f->fast_inc = inc;
     hipFree(f->d_T2); f->d_T2 = nullptr; f->nm = 0; // rebuilt on demand for the new increment
     hipFree(f->d_Hp); f->d_Hp = nullptr; f->fastp_nc = 0;
@@ -723,8 +723,11 @@ static bool window_prefers_periodic(const redio_src *f, long n, int inc, long ep
         bool ok = true;
         for (long k = 0; ok && k + P < n; ++k) ok = start[k + P] == start[k] && pos[k + P] - pos[k] == Q;
         if (!ok) continue;
-        const int wing = (int)((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 1; // taps of one wing, at most
-        return periodic_epoch_eligible(P, Q, wing, wing, pos[P - 1] - pos[0], epoch_outputs);
+        // try_periodic_epoch applies the rule to the epoch's real wing lengths (at most wing + 1 taps) and its real output count
+        // (epoch_outputs is an estimate): answer "periodic" only with a margin on both, so that a ratio near the table-size or
+        // 8 x count boundary keeps the single-launch window instead of having every epoch declined afterwards
+        const int wing = (int)((long)(f->coeff_half_len << SRC_SHIFT) / inc) + 3;
+        return periodic_epoch_eligible(P, Q, wing, wing, pos[P - 1] - pos[0], epoch_outputs - epoch_outputs / 8);
     }
     return false;
 }

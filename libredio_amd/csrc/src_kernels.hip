@@ -658,7 +658,7 @@ __global__ __launch_bounds__(2 * LW) void src_window_rb_kernel(SrcWindow w, cons
 // which register blocking serves (S, taps): 0 = none (the one-output-per-lane kernel runs)
 int src_rb_choose(int S, int ncl, int ncr)
 {
-    const int forced = getenv("REDIO_SRC_RB") ? atoi(getenv("REDIO_SRC_RB")) : -1; // measurement only: 0 = off, 2 / 4 = that blocking
+    const int forced = measure_env("REDIO_SRC_RB") ? atoi(measure_env("REDIO_SRC_RB")) : -1; // measurement only: 0 = off, 2 / 4 = that blocking
     if (forced == 0) return 0;
     const int nmin = ncl < ncr ? ncl : ncr;
     const int cand[2] = {forced == 4 ? 4 : 2, forced == 2 ? 2 : 4};
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(64 * SrcFastP<NPAIR>::W) void src_window_fastp_kern
 #define REDIO_FASTP_SHAPES(X) X(16) X(20) X(24) X(32) X(40) X(46) X(48)
 int src_fastp_pairs(int S, int KH)
 {
-    if (getenv("REDIO_SRC_FASTP") && !atoi(getenv("REDIO_SRC_FASTP"))) return 0; // measurement only
+    if (measure_env("REDIO_SRC_FASTP") && !atoi(measure_env("REDIO_SRC_FASTP"))) return 0; // measurement only
     const int npair = ((KH + S - 1) / S + 1) / 2;
 #define X(N) if (npair <= N) return SrcFastP<N>::fits(S) ? N : 0;
     REDIO_FASTP_SHAPES(X)
@@ -1034,7 +1034,7 @@ hipError_t launch_src_window(const float *old_img, long old_stride, const float 
             if (padded) LAUNCH_F(true) else LAUNCH_F(false)
 #undef LAUNCH_F
         } else if (const int RB = src_rb_choose(S, ncl, ncr)) {
-            const bool wide = RB == 2 && getenv("REDIO_SRC_RB_WIDE") && atoi(getenv("REDIO_SRC_RB_WIDE")) &&
+            const bool wide = RB == 2 && measure_env("REDIO_SRC_RB_WIDE") && atoi(measure_env("REDIO_SRC_RB_WIDE")) &&
                               (size_t)src_rb_tile_floats(640, 2, S, cl, cr) * sizeof(float) + 640 * sizeof(double) <= 160 * 1024; // measurement only
             const int NOt = wide ? 640 : 256;
             const size_t b = (size_t)src_rb_tile_floats(NOt, RB, S, cl, cr) * sizeof(float) + NOt * sizeof(double);

@@ -120,9 +120,27 @@ class Chain:
         """Size the two-kernel path's intermediate up front (enqueue then never allocates)."""
         check(lib().redio_chain_reserve(self._h, int(n_in)), "chain_reserve")
 
+    def blocks_per_wave(self, nblocks):
+        """redio_chain_blocks_per_wave: consecutive blocks one wavefront of the fused launch over `nblocks` blocks owns (0: two kernels)."""
+        return lib().redio_chain_blocks_per_wave(self._h, int(nblocks))
+
+    def launch_waves(self, nblocks):
+        """redio_chain_launch_waves: wavefronts of the fused launch over `nblocks` blocks (0: two kernels)."""
+        return lib().redio_chain_launch_waves(self._h, int(nblocks))
+
+    @property
+    def kernel_name(self):
+        """redio_chain_kernel_name: the fused kernel as rocprofv3 names it, spaces removed (None for a two-kernel plan)."""
+        n = lib().redio_chain_kernel_name(self._h)
+        return n.decode() if n else None
+
     def set_debug_stamps(self, buf):
-        """Diagnostic per-wave stamps of this plan's fused launches into `buf` (int64 CUDA tensor, 4 per wave); None = off."""
-        check(lib().redio_chain_set_debug_stamps(self._h, None if buf is None else C.c_void_p(buf.data_ptr())), "chain_set_debug_stamps")
+        """Diagnostic per-wave stamps of this plan's fused launches into `buf` (int64 CUDA tensor, 4 per wave: size it with
+        4 * launch_waves(nblocks); wavefronts beyond its capacity leave no stamp); None = off."""
+        if buf is None:
+            check(lib().redio_chain_set_debug_stamps(self._h, None, 0), "chain_set_debug_stamps")
+        else:
+            check(lib().redio_chain_set_debug_stamps(self._h, C.c_void_p(buf.data_ptr()), buf.numel() // 4), "chain_set_debug_stamps")
 
     def __call__(self, x, out=None):
         import torch

@@ -7,9 +7,9 @@
 #     which includes a block that throws mid-stream -- the reference's panic cascade, kpn.rs:17-29 -- and the bounded channels)
 # then the CPU test suite (pytest -m "not gpu") with the sanitized oracle and lane programs loaded (libasan preloaded into python;
 # leak checking off: the interpreter never frees its own arenas).  usage: bash tests/san_check.sh [logfile]
-set -e
+set -e -o pipefail   # a sanitizer abort or a failing test ends the script non-zero (tail / tee no longer hide the status)
 R=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$R/profiles/r03_sanitizers.txt}
+LOG=${1:-$R/profiles/r04_sanitizers.txt}
 cd $R
 make -C oracle -s SAN=1
 make -C tests/emu -s SAN=1

@@ -325,6 +325,30 @@ def test_chain_bit_exact(gpu, redio, oracle, fused, nblocks):
     assert int((stamps != 0).sum()) == 0
 
 
+def test_chain_stamp_buffer_capacity_is_honoured(gpu, redio, oracle):
+    """redio_chain_set_debug_stamps(buf, capacity): a launch with more wavefronts than the buffer has records (the launcher gives a
+    wavefront at most 4 blocks, so 2^28 samples are 13107 wavefronts) stamps only the first `capacity` and writes nothing beyond."""
+    taps = oracle.lpf_corrected(127, 0.08)
+    nblocks = 5000
+    n = nblocks * 5120 + 126
+    x = redio.synth_iq(0x5EED0002, 0, n)
+    chain = redio.Chain(taps, 5, 1024, fused=True)
+    waves, bpw = chain.launch_waves(nblocks), chain.blocks_per_wave(nblocks)
+    assert waves == -(-nblocks // bpw) and waves > 1024
+    cap = 1024
+    guard = gpu.full((4 * cap + 4096,), -7, dtype=gpu.int64, device="cuda")
+    chain.set_debug_stamps(guard[: 4 * cap])
+    out = chain(x)
+    chain.set_debug_stamps(None)
+    g = guard.cpu().numpy()
+    assert (g[4 * cap:] == -7).all(), "a wavefront beyond the buffer's capacity wrote a stamp"
+    assert (g[: 4 * cap].reshape(cap, 4)[:, 1] > 0).all(), "every wavefront below the capacity leaves its record"
+    assert same_bits(out.cpu().numpy()[-2:], oracle.chain_fir_fft(oracle.synth_iq(0x5EED0002, (nblocks - 2) * 5120, 2 * 5120 + 126), taps, 5, 1024, fused=True))
+    assert chain.kernel_name == "chain_v4_kernel<127,5,true,2,8,false,true,false>"
+    two = redio.Chain(taps, 2, 64, fused=False)
+    assert two.kernel_name is None and two.launch_waves(100) == 0 and two.blocks_per_wave(100) == 0
+
+
 def test_chain_fused_rounding_vs_reference_rounding_tolerance(gpu, redio, oracle):
     """The stated f32 tolerance of the fmaf build of the chain against the REFERENCE arithmetic (Rust never
     contracts: separately rounded multiply and add, dsputils.rs:31).  Per FIR output the two folds differ
@@ -386,20 +410,24 @@ def test_chain_full_size_properties(gpu, redio, oracle):
         nb = chain.nblocks(n)
         assert nb == ((n - 127) // 5 + 1) // 1024
         out = chain(x)
-        # a wave owns a run of blocks_per_wave consecutive blocks and carries the FIR halo inside LDS from one
-        # sub-tile to the next (chain_v4.hip): check the first and the last block of EVERY run, whatever the run
-        # length the launcher picked for this device (8 waves per CU), plus every 64th block
-        cus = gpu.cuda.get_device_properties(0).multi_processor_count
-        picks = {0, 1, nb // 2, nb - 1} | set(range(0, nb, 64))
-        for waves in {8 * cus, 12 * cus}:
-            bpw = -(-nb // waves)
-            picks |= set(range(0, nb, bpw)) | {min(b + bpw - 1, nb - 1) for b in range(0, nb, bpw)}
+        # a wave owns a run of blocks_per_wave consecutive blocks and carries the FIR halo inside LDS from one sub-tile to the
+        # next (chain_v4.hip).  The run length comes from the launcher itself (redio_chain_blocks_per_wave), and EVERY block of
+        # the launch -- so the first and the last block of every run, whatever that length is -- is compared with the oracle,
+        # which computes each slice of 4096 blocks from nothing but that slice's own input window (tile independence)
+        bpw, waves = chain.blocks_per_wave(nb), chain.launch_waves(nb)
+        assert 1 <= bpw and waves == -(-nb // bpw) and waves > 4096, (bpw, waves)
         outh = out.cpu().numpy()
-        for b in sorted(picks):
-            lo = b * 5120
-            xw = oracle.synth_iq(0x5EED0002, lo, 5120 + 126)
-            want = oracle.chain_fir_fft(xw, taps, 5, 1024, fused=fused)[0]
-            assert same_bits(outh[b], want), (fused, b)
+        step = 4096
+        assert step % bpw == 0 or bpw > step  # slices start on run boundaries: a run's first block is some slice's block too
+        for b0 in range(0, nb, step):
+            cnt = min(step, nb - b0)
+            xw = oracle.synth_iq(0x5EED0002, b0 * 5120, cnt * 5120 + 126)
+            want = oracle.chain_fir_fft(xw, taps, 5, 1024, fused=fused)
+            assert want.shape == (cnt, 1024)
+            if not same_bits(outh[b0:b0 + cnt], want):
+                bad = [b0 + i for i in range(cnt) if not same_bits(outh[b0 + i], want[i])]
+                raise AssertionError((fused, "blocks that differ", bad[:8], "position in their run", [b % bpw for b in bad[:8]]))
+        del outh
     s1 = gpu.view_as_real(out).view(gpu.int32).sum(dtype=gpu.int64).item()
     out2 = chain(x * 4.0)
     assert gpu.equal(out2, out * 4.0)

@@ -29,6 +29,9 @@ def main():
     import libredio_amd as R
     from libredio_amd import sharding
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if a.backend == "nccl" and int(os.environ.get("LOCAL_RANK", "0")) >= torch.cuda.device_count():
+        sys.exit(f"bench_c4.py rank {rank}: LOCAL_RANK {os.environ.get('LOCAL_RANK')} but only {torch.cuda.device_count()} HIP devices are visible "
+                 f"(ranks never share a GPU under the nccl backend)")
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -36,6 +39,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         dist.init_process_group(a.backend, rank=rank, world_size=world)
+    # who takes part: the world size torch.distributed reports and every rank's device.  Under the nccl backend ranks that share a
+    # device would give a curve that is not a scaling curve: every rank exits non-zero before anything is timed.
+    pr = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "device": local, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+          "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0))}
+    seen = [None] * dist.get_world_size()
+    dist.all_gather_object(seen, me)
+    distinct = len({(d["pci"], d["uuid"]) for d in seen})
+    if a.backend == "nccl" and distinct != world:
+        if rank == 0:
+            print(f"bench_c4.py: {world} ranks on {distinct} distinct devices ({[d['pci'] for d in seen]}); refusing to time ranks that share a GPU", file=sys.stderr)
+        dist.destroy_process_group()
+        sys.exit(3)
     M, P = 64, 16
     h = R.dsputils.lpf_corrected(M * P, 0.45 / M)
     plan = R.Channelizer(h)
@@ -99,13 +115,6 @@ def main():
         if not torch.equal(pipe_buf, mine):
             bad = (torch.view_as_real(pipe_buf) != torch.view_as_real(mine)).any(dim=2).any(dim=1).nonzero().flatten()
             raise AssertionError(f"piece-wise pipeline differs from the one-shot exchange: {bad.numel()} rows, first {bad[:8].tolist()}, last {bad[-4:].tolist()} of {mine.shape[0]}")
-    # who took part: the world size torch.distributed reports and every rank's device (a launch that landed all ranks on one
-    # device, or fewer ranks than asked for, must be impossible to miss)
-    pr = torch.cuda.get_device_properties(local)
-    me = {"rank": rank, "device": local, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
-          "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0))}
-    seen = [None] * dist.get_world_size()
-    dist.all_gather_object(seen, me)
     if rank == 0:
         egress = nrows * (M - cpg) * 8                  # bytes this GPU sends to its peers per step
         print(json.dumps({"workload": "BASELINE.json configs[3]: 64-channel polyphase channelizer, P=16, channels sharded over the GPUs",
@@ -117,7 +126,7 @@ def main():
                           "exchange_egress_GBps_per_gpu": (egress / max(t_both - t_analysis, 1e-9) / 1e9) if world > 1 else None,
                           # xGMI is point to point: a rank's world - 1 transfers of a step each have a link of their own
                           "exchange_egress_GBps_per_link": (egress / (world - 1) / max(t_both - t_analysis, 1e-9) / 1e9) if world > 1 else None,
-                          "ranks_seen": {"world_size": dist.get_world_size(), "devices": seen, "distinct_devices": len({(d["pci"], d["uuid"]) for d in seen})},
+                          "ranks_seen": {"world_size": dist.get_world_size(), "devices": seen, "distinct_devices": distinct},
                           "scaling": "weak",
                           "collective": "redio_pfb_exchange: RCCL ncclSend/ncclRecv group (C ABI)" if use_cabi else "all_to_all_single (%s)" % a.backend}))
     dist.destroy_process_group()

@@ -3,6 +3,8 @@ src_window_rb_kernel (REDIO_SRC_RB = 0: one output per lane, 2 / 4: that many ou
 ONE process, outputs compared bit for bit.  usage: python tools/c3_variants.py [frames_log2]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the knobs below exist only in the measurement build (make -C libredio_amd/csrc measure -> libredio_amd/_build_measure)
+os.environ.setdefault("REDIO_BUILD_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libredio_amd", "_build_measure"))
 import torch, libredio_amd as R
 
 nch, frames = 256, 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)

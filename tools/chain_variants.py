@@ -3,6 +3,8 @@ set of addresses in flight is) swept, 300 launches after 300 warm-up launches ea
 directory (REDIO_BUILD_DIR) to compare load / store cache policies.  usage: python tools/chain_variants.py [bpw ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the knobs below exist only in the measurement build (make -C libredio_amd/csrc measure -> libredio_amd/_build_measure)
+os.environ.setdefault("REDIO_BUILD_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libredio_amd", "_build_measure"))
 import torch, libredio_amd as R
 
 n = 1 << 28

@@ -7,7 +7,7 @@ lib = R.lib()
 n = 1 << 28
 chain = R.Chain(R.dsputils.lpf_corrected(127, 0.08), 5, 1024, fused=True)
 x = R.synth_iq(0x5EED0002, 0, n); out = torch.empty((chain.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
-dbg = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4 * chain.launch_waves(chain.nblocks(n)), dtype=torch.int64, device="cuda")  # one record per wavefront of the launch
 for burst in (5, 50, 500):
     for _ in range(burst): chain(x, out)        # load the chip
     chain.set_debug_stamps(dbg)

@@ -6,7 +6,7 @@ lib = R.lib()
 n = 1 << 28
 chain = R.Chain(R.dsputils.lpf_corrected(127, 0.08), 5, 1024, fused=True)
 x = R.synth_iq(0x5EED0002, 0, n); out = torch.empty((chain.nblocks(n), 1024), dtype=torch.complex64, device="cuda")
-dbg = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4 * chain.launch_waves(chain.nblocks(n)), dtype=torch.int64, device="cuda")  # one record per wavefront of the launch
 for _ in range(300): chain(x, out)
 chain.set_debug_stamps(dbg); chain(x, out); torch.cuda.synchronize(); chain.set_debug_stamps(None)
 d = dbg.cpu().numpy().reshape(-1, 4); d = d[d[:, 1] > 0]
@@ -14,6 +14,7 @@ life = d[:, 1] / 100.0
 xcc = (d[:, 3] >> 32) & 0xF; hw = d[:, 3] & 0xFFFFFFFF
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 cuid = xcc * 1000 + se * 100 + sh * 20 + cu
+print("blocks per wavefront", chain.blocks_per_wave(chain.nblocks(n)), "(a residency slot hosts several wavefronts one after another when the launch has more wavefronts than slots: the per-CU counts below are wavefronts hosted over the launch, not concurrent ones)")
 print("waves", len(d), "distinct CUs", len(set(cuid)), "life us: min %.0f med %.0f max %.0f" % (life.min(), np.median(life), life.max()))
 cnt = collections.Counter(cuid)
 print("waves per CU histogram:", sorted(collections.Counter(cnt.values()).items()))

@@ -41,7 +41,7 @@ for fused in ((True,) if 'fused' in sys.argv else (True, False)):
         lib.redio_event_record(evs[0], st)
         for k in range(steps):
             chain(data, out); lib.redio_event_record(evs[k + 1], st)
-        dbg = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
+        dbg = torch.zeros(4 * chain.launch_waves(chain.nblocks(n)), dtype=torch.int64, device="cuda")  # one record per wavefront of the launch
         chain.set_debug_stamps(dbg); chain(data, out); torch.cuda.synchronize(); chain.set_debug_stamps(None)
         stop.set(); th.join()
         ms = []
