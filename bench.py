@@ -281,7 +281,7 @@ def main():
         for e in sev:
             lib.redio_event_destroy(e)
         tail = sorted(sms[len(sms) // 3:])          # the last two thirds: past the clock ramp
-        steady = {"launches": a.steady, "after_launches": a.warmup + a.steps,
+        steady = {"launches": a.steady, "after_launches": a.warmup + a.steps + (precondition["launches"] if precondition else 0),
                   "kernel_ms_mean": sum(tail) / len(tail), "kernel_ms_median": tail[len(tail) // 2], "kernel_ms_min": tail[0],
                   "series_every_10th_ms": [round(v, 4) for v in sms[::10]]}
 
