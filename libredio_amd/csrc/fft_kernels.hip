@@ -9,6 +9,7 @@
 //   fft_global_*        larger N: digit-reversal copy + one launch per stage in global memory.
 #include "redio_internal.h"
 #include "fft_wave.h"
+#include "fft_big_core.h"
 
 namespace redio {
 
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256) void fft_global_generic_stage_kernel(FftPlanDe
 // Stage A multiplies by tw[n kA fsA] (n = 1, 2, 3; the same for its four butterflies), stage B butterfly u by
 // tw[n (kB + u step) fsB].  The 15 values are loaded as one batch (behind a scheduling barrier where the caller wants the
 // next group's batch in flight during the current group's arithmetic); the compiler otherwise sinks each load to its use.
-struct FftTw15 { float2 t[15]; };
+// (FftTw15 and macro16_apply: fft_big_core.h)
 template <typename TwPtr>
 __device__ __forceinline__ void tw15_load(FftTw15 &T, TwPtr tw, unsigned kA, unsigned fsA, unsigned kB, unsigned step, unsigned fsB)
 {
@@ -744,18 +745,6 @@ __device__ __forceinline__ void tw15_load(FftTw15 &T, TwPtr tw, unsigned kA, uns
         const unsigned k = kB + u * step;
         T.t[3 + 3 * u] = tw_get(tw, k, fsB, 1); T.t[4 + 3 * u] = tw_get(tw, k, fsB, 2); T.t[5 + 3 * u] = tw_get(tw, k, fsB, 3);
     }
-}
-template <bool INV>
-__device__ __forceinline__ void macro16_apply(float2 (&a)[16], const FftTw15 &T)
-{
-#pragma unroll
-    for (int q = 0; q < 4; q += 2)
-        bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], T.t[0], T.t[1], T.t[2], a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7],
-                     T.t[0], T.t[1], T.t[2]);
-#pragma unroll
-    for (int u = 0; u < 4; u += 2)
-        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], T.t[3 + 3 * u], T.t[4 + 3 * u], T.t[5 + 3 * u], a[u + 1], a[u + 5], a[u + 9], a[u + 13],
-                     T.t[6 + 3 * u], T.t[7 + 3 * u], T.t[8 + 3 * u]);
 }
 // four groups with per-group twiddles: batch g + 1 is requested before group g is computed
 template <bool INV, bool AHEAD = true, typename LoadFn>
@@ -783,59 +772,7 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
     return p;
 }
 
-// twiddle n k N / (4 m) of the stage with sub-length m: straight from kissfft's table (stride fs = N / (4 m)), or from the
-// pass-ordered copy T[(n - 1) m + k] (fftbig_tables_build), where lanes with neighbouring k read neighbouring entries --
-// in the table order a wave's 64 twiddles of an in-place pass sit in 64 different cache lines
-struct TwGather {
-    const float2 *tw; unsigned fs;
-    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return tw[n * k * fs]; }
-    __device__ __forceinline__ void get3(unsigned k, float2 &t1, float2 &t2, float2 &t3) const { t1 = get(1, k); t2 = get(2, k); t3 = get(3, k); }
-};
-struct TwOrdered {
-    const float2 *T; unsigned m;
-    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[(n - 1) * m + k]; }
-    __device__ __forceinline__ void get3(unsigned k, float2 &t1, float2 &t2, float2 &t3) const { t1 = get(1, k); t2 = get(2, k); t3 = get(3, k); }
-};
-// the copy of a four-stage in-place pass, INTERLEAVED: entry k of a stage holds its three twiddles side by side, T[4 k + (n - 1)]
-// (the fourth slot pads the entry to 32 bytes).  A butterfly's three twiddles are then one 16-byte and one 8-byte load from one
-// 32-byte entry instead of three 8-byte loads from three planes m entries apart -- measured on the access pattern alone: the
-// in-place pass of 65536 points 283 -> 233 us per 2^26 points, of 2^24 points 318 -> 254 (profiles/r02_fft_pass_times.txt).
-// Round 3: a tile reads 43 KB of these entries for its 32 KB of samples, all from L2 -- and a timing-only build in which every lane reads
-// entry k mod 16 runs the in-place pass of 65536 points in 253 us against 246, the overlap-save passes in 32.1 / 46.0 us against 33.6 / 47.2:
-// the twiddle traffic is not what holds the passes at 4.2-5.5 TB/s, so a workgroup-resident LDS copy of them was not built.
-struct TwInter {
-    const float2 *T;
-    __device__ __forceinline__ float2 get(unsigned n, unsigned k) const { return T[4 * k + (n - 1)]; }
-    __device__ __forceinline__ void get3(unsigned k, float2 &t1, float2 &t2, float2 &t3) const
-    {
-        const float4 q = *reinterpret_cast<const float4 *>(T + 4 * (size_t)k); // 32-byte entries of a 256-byte aligned table
-        t1 = make_float2(q.x, q.y); t2 = make_float2(q.z, q.w); t3 = T[4 * (size_t)k + 2];
-    }
-};
-template <bool INV, typename TA, typename TB>
-__device__ __forceinline__ void big_macro16(float2 (&a)[16], TA ta, TB tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
-{
-    {
-        const unsigned k = l + m_lo * kk;
-        float2 t1, t2, t3;
-        ta.get3(k, t1, t2, t3);
-#pragma unroll
-        for (int q = 0; q < 4; q += 2)
-            bfly4x2<INV>(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], t1, t2, t3, a[4 * q + 4], a[4 * q + 5], a[4 * q + 6], a[4 * q + 7], t1, t2, t3);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u += 2) {
-        const unsigned k = l + m_lo * (kk + u * m), kb = k + m_lo * m;
-        float2 p1, p2, p3, r1, r2, r3;
-        tb.get3(k, p1, p2, p3);
-        tb.get3(kb, r1, r2, r3);
-        bfly4x2<INV>(a[u], a[u + 4], a[u + 8], a[u + 12], p1, p2, p3, a[u + 1], a[u + 5], a[u + 9], a[u + 13], r1, r2, r3);
-    }
-}
-// the ordered copy of one pass: stage t (sub-length m_lo 4^t) starts at m_lo (4^t - 1) and holds 3 m_lo 4^t entries
-__device__ __forceinline__ TwOrdered tw_ordered_stage(const float2 *T, unsigned m_lo, int t) { return TwOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
-// the interleaved copy: stage t (sub-length m_lo 4^t) starts at entry m_lo (4^t - 1) / 3 and holds m_lo 4^t entries of four float2
-__device__ __forceinline__ TwInter tw_inter_stage(const float2 *T, unsigned m_lo, int t) { return TwInter{T + 4 * (size_t)(m_lo * (((1u << (2 * t)) - 1) / 3))}; }
+// (TwGather / TwOrdered / TwInter, big_macro16, tw_ordered_stage, tw_inter_stage: fft_big_core.h)
 __global__ __launch_bounds__(256) void fftbig_tables_inter_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned m_lo, int nstages, unsigned N)
 {
     const unsigned total = m_lo * (((1u << (2 * nstages)) - 1) / 3); // entries over all stages
@@ -950,12 +887,25 @@ __device__ __forceinline__ void big_st_once(float2 *p, float2 v)
 #endif
 }
 
+} // namespace redio
+// Round 4: the two-column ("pair") form of the four-stage tile passes (fft_pair.h, fft_big_core.h): 16-byte global and LDS accesses.
+// -DREDIO_TILE_PAIR=0 builds the one-column program below for comparison; both give the same bits.
+#ifndef REDIO_TILE_PAIR
+#define REDIO_TILE_PAIR 1
+#endif
+#include "fft_pair.h"
+namespace redio {
+
 // overlap-save middle pass: forward pass 1, spectrum product, inverse pass 0 on the same tile.  After the forward
 // stages lane (col, q) holds rows s + 16 j, s = q + 4 x: in the inverse transform's digit-reversed order that IS
 // group 4 q + x with rows in rev2 order, so the inverse starts from registers without another exchange.
 __device__ __forceinline__ void ovsave64k_mid_tile(const float2 *__restrict__ a_blk, float2 *__restrict__ b_blk, const float2 *__restrict__ Tf,
                                                    const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc, int c, int lane, float2 *Lw)
 {
+#if REDIO_TILE_PAIR
+    pw_ovsave64k_mid_tile(a_blk, b_blk, Tf, tw_i, Hc, c, lane, reinterpret_cast<float4 *>(Lw));
+    return;
+#endif
     const int col = lane & 15, q = lane >> 4;
     const float2 *src = a_blk + F64K_COLS * c;
     float2 *dst = b_blk;
@@ -997,7 +947,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
                                                                  const float2 *__restrict__ Tf, const float2 *__restrict__ tw_i,
                                                                  const float2 *__restrict__ Hc, long ntiles)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile() + w;
     if (tile >= ntiles) return;
@@ -1009,6 +959,10 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_mid_wave_kernel(const float2
 __device__ __forceinline__ void ovsave64k_last_tile(const float2 *__restrict__ b_blk, float2 *__restrict__ out_blk, const float2 *__restrict__ Ti,
                                                     long hop, float scale, int c, int lane, float2 *Lw)
 {
+#if REDIO_TILE_PAIR
+    pw_ovsave64k_last_tile(b_blk, out_blk, Ti, hop, scale, c, lane, reinterpret_cast<float4 *>(Lw));
+    return;
+#endif
     const int col = lane & 15, q = lane >> 4;
     const float2 *src = b_blk + F64K_COLS * c;
     float2 *dst = out_blk + F64K_COLS * c;
@@ -1034,7 +988,7 @@ __device__ __forceinline__ void ovsave64k_last_tile(const float2 *__restrict__ b
 __global__ __launch_bounds__(256, 2) void ovsave64k_last_wave_kernel(const float2 *__restrict__ b_in, float2 *__restrict__ out,
                                                                   const float2 *__restrict__ Ti, long hop, float scale, long ntiles)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile() + w;
     if (tile >= ntiles) return;
@@ -1475,6 +1429,11 @@ template <bool INV>
 __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *out_blk, const float2 *__restrict__ tw, int L, unsigned c,
                                                   int lane, float2 *Lw, const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
 {
+#if REDIO_TILE_PAIR
+    (void)tw;
+    pw_first_tile<INV>(in_blk, out_blk, L, c, lane, reinterpret_cast<float4 *>(Lw), mulH, T1);
+    return;
+#endif
     const unsigned N = 1u << (2 * L), S = N >> 8; // S: source row stride
     const int col = lane & 15, q = lane >> 4;
     const float2 *src = in_blk + 16 * c;
@@ -1515,7 +1474,7 @@ template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
                                                            long ntiles, int L, const float2 *__restrict__ mulH = nullptr, const float2 *__restrict__ T1 = nullptr)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile() + w;
     if (tile >= ntiles) return;
@@ -1528,7 +1487,7 @@ template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ T, long ntiles, int lgN, int lm, float2 *__restrict__ vout = nullptr,
                                                          long hop = 0, float scale = 1.0f, int rev = 0)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile = f64w_first_tile(rev) + w;
     if (tile >= ntiles) return;
@@ -1539,6 +1498,10 @@ __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const 
     const unsigned c = tt & ((m_lo >> 4) - 1), h = tt >> (lm - 4); // positions l = 16c + col of block h
     const int col = lane & 15, q = lane >> 4;
     float2 *base = data + xf * (long)N + (long)h * 256 * m_lo + 16 * c;
+#if REDIO_TILE_PAIR
+    pw_mid_tile<INV>(base, (long)m_lo, 16 * c, T, reinterpret_cast<float4 *>(Lw), lane, vout ? vout + xf * hop : nullptr, (long)h * 256 * m_lo + 16 * c, hop, scale);
+    return;
+#endif
     const unsigned l = 16 * c + col;
     float2 a[4][16], b[4][16];
     const unsigned lo_ld = col + 16u * m_lo * q, lo_st = col + m_lo * q;
@@ -1578,7 +1541,7 @@ template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const float2 *__restrict__ T, long ngroups, int lgN, int lm,
                                                           float2 *__restrict__ vout = nullptr, long hop = 0, float scale = 1.0f, int rev = 0)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     __shared__ F5Image X;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long group = f64w_first_tile(rev) >> 2;
@@ -1641,7 +1604,7 @@ template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first5_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T1,
                                                             long in_stride, long ngroups, int L, const float2 *__restrict__ mulH = nullptr)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     __shared__ F5Image X;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long group = f64w_first_tile() >> 2;
@@ -2162,7 +2125,11 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
     fftbig_after_first(lgN, lm, left);
     float2 *T = tables;
     for (; left >= 4; lm += 8, left -= 4) {
+#if REDIO_TILE_PAIR // the pair tile program reads the ORDERED copy two neighbouring entries at a time (fft_big_core.h, TwPairOrdered); 255 of the 340 float2 per unit
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm, 4, (unsigned)nfft);
+#else
         hipLaunchKernelGGL(fftbig_tables_inter_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lm, 4, (unsigned)nfft);
+#endif
         T += (size_t)FFTBIG_MID4_ELEMS << lm;
     }
     if (left == 3) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft); T += (size_t)15 << (lgN - 6); }
@@ -2171,7 +2138,11 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
         int lmb = fftbig_plan_b_lm0(pb);
         for (int i = 0; i < pb.nmid; ++i) {
             if (pb.mid[i] == 5) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, 5, (unsigned)nfft);
+#if REDIO_TILE_PAIR
+            else hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, 4, (unsigned)nfft);
+#else
             else hipLaunchKernelGGL(fftbig_tables_inter_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << lmb, 4, (unsigned)nfft);
+#endif
             T += (size_t)(pb.mid[i] == 5 ? 1023 : FFTBIG_MID4_ELEMS) << lmb;
             lmb += 2 * pb.mid[i];
         }
@@ -2268,7 +2239,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_first_kernel(const floa
                                                                    const float2 *__restrict__ x_next, float2 *__restrict__ a_out,
                                                                    const float2 *__restrict__ tw_f, long ntiles_first, const float2 *__restrict__ T1)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *Lw = Ls + w * F64W_REGION;
     // workgroup b: kind = b & 1 while both kinds have work left, the longer kind takes the rest
@@ -2302,7 +2273,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_step_kernel(Ovs64kStep st, c
                                                              const float2 *__restrict__ tw_f, const float2 *__restrict__ tw_i,
                                                              const float2 *__restrict__ Hc, const float2 *__restrict__ T1, long hop, float scale)
 {
-    __shared__ float2 Ls[4 * F64W_REGION];
+    __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *Lw = Ls + w * F64W_REGION;
     // workgroup b -> (kind, workgroup of that kind): round r hands one workgroup to every kind that still has more than r.  (An XCD-aware

@@ -1,0 +1,253 @@
+// fft_pair.h -- device side of the two-column ("pair") tile program of the four-stage passes (maps and LDS images: fft_big_core.h).
+// Included by fft_kernels.hip after its tile helpers (wave_lds_fence, big_ld_once / big_st_once, f64k constants).
+//
+// One wavefront per 256-row x 16-column tile, 64 points per lane as before, but a lane holds two adjacent columns (two adjacent rows
+// on the transposed side): 32 global_load_dwordx4 + 32 global_store_dwordx4 per lane and pass instead of 64 + 64 dwordx2, and
+// 32 ds_write_b128 + 32 ds_read_b128 per regrouping instead of 64 + 64 b64.  Same butterflies in the same order with the same
+// twiddles: the results are the bits of the one-column program (kissfft's, oracle/oracle_kiss.c).
+#pragma once
+#include "fft_big_core.h"
+
+namespace redio {
+
+typedef float pw_v4 __attribute__((ext_vector_type(4)));
+// the caller's buffers (block b of the stream starts at x + b hop: 8-byte aligned only when hop is odd)
+typedef float pw_v4u __attribute__((ext_vector_type(4), aligned(8)));
+
+__device__ __forceinline__ float4 pw_ld(const float2 *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void pw_st(float2 *p, float2 lo, float2 hi) { *reinterpret_cast<float4 *>(p) = make_float4(lo.x, lo.y, hi.x, hi.y); }
+// data touched ONCE by a multi-pass transform (the caller's input / output): non-temporal, like big_ld_once / big_st_once
+__device__ __forceinline__ float4 pw_ld_once(const float2 *p)
+{
+#if REDIO_EXP_BIG_NT & 1
+    const pw_v4u v = __builtin_nontemporal_load(reinterpret_cast<const pw_v4u *>(p));
+#else
+    const pw_v4u v = *reinterpret_cast<const pw_v4u *>(p);
+#endif
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void pw_st_once(float2 *p, float2 lo, float2 hi)
+{
+    const pw_v4u v = {lo.x, lo.y, hi.x, hi.y};
+#if REDIO_EXP_BIG_NT & 2
+    __builtin_nontemporal_store(v, reinterpret_cast<pw_v4u *>(p));
+#else
+    *reinterpret_cast<pw_v4u *>(p) = v;
+#endif
+}
+
+// the four rounds of a regrouping; every lane has written before any lane reads, and has read before the image is written again
+template <typename G>
+__device__ __forceinline__ void pw_exchange_plain(float2 (&a)[2][2][16], float2 (&b)[2][2][16], float4 *Lw, int lane)
+{
+    pw_plain_write<0, 0>(a, Lw, lane); wave_lds_fence(); pw_plain_read<G, 0, 0>(b, Lw, lane); wave_lds_fence();
+    pw_plain_write<0, 1>(a, Lw, lane); wave_lds_fence(); pw_plain_read<G, 0, 1>(b, Lw, lane); wave_lds_fence();
+    pw_plain_write<1, 0>(a, Lw, lane); wave_lds_fence(); pw_plain_read<G, 1, 0>(b, Lw, lane); wave_lds_fence();
+    pw_plain_write<1, 1>(a, Lw, lane); wave_lds_fence(); pw_plain_read<G, 1, 1>(b, Lw, lane); wave_lds_fence();
+}
+template <typename G>
+__device__ __forceinline__ void pw_exchange_tr(float2 (&a)[2][2][16], float2 (&b)[2][2][16], float4 *Lw, int lane)
+{
+    pw_tr_write<0, 0>(a, Lw, lane); wave_lds_fence(); pw_tr_read<G, 0, 0>(b, Lw, lane); wave_lds_fence();
+    pw_tr_write<0, 1>(a, Lw, lane); wave_lds_fence(); pw_tr_read<G, 0, 1>(b, Lw, lane); wave_lds_fence();
+    pw_tr_write<1, 0>(a, Lw, lane); wave_lds_fence(); pw_tr_read<G, 1, 0>(b, Lw, lane); wave_lds_fence();
+    pw_tr_write<1, 1>(a, Lw, lane); wave_lds_fence(); pw_tr_read<G, 1, 1>(b, Lw, lane); wave_lds_fence();
+}
+
+// ---- in-place four-stage pass on rows m_lo apart: load, stages 0-1, plain regrouping, stages 2-3 --------------------------------------
+// base: the tile's origin (row 0, column 0); l0: position of column 0 inside the sub-length m_lo (the twiddle index of a column);
+// T: the pass's ORDERED twiddle copy (in a pair build fftbig_tables_build lays the four-stage passes' copies out that way: a lane's two
+// columns are two neighbouring entries, one 16-byte load per twiddle pair).  On return b[x][e][j] = row (q + 8 x) + 16 j of column 2 cp + e.
+template <bool INV>
+__device__ __forceinline__ void pw_mid_stages(float2 (&b)[2][2][16], const float2 *base, long m_lo, unsigned l0, const float2 *__restrict__ T,
+                                              float4 *Lw, int lane)
+{
+    const int cp = lane & 7, q = lane >> 3;
+    const unsigned ml = (unsigned)m_lo;
+    float2 a[2][2][16];
+    const unsigned lo = (unsigned)pw_mid_ld(m_lo, q, cp, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 v = pw_ld((base + pw_mid_ld(m_lo, 0, 0, i, j)) + lo);
+            a[i][0][j] = make_float2(v.x, v.y); a[i][1][j] = make_float2(v.z, v.w);
+        }
+    RD_SCHED_BARRIER();
+    {
+        FftTw15 T0, T1;
+        big_tw15x2(T0, T1, tw_pair_stage(T, ml, 0), tw_pair_stage(T, ml, 1), l0 + 2u * cp, ml, 0u, 1u);
+        RD_SCHED_BARRIER();
+        macro16_apply<INV>(a[0][0], T0); macro16_apply<INV>(a[1][0], T0);
+        macro16_apply<INV>(a[0][1], T1); macro16_apply<INV>(a[1][1], T1);
+    }
+    pw_exchange_plain<PwGroupsLinear>(a, b, Lw, lane);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        FftTw15 T0, T1;
+        big_tw15x2(T0, T1, tw_pair_stage(T, ml, 2), tw_pair_stage(T, ml, 3), l0 + 2u * cp, ml, (unsigned)(q + 8 * x), 16u);
+        RD_SCHED_BARRIER();
+        macro16_apply<INV>(b[x][0], T0);
+        macro16_apply<INV>(b[x][1], T1);
+    }
+}
+
+// the in-place pass as a whole (fftbig_mid_kernel); vout: overlap-save, this was the last pass -- 1/N and only the hop valid outputs, packed
+template <bool INV>
+__device__ __forceinline__ void pw_mid_tile(float2 *base, long m_lo, unsigned l0, const float2 *__restrict__ T, float4 *Lw, int lane,
+                                            float2 *__restrict__ vout_blk, long e0, long hop, float scale)
+{
+    const int cp = lane & 7, q = lane >> 3;
+    float2 b[2][2][16];
+    pw_mid_stages<INV>(b, base, m_lo, l0, T, Lw, lane);
+    const unsigned lo = (unsigned)pw_mid_st(m_lo, q, cp, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (vout_blk) { // e0: position of the tile's origin inside the block
+                const long e = e0 + pw_mid_st(m_lo, 0, 0, x, j) + lo;
+                const float2 v0 = make_float2(mul_rn(b[x][0][j].x, scale), mul_rn(b[x][0][j].y, scale));
+                const float2 v1 = make_float2(mul_rn(b[x][1][j].x, scale), mul_rn(b[x][1][j].y, scale));
+                if (e + 1 < hop) pw_st_once(vout_blk + e, v0, v1);
+                else if (e < hop) big_st_once(vout_blk + e, v0);
+            } else pw_st((base + pw_mid_st(m_lo, 0, 0, x, j)) + lo, b[x][0][j], b[x][1][j]);
+        }
+}
+
+// ---- gather pass of a 4^L-point transform: digit-reversed load, stages 0-1, transposed regrouping, stages 2-3, working-order store -----
+// in_blk + 16 c: source columns 16 c .. 16 c + 15; T1: the gather pass's ordered twiddle copy (sub-lengths 1 .. 256)
+template <bool INV>
+__device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_blk, int L, unsigned c, int lane, float4 *Lw,
+                                              const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
+{
+    const long S = 1l << (2 * L - 8); // source row stride
+    const int cp = lane & 7, q = lane >> 3;
+    const float2 *src = in_blk + 16 * c;
+    float2 a[2][2][16], b[2][2][16];
+    const unsigned lo_src = (unsigned)pw_first_ld(S, q, cp, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 v = pw_ld_once((src + pw_first_ld(S, 0, 0, i, j)) + lo_src);
+            a[i][0][j] = make_float2(v.x, v.y); a[i][1][j] = make_float2(v.z, v.w);
+        }
+    if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
+        const float2 *hsrc = mulH + 16 * c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jh = 0; jh < 16; jh += 8) { // eight pairs of spectrum taps per batch of loads (sixteen spill: 128 sample registers are live)
+                float4 hv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = pw_ld((hsrc + pw_first_ld(S, 0, 0, i, jh + j)) + lo_src);
+                RD_SCHED_BARRIER();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a[i][0][jh + j] = cmul_rn(a[i][0][jh + j], make_float2(hv[j].x, hv[j].y));
+                    a[i][1][jh + j] = cmul_rn(a[i][1][jh + j], make_float2(hv[j].z, hv[j].w));
+                }
+            }
+    }
+    RD_SCHED_BARRIER();
+    {
+        FftTw15 T0; // sub-lengths 1 and 4: the twiddle depends on the row only (wave-uniform)
+        big_tw15(T0, tw_ordered_stage(T1, 1u, 0), tw_ordered_stage(T1, 1u, 1), 0u, 1u, 0u, 1u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) macro16_apply<INV>(a[i][e], T0);
+    }
+    pw_exchange_tr<PwGroupsLinear>(a, b, Lw, lane);
+    const int sp = lane & 7, qq = lane >> 3;
+    {
+        FftTw15 T0, Tb; // sub-lengths 16 and 64: index = the row inside the 256-row transform, 2 sp + e (+ 16 u)
+        big_tw15(T0, tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
+        big_tw15(Tb, tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp + 1), 16u);
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int x = 0; x < 2; ++x) { macro16_apply<INV>(b[x][0], T0); macro16_apply<INV>(b[x][1], Tb); }
+    }
+    unsigned rc = 0; // digit reversal of c over L - 6 digits
+    for (int d = 0, cc = (int)c; d < L - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
+    float2 *dst = out_blk + 256l * rc;
+    const unsigned lo_dst = (unsigned)pw_first_st(L, qq, sp, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pw_st((dst + pw_first_st(L, 0, 0, x, j)) + lo_dst, b[x][0][j], b[x][1][j]);
+}
+
+// ---- overlap-save, 65536-point blocks: middle pass = forward pass 1, x conj H, inverse pass 0 on the same tile -----------------------------
+// After the forward stages lane (cp, q) holds rows s + 16 j, s = q + 8 x, of its two columns: in the inverse transform's gather pass
+// that is group rev2(s) with its rows in rev2 order (PwGroupsRev), so the inverse starts from registers.
+__device__ __forceinline__ void pw_ovsave64k_mid_tile(const float2 *__restrict__ a_blk, float2 *__restrict__ b_blk, const float2 *__restrict__ Tf,
+                                                      const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc, int c, int lane, float4 *Lw)
+{
+    const int cp = lane & 7, q = lane >> 3;
+    float2 a[2][2][16], b[2][2][16];
+    pw_mid_stages<false>(b, a_blk + 16 * c, 256l, (unsigned)(16 * c), Tf, Lw, lane);
+    const float2 *hc = Hc + 16 * c;
+    const unsigned lo = (unsigned)pw_mid_st(256l, q, cp, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { // sixteen pairs of spectrum taps as one batch of loads
+        float4 h[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h[j] = pw_ld((hc + pw_mid_st(256l, 0, 0, x, j)) + lo);
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { // row s + 16 j = digit reversal of 16 rev2(s) + rev2(j)
+            a[x][0][pw_rev2(j)] = cmul_rn(b[x][0][j], make_float2(h[j].x, h[j].y));
+            a[x][1][pw_rev2(j)] = cmul_rn(b[x][1][j], make_float2(h[j].z, h[j].w));
+        }
+    }
+    {
+        FftTw15 T0; // the inverse's sub-lengths 1 and 4 (table stride 16384, 4096)
+        big_tw15(T0, TwGather{tw_i, 16384u}, TwGather{tw_i, 4096u}, 0u, 1u, 0u, 1u);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) macro16_apply<true>(a[x][e], T0);
+    }
+    pw_exchange_tr<PwGroupsRev>(a, b, Lw, lane);
+    const int sp = lane & 7, qq = lane >> 3;
+    {
+        FftTw15 T0, Tb; // sub-lengths 16 and 64 (table stride 1024, 256), index 2 sp + e (+ 16 u)
+        big_tw15(T0, TwGather{tw_i, 1024u}, TwGather{tw_i, 256u}, 0u, 1u, (unsigned)(2 * sp), 16u);
+        big_tw15(Tb, TwGather{tw_i, 1024u}, TwGather{tw_i, 256u}, 0u, 1u, (unsigned)(2 * sp + 1), 16u);
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int x = 0; x < 2; ++x) { macro16_apply<true>(b[x][0], T0); macro16_apply<true>(b[x][1], Tb); }
+    }
+    float2 *dst = b_blk + 256 * pw_rev2(c);
+    const unsigned lo_dst = (unsigned)pw_first_st(8, qq, sp, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pw_st((dst + pw_first_st(8, 0, 0, x, j)) + lo_dst, b[x][0][j], b[x][1][j]);
+}
+
+// last pass: inverse pass 1, 1/N, only the hop valid outputs of the block stored
+__device__ __forceinline__ void pw_ovsave64k_last_tile(const float2 *__restrict__ b_blk, float2 *__restrict__ out_blk, const float2 *__restrict__ Ti,
+                                                       long hop, float scale, int c, int lane, float4 *Lw)
+{
+    const int cp = lane & 7, q = lane >> 3;
+    float2 b[2][2][16];
+    pw_mid_stages<true>(b, b_blk + 16 * c, 256l, (unsigned)(16 * c), Ti, Lw, lane);
+    float2 *dst = out_blk + 16 * c;
+    const unsigned lo = (unsigned)pw_mid_st(256l, q, cp, 0, 0);
+    const long lim = hop - 16 * c - (long)lo; // pos < hop
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long r = pw_mid_st(256l, 0, 0, x, j);
+            const float2 v0 = make_float2(mul_rn(b[x][0][j].x, scale), mul_rn(b[x][0][j].y, scale));
+            const float2 v1 = make_float2(mul_rn(b[x][1][j].x, scale), mul_rn(b[x][1][j].y, scale));
+            if (r + 1 < lim) pw_st_once((dst + r) + lo, v0, v1);
+            else if (r < lim) big_st_once((dst + r) + lo, v0);
+        }
+}
+
+} // namespace redio

@@ -388,3 +388,245 @@ extern "C" int emu_src_rb(const float *xt, const double *L, int ncl, const doubl
     else return -1;
     return 0;
 }
+
+// ================================================================================================================================
+// The two-column ("pair") tile program of the four-stage passes (libredio_amd/csrc/fft_big_core.h; device side: fft_pair.h), one
+// lane at a time: the same lane <-> row / column maps, LDS images, group maps and twiddle batches as the kernels, so that the
+// 65536-point transform and the three-pass overlap-save block can be checked against the oracle without a GPU.
+// ================================================================================================================================
+#include "../../libredio_amd/csrc/fft_big_core.h"
+
+namespace {
+struct PairLane { float2 a[2][2][16], b[2][2][16]; };
+
+// the tables the plans build on the device (fftbig_tables_kernel / fftbig_tables_inter_kernel): same formulas
+std::vector<float2> pair_ordered_table(const std::vector<float2> &tw, unsigned m_lo, int nstages, unsigned N)
+{
+    const unsigned total = m_lo * ((1u << (2 * nstages)) - 1);
+    std::vector<float2> T(total);
+    for (unsigned i = 0; i < total; ++i) {
+        int t = 0;
+        while (i >= m_lo * ((1u << (2 * (t + 1))) - 1)) ++t;
+        const unsigned m = m_lo << (2 * t), r = i - m_lo * ((1u << (2 * t)) - 1), n = r / m + 1, k = r - (n - 1) * m;
+        T[i] = tw[(size_t)n * k * (N / (4 * m))];
+    }
+    return T;
+}
+std::vector<float2> pair_inter_table(const std::vector<float2> &tw, unsigned m_lo, int nstages, unsigned N)
+{
+    const unsigned total = m_lo * (((1u << (2 * nstages)) - 1) / 3);
+    std::vector<float2> T((size_t)4 * total + 8);
+    for (unsigned i = 0; i < total; ++i) {
+        int t = 0;
+        while (i >= m_lo * (((1u << (2 * (t + 1))) - 1) / 3)) ++t;
+        const unsigned m = m_lo << (2 * t), k = i - m_lo * (((1u << (2 * t)) - 1) / 3), fs = N / (4 * m);
+        T[4 * (size_t)i] = tw[(size_t)k * fs]; T[4 * (size_t)i + 1] = tw[(size_t)2 * k * fs]; T[4 * (size_t)i + 2] = tw[(size_t)3 * k * fs];
+        T[4 * (size_t)i + 3] = make_float2(0.f, 0.f);
+    }
+    return T;
+}
+
+template <typename G> void pair_exchange_plain(std::vector<PairLane> &L, std::vector<float4> &img)
+{
+    auto round = [&](auto wr, auto rd) {
+        for (int lane = 0; lane < 64; ++lane) wr(lane);
+        for (int lane = 0; lane < 64; ++lane) rd(lane);
+    };
+    round([&](int l) { pw_plain_write<0, 0>(L[l].a, img.data(), l); }, [&](int l) { pw_plain_read<G, 0, 0>(L[l].b, img.data(), l); });
+    round([&](int l) { pw_plain_write<0, 1>(L[l].a, img.data(), l); }, [&](int l) { pw_plain_read<G, 0, 1>(L[l].b, img.data(), l); });
+    round([&](int l) { pw_plain_write<1, 0>(L[l].a, img.data(), l); }, [&](int l) { pw_plain_read<G, 1, 0>(L[l].b, img.data(), l); });
+    round([&](int l) { pw_plain_write<1, 1>(L[l].a, img.data(), l); }, [&](int l) { pw_plain_read<G, 1, 1>(L[l].b, img.data(), l); });
+}
+template <typename G> void pair_exchange_tr(std::vector<PairLane> &L, std::vector<float4> &img)
+{
+    auto round = [&](auto wr, auto rd) {
+        for (int lane = 0; lane < 64; ++lane) wr(lane);
+        for (int lane = 0; lane < 64; ++lane) rd(lane);
+    };
+    round([&](int l) { pw_tr_write<0, 0>(L[l].a, img.data(), l); }, [&](int l) { pw_tr_read<G, 0, 0>(L[l].b, img.data(), l); });
+    round([&](int l) { pw_tr_write<0, 1>(L[l].a, img.data(), l); }, [&](int l) { pw_tr_read<G, 0, 1>(L[l].b, img.data(), l); });
+    round([&](int l) { pw_tr_write<1, 0>(L[l].a, img.data(), l); }, [&](int l) { pw_tr_read<G, 1, 0>(L[l].b, img.data(), l); });
+    round([&](int l) { pw_tr_write<1, 1>(L[l].a, img.data(), l); }, [&](int l) { pw_tr_read<G, 1, 1>(L[l].b, img.data(), l); });
+}
+
+// pw_mid_stages of fft_pair.h: load, stages 0-1, plain regrouping, stages 2-3
+template <bool INV> void pair_mid_stages(std::vector<PairLane> &L, const float2 *base, long m_lo, unsigned l0, const float2 *T, std::vector<float4> &img)
+{
+    const unsigned ml = (unsigned)m_lo;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int cp = lane & 7, q = lane >> 3;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 16; ++j) {
+                const float2 *p = base + pw_mid_ld(m_lo, 0, 0, i, j) + pw_mid_ld(m_lo, q, cp, 0, 0);
+                L[lane].a[i][0][j] = p[0]; L[lane].a[i][1][j] = p[1];
+            }
+        {
+            FftTw15 T0, T1;
+            big_tw15x2(T0, T1, tw_pair_stage(T, ml, 0), tw_pair_stage(T, ml, 1), l0 + 2u * cp, ml, 0u, 1u);
+            macro16_apply<INV>(L[lane].a[0][0], T0); macro16_apply<INV>(L[lane].a[1][0], T0);
+            macro16_apply<INV>(L[lane].a[0][1], T1); macro16_apply<INV>(L[lane].a[1][1], T1);
+        }
+    }
+    pair_exchange_plain<PwGroupsLinear>(L, img);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int cp = lane & 7, q = lane >> 3;
+        for (int x = 0; x < 2; ++x) {
+            FftTw15 T0, T1;
+            big_tw15x2(T0, T1, tw_pair_stage(T, ml, 2), tw_pair_stage(T, ml, 3), l0 + 2u * cp, ml, (unsigned)(q + 8 * x), 16u);
+            macro16_apply<INV>(L[lane].b[x][0], T0); macro16_apply<INV>(L[lane].b[x][1], T1);
+        }
+    }
+}
+template <bool INV> void pair_mid_tile(float2 *base, long m_lo, unsigned l0, const float2 *T, std::vector<float4> &img)
+{
+    std::vector<PairLane> L(64);
+    pair_mid_stages<INV>(L, base, m_lo, l0, T, img);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int cp = lane & 7, q = lane >> 3;
+        for (int x = 0; x < 2; ++x)
+            for (int j = 0; j < 16; ++j) {
+                float2 *p = base + pw_mid_st(m_lo, 0, 0, x, j) + pw_mid_st(m_lo, q, cp, 0, 0);
+                p[0] = L[lane].b[x][0][j]; p[1] = L[lane].b[x][1][j];
+            }
+    }
+}
+// pw_first_tile
+template <bool INV> void pair_first_tile(const float2 *in_blk, float2 *out_blk, int Lg, unsigned c, const float2 *T1, std::vector<float4> &img)
+{
+    const long S = 1l << (2 * Lg - 8);
+    std::vector<PairLane> L(64);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int cp = lane & 7, q = lane >> 3;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 16; ++j) {
+                const float2 *p = in_blk + 16 * c + pw_first_ld(S, 0, 0, i, j) + pw_first_ld(S, q, cp, 0, 0);
+                L[lane].a[i][0][j] = p[0]; L[lane].a[i][1][j] = p[1];
+            }
+        FftTw15 T0;
+        big_tw15(T0, tw_ordered_stage(T1, 1u, 0), tw_ordered_stage(T1, 1u, 1), 0u, 1u, 0u, 1u);
+        for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 2; ++e) macro16_apply<INV>(L[lane].a[i][e], T0);
+    }
+    pair_exchange_tr<PwGroupsLinear>(L, img);
+    unsigned rc = 0;
+    for (int d = 0, cc = (int)c; d < Lg - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int sp = lane & 7, qq = lane >> 3;
+        for (int e = 0; e < 2; ++e) {
+            FftTw15 T0;
+            big_tw15(T0, tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp + e), 16u);
+            for (int x = 0; x < 2; ++x) macro16_apply<INV>(L[lane].b[x][e], T0);
+        }
+        for (int x = 0; x < 2; ++x)
+            for (int j = 0; j < 16; ++j) {
+                float2 *p = out_blk + 256l * rc + pw_first_st(Lg, 0, 0, x, j) + pw_first_st(Lg, qq, sp, 0, 0);
+                p[0] = L[lane].b[x][0][j]; p[1] = L[lane].b[x][1][j];
+            }
+    }
+}
+} // namespace
+
+// 65536-point transform = gather pass + one in-place pass, every tile through the pair program
+extern "C" void emu_pair_fft64k(const float2 *in, float2 *out, int inverse)
+{
+    const unsigned N = 65536;
+    std::vector<float2> tw = make_tw((int)N, inverse);
+    std::vector<float2> T1 = pair_ordered_table(tw, 1u, 5, N), T = pair_ordered_table(tw, 256u, 4, N);
+    std::vector<float4> img(PW_UNITS);
+    for (unsigned c = 0; c < 16; ++c) {
+        if (inverse) pair_first_tile<true>(in, out, 8, c, T1.data(), img);
+        else pair_first_tile<false>(in, out, 8, c, T1.data(), img);
+    }
+    for (unsigned c = 0; c < 16; ++c) {
+        if (inverse) pair_mid_tile<true>(out + 16 * c, 256l, 16 * c, T.data(), img);
+        else pair_mid_tile<false>(out + 16 * c, 256l, 16 * c, T.data(), img);
+    }
+}
+
+// one 65536-point overlap-save block through the three passes: x (65536 samples), Hc = conj(kiss_fft(h padded)), out (hop samples)
+extern "C" void emu_pair_ovsave64k(const float2 *x, const float2 *Hc, float2 *out, long hop)
+{
+    const unsigned N = 65536;
+    std::vector<float2> twf = make_tw((int)N, 0), twi = make_tw((int)N, 1);
+    std::vector<float2> T1 = pair_ordered_table(twf, 1u, 5, N), Tf = pair_ordered_table(twf, 256u, 4, N), Ti = pair_ordered_table(twi, 256u, 4, N);
+    std::vector<float4> img(PW_UNITS);
+    std::vector<float2> A(N), B(N);
+    for (unsigned c = 0; c < 16; ++c) pair_first_tile<false>(x, A.data(), 8, c, T1.data(), img);
+    for (int c = 0; c < 16; ++c) { // pw_ovsave64k_mid_tile
+        std::vector<PairLane> L(64);
+        pair_mid_stages<false>(L, A.data() + 16 * c, 256l, (unsigned)(16 * c), Tf.data(), img);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int cp = lane & 7, q = lane >> 3;
+            for (int xx = 0; xx < 2; ++xx)
+                for (int j = 0; j < 16; ++j) {
+                    const float2 *h = Hc + 16 * c + pw_mid_st(256l, 0, 0, xx, j) + pw_mid_st(256l, q, cp, 0, 0);
+                    L[lane].a[xx][0][pw_rev2(j)] = cmul_rn(L[lane].b[xx][0][j], h[0]);
+                    L[lane].a[xx][1][pw_rev2(j)] = cmul_rn(L[lane].b[xx][1][j], h[1]);
+                }
+            FftTw15 T0;
+            big_tw15(T0, TwGather{twi.data(), 16384u}, TwGather{twi.data(), 4096u}, 0u, 1u, 0u, 1u);
+            for (int xx = 0; xx < 2; ++xx)
+                for (int e = 0; e < 2; ++e) macro16_apply<true>(L[lane].a[xx][e], T0);
+        }
+        pair_exchange_tr<PwGroupsRev>(L, img);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int sp = lane & 7, qq = lane >> 3;
+            for (int e = 0; e < 2; ++e) {
+                FftTw15 T0;
+                big_tw15(T0, TwGather{twi.data(), 1024u}, TwGather{twi.data(), 256u}, 0u, 1u, (unsigned)(2 * sp + e), 16u);
+                for (int xx = 0; xx < 2; ++xx) macro16_apply<true>(L[lane].b[xx][e], T0);
+            }
+            for (int xx = 0; xx < 2; ++xx)
+                for (int j = 0; j < 16; ++j) {
+                    float2 *p = B.data() + 256 * pw_rev2(c) + pw_first_st(8, 0, 0, xx, j) + pw_first_st(8, qq, sp, 0, 0);
+                    p[0] = L[lane].b[xx][0][j]; p[1] = L[lane].b[xx][1][j];
+                }
+        }
+    }
+    const float scale = 1.0f / 65536.0f;
+    for (int c = 0; c < 16; ++c) { // pw_ovsave64k_last_tile
+        std::vector<PairLane> L(64);
+        pair_mid_stages<true>(L, B.data() + 16 * c, 256l, (unsigned)(16 * c), Ti.data(), img);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int cp = lane & 7, q = lane >> 3;
+            const long lo = pw_mid_st(256l, q, cp, 0, 0), lim = hop - 16 * c - lo;
+            for (int xx = 0; xx < 2; ++xx)
+                for (int j = 0; j < 16; ++j) {
+                    const long r = pw_mid_st(256l, 0, 0, xx, j);
+                    for (int e = 0; e < 2; ++e)
+                        if (r + e < lim) out[16 * c + r + lo + e] = make_float2(mul_rn(L[lane].b[xx][e][j].x, scale), mul_rn(L[lane].b[xx][e][j].y, scale));
+                }
+        }
+    }
+}
+
+// ds_write_b128 / ds_read_b128 of the pair images: a b128 access is served in four groups of 16 lanes ({0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}, the same + 32); returns the worst number of lanes of one group that share a 16-byte bank position (1 = conflict free)
+extern "C" int emu_pair_bank_conflicts(void)
+{
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int worst = 1;
+    auto check = [&](auto unit_of /* (lane, access) -> unit */) {
+        for (int acc = 0; acc < 8; ++acc)
+            for (int half = 0; half < 2; ++half)
+                for (int g = 0; g < 2; ++g) {
+                    int cnt[16] = {0};
+                    for (int t = 0; t < 16; ++t) cnt[unit_of(grp[g][t] + 32 * half, acc) % 16]++;
+                    for (int b = 0; b < 16; ++b) if (cnt[b] > worst) worst = cnt[b];
+                }
+    };
+    check([](int l, int jj) { return pw_unit_plain(l >> 3, jj, l & 7); });  // pw_plain_write
+    check([](int l, int qw) { return pw_unit_plain(qw, l >> 3, l & 7); });  // pw_plain_read
+    check([](int l, int jp) { return pw_unit_tr(l & 7, l >> 3, jp); });     // pw_tr_write
+    check([](int l, int qw) { return pw_unit_tr(l >> 3, qw, l & 7); });     // pw_tr_read
+    // the images are permutations of the 512 units
+    bool seen[2][PW_UNITS] = {{false}};
+    for (int a = 0; a < 8; ++a)
+        for (int b = 0; b < 8; ++b)
+            for (int c = 0; c < 8; ++c) {
+                const int u = pw_unit_plain(a, b, c), v = pw_unit_tr(a, b, c);
+                if (u < 0 || u >= PW_UNITS || v < 0 || v >= PW_UNITS || seen[0][u] || seen[1][v]) return 99;
+                seen[0][u] = seen[1][v] = true;
+            }
+    return worst;
+}

@@ -124,3 +124,35 @@ def test_resampler_register_blocked_wings(emu, R, U, S, ncl, ncr):
         assert np.array_equal(bits(out), bits(ref)), (R, U, S, poison, np.flatnonzero(bits(out) != bits(ref))[:8])
         if poison:
             assert not np.isfinite(ref[0]) and not np.isfinite(ref[-1]) and np.isfinite(ref[1:-1]).all()
+
+
+# ---- the two-column ("pair") tile program of the four-stage passes (fft_big_core.h, fft_pair.h) --------------------------
+@pytest.mark.parametrize("inv", [0, 1])
+def test_pair_tile_program_fft_65536(emu, oracle, inv):
+    """Gather pass + in-place pass of the 65536-point transform, every tile through the pair program's lane maps, LDS images and
+    twiddle batches: the oracle's kiss_fft, bit for bit."""
+    emu.emu_pair_fft64k.argtypes = [c64, c64, C.c_int]
+    x = oracle.synth_iq(77 + inv, 0, 65536)
+    y = np.empty_like(x)
+    emu.emu_pair_fft64k(x, y, inv)
+    assert np.array_equal(bits(y), bits(oracle.fft(x, inverse=bool(inv))))
+
+
+@pytest.mark.parametrize("k", [127, 8193, 8192])
+def test_pair_tile_program_overlap_save_block(emu, oracle, k):
+    """One 65536-point overlap-save block through the three pair-program passes (gather; forward pass 1 x conj H x inverse pass 0 on
+    one tile; inverse pass 1 with the masked, scaled store): orc_overlap_save on the same block, bit for bit (odd and even hop)."""
+    emu.emu_pair_ovsave64k.argtypes = [c64, c64, c64, C.c_long]
+    n = 65536
+    x = oracle.synth_iq(5, 0, n)
+    h = oracle.lpf_corrected(k, 0.1)
+    hp = np.zeros(n, np.complex64); hp[:k] = h
+    Hc = np.conj(oracle.fft(hp)).astype(np.complex64)
+    hop = n - k + 1
+    out = np.zeros(hop, np.complex64)
+    emu.emu_pair_ovsave64k(x, np.ascontiguousarray(Hc), out, hop)
+    assert np.array_equal(bits(out), bits(oracle.overlap_save(x, h, n)))
+
+
+def test_pair_lds_images_are_bank_conflict_free(emu):
+    assert emu.emu_pair_bank_conflicts() == 1
