@@ -60,17 +60,28 @@ struct TwInter {
 // the ordered copy read two neighbouring k at a time (the pair tile program: a lane's two columns are twiddle indices k, k + 1, k even):
 // T[(n - 1) m + k] and T[(n - 1) m + k + 1] are one aligned 16-byte load, and the eight lanes of a row group read 128 contiguous
 // bytes per load -- one cache line per row group and load instead of the four half-used lines of the 32-byte interleaved entries
-struct TwPairOrdered {
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float rd_v4u __attribute__((ext_vector_type(4), aligned(8)));
+RD_HD float4 rd_ld_pair(const float2 *p) { const rd_v4u v = *reinterpret_cast<const rd_v4u *>(p); return make_float4(v.x, v.y, v.z, v.w); }
+#else
+RD_HD float4 rd_ld_pair(const float2 *p) { return make_float4(p[0].x, p[0].y, p[1].x, p[1].y); }
+#endif
+// ALIGNED = false: the gather pass's copy (sub-lengths 1, 4, 16, 64, 256 back to back: a stage starts on an odd entry) -- the same
+// 16-byte load from an 8-byte aligned address
+template <bool ALIGNED = true>
+struct TwPairOrderedT {
     const float2 *T; unsigned m;
     RD_HD void get3x2(unsigned k, float2 &a1, float2 &a2, float2 &a3, float2 &b1, float2 &b2, float2 &b3) const
     {
-        const float4 q1 = *reinterpret_cast<const float4 *>(T + k), q2 = *reinterpret_cast<const float4 *>(T + m + k),
-                     q3 = *reinterpret_cast<const float4 *>(T + 2 * m + k);
+        const float4 q1 = ALIGNED ? *reinterpret_cast<const float4 *>(T + k) : rd_ld_pair(T + k),
+                     q2 = ALIGNED ? *reinterpret_cast<const float4 *>(T + m + k) : rd_ld_pair(T + m + k),
+                     q3 = ALIGNED ? *reinterpret_cast<const float4 *>(T + 2 * m + k) : rd_ld_pair(T + 2 * m + k);
         a1 = make_float2(q1.x, q1.y); b1 = make_float2(q1.z, q1.w);
         a2 = make_float2(q2.x, q2.y); b2 = make_float2(q2.z, q2.w);
         a3 = make_float2(q3.x, q3.y); b3 = make_float2(q3.z, q3.w);
     }
 };
+typedef TwPairOrderedT<true> TwPairOrdered;
 template <bool INV, typename TA, typename TB>
 RD_HD void big_macro16(float2 (&a)[16], TA ta, TB tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
 {
@@ -106,7 +117,8 @@ RD_HD void big_tw15(FftTw15 &T, TA ta, TB tb, unsigned l, unsigned m_lo, unsigne
     for (unsigned u = 0; u < 4; ++u) tb.get3(l + m_lo * (kk + u * m), T.t[3 + 3 * u], T.t[4 + 3 * u], T.t[5 + 3 * u]);
 }
 // ... for the two columns l, l + 1 (l even) of a lane of the pair program, from the ordered copy
-RD_HD void big_tw15x2(FftTw15 &Ta, FftTw15 &Tb, TwPairOrdered ta, TwPairOrdered tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
+template <typename TP>
+RD_HD void big_tw15x2(FftTw15 &Ta, FftTw15 &Tb, TP ta, TP tb, unsigned l, unsigned m_lo, unsigned kk, unsigned m)
 {
     ta.get3x2(l + m_lo * kk, Ta.t[0], Ta.t[1], Ta.t[2], Tb.t[0], Tb.t[1], Tb.t[2]);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -118,6 +130,7 @@ RD_HD void big_tw15x2(FftTw15 &Ta, FftTw15 &Tb, TwPairOrdered ta, TwPairOrdered 
 // the ordered copy of one pass: stage t (sub-length m_lo 4^t) starts at m_lo (4^t - 1) and holds 3 m_lo 4^t entries
 RD_HD TwOrdered tw_ordered_stage(const float2 *T, unsigned m_lo, int t) { return TwOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
 RD_HD TwPairOrdered tw_pair_stage(const float2 *T, unsigned m_lo, int t) { return TwPairOrdered{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
+RD_HD TwPairOrderedT<false> tw_pair_stage_u(const float2 *T, unsigned m_lo, int t) { return TwPairOrderedT<false>{T + m_lo * ((1u << (2 * t)) - 1), m_lo << (2 * t)}; }
 // the interleaved copy: stage t (sub-length m_lo 4^t) starts at entry m_lo (4^t - 1) / 3 and holds m_lo 4^t entries of four float2
 RD_HD TwInter tw_inter_stage(const float2 *T, unsigned m_lo, int t) { return TwInter{T + 4 * (size_t)(m_lo * (((1u << (2 * t)) - 1) / 3))}; }
 

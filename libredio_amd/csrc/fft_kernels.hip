@@ -2312,6 +2312,9 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
     if (!Tf || !Ti || chunk < 1) return hipErrorInvalidValue; // the plans' pass-ordered twiddle copies (fftbig_tables_build)
     auto tiles = [&](long b0) { const long nb = nblk - b0 < chunk ? nblk - b0 : chunk; return nb * 16; };
     const float2 *T1 = Tf + (fftbig_tables_elems(F64K_N) - fftbig_first_elems(16)); // the forward plan's gather-pass copy
+#if REDIO_TILE_PAIR // the pair program's middle tile reads the inverse gather pass's twiddles from the INVERSE plan's ordered copy, not from the table
+    tw_i = Ti + (fftbig_tables_elems(F64K_N) - fftbig_first_elems(16));
+#endif
     hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8, nullptr, T1);
     static const bool fused3 = !measure_env("REDIO_OVS_NO_STEP"); // measurement knob: the two-launch form below
     if (fused3 && doubled) { // a, b hold TWO chunks each

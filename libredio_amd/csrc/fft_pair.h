@@ -162,9 +162,8 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
     pw_exchange_tr<PwGroupsLinear>(a, b, Lw, lane);
     const int sp = lane & 7, qq = lane >> 3;
     {
-        FftTw15 T0, Tb; // sub-lengths 16 and 64: index = the row inside the 256-row transform, 2 sp + e (+ 16 u)
-        big_tw15(T0, tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
-        big_tw15(Tb, tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp + 1), 16u);
+        FftTw15 T0, Tb; // sub-lengths 16 and 64: index = the row inside the 256-row transform, 2 sp + e (+ 16 u): neighbouring entries
+        big_tw15x2(T0, Tb, tw_pair_stage_u(T1, 1u, 2), tw_pair_stage_u(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
         RD_SCHED_BARRIER();
 #pragma unroll
         for (int x = 0; x < 2; ++x) { macro16_apply<INV>(b[x][0], T0); macro16_apply<INV>(b[x][1], Tb); }
@@ -183,8 +182,8 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
 // After the forward stages lane (cp, q) holds rows s + 16 j, s = q + 8 x, of its two columns: in the inverse transform's gather pass
 // that is group rev2(s) with its rows in rev2 order (PwGroupsRev), so the inverse starts from registers.
 __device__ __forceinline__ void pw_ovsave64k_mid_tile(const float2 *__restrict__ a_blk, float2 *__restrict__ b_blk, const float2 *__restrict__ Tf,
-                                                      const float2 *__restrict__ tw_i, const float2 *__restrict__ Hc, int c, int lane, float4 *Lw)
-{
+                                                      const float2 *__restrict__ T1i, const float2 *__restrict__ Hc, int c, int lane, float4 *Lw)
+{ // T1i: the INVERSE plan's gather-pass ordered copy (sub-lengths 1 .. 256), as pw_first_tile reads it
     const int cp = lane & 7, q = lane >> 3;
     float2 a[2][2][16], b[2][2][16];
     pw_mid_stages<false>(b, a_blk + 16 * c, 256l, (unsigned)(16 * c), Tf, Lw, lane);
@@ -203,8 +202,8 @@ __device__ __forceinline__ void pw_ovsave64k_mid_tile(const float2 *__restrict__
         }
     }
     {
-        FftTw15 T0; // the inverse's sub-lengths 1 and 4 (table stride 16384, 4096)
-        big_tw15(T0, TwGather{tw_i, 16384u}, TwGather{tw_i, 4096u}, 0u, 1u, 0u, 1u);
+        FftTw15 T0; // the inverse's sub-lengths 1 and 4: wave-uniform
+        big_tw15(T0, tw_ordered_stage(T1i, 1u, 0), tw_ordered_stage(T1i, 1u, 1), 0u, 1u, 0u, 1u);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -213,9 +212,8 @@ __device__ __forceinline__ void pw_ovsave64k_mid_tile(const float2 *__restrict__
     pw_exchange_tr<PwGroupsRev>(a, b, Lw, lane);
     const int sp = lane & 7, qq = lane >> 3;
     {
-        FftTw15 T0, Tb; // sub-lengths 16 and 64 (table stride 1024, 256), index 2 sp + e (+ 16 u)
-        big_tw15(T0, TwGather{tw_i, 1024u}, TwGather{tw_i, 256u}, 0u, 1u, (unsigned)(2 * sp), 16u);
-        big_tw15(Tb, TwGather{tw_i, 1024u}, TwGather{tw_i, 256u}, 0u, 1u, (unsigned)(2 * sp + 1), 16u);
+        FftTw15 T0, Tb; // sub-lengths 16 and 64, index 2 sp + e (+ 16 u): neighbouring entries of the ordered copy
+        big_tw15x2(T0, Tb, tw_pair_stage_u(T1i, 1u, 2), tw_pair_stage_u(T1i, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
         RD_SCHED_BARRIER();
 #pragma unroll
         for (int x = 0; x < 2; ++x) { macro16_apply<true>(b[x][0], T0); macro16_apply<true>(b[x][1], Tb); }

@@ -512,10 +512,10 @@ template <bool INV> void pair_first_tile(const float2 *in_blk, float2 *out_blk, 
     for (int d = 0, cc = (int)c; d < Lg - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
     for (int lane = 0; lane < 64; ++lane) {
         const int sp = lane & 7, qq = lane >> 3;
-        for (int e = 0; e < 2; ++e) {
-            FftTw15 T0;
-            big_tw15(T0, tw_ordered_stage(T1, 1u, 2), tw_ordered_stage(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp + e), 16u);
-            for (int x = 0; x < 2; ++x) macro16_apply<INV>(L[lane].b[x][e], T0);
+        {
+            FftTw15 T0, Tb;
+            big_tw15x2(T0, Tb, tw_pair_stage_u(T1, 1u, 2), tw_pair_stage_u(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
+            for (int x = 0; x < 2; ++x) { macro16_apply<INV>(L[lane].b[x][0], T0); macro16_apply<INV>(L[lane].b[x][1], Tb); }
         }
         for (int x = 0; x < 2; ++x)
             for (int j = 0; j < 16; ++j) {
@@ -548,7 +548,7 @@ extern "C" void emu_pair_ovsave64k(const float2 *x, const float2 *Hc, float2 *ou
 {
     const unsigned N = 65536;
     std::vector<float2> twf = make_tw((int)N, 0), twi = make_tw((int)N, 1);
-    std::vector<float2> T1 = pair_ordered_table(twf, 1u, 5, N), Tf = pair_ordered_table(twf, 256u, 4, N), Ti = pair_ordered_table(twi, 256u, 4, N);
+    std::vector<float2> T1 = pair_ordered_table(twf, 1u, 5, N), T1i = pair_ordered_table(twi, 1u, 5, N), Tf = pair_ordered_table(twf, 256u, 4, N), Ti = pair_ordered_table(twi, 256u, 4, N);
     std::vector<float4> img(PW_UNITS);
     std::vector<float2> A(N), B(N);
     for (unsigned c = 0; c < 16; ++c) pair_first_tile<false>(x, A.data(), 8, c, T1.data(), img);
@@ -564,17 +564,17 @@ extern "C" void emu_pair_ovsave64k(const float2 *x, const float2 *Hc, float2 *ou
                     L[lane].a[xx][1][pw_rev2(j)] = cmul_rn(L[lane].b[xx][1][j], h[1]);
                 }
             FftTw15 T0;
-            big_tw15(T0, TwGather{twi.data(), 16384u}, TwGather{twi.data(), 4096u}, 0u, 1u, 0u, 1u);
+            big_tw15(T0, tw_ordered_stage(T1i.data(), 1u, 0), tw_ordered_stage(T1i.data(), 1u, 1), 0u, 1u, 0u, 1u);
             for (int xx = 0; xx < 2; ++xx)
                 for (int e = 0; e < 2; ++e) macro16_apply<true>(L[lane].a[xx][e], T0);
         }
         pair_exchange_tr<PwGroupsRev>(L, img);
         for (int lane = 0; lane < 64; ++lane) {
             const int sp = lane & 7, qq = lane >> 3;
-            for (int e = 0; e < 2; ++e) {
-                FftTw15 T0;
-                big_tw15(T0, TwGather{twi.data(), 1024u}, TwGather{twi.data(), 256u}, 0u, 1u, (unsigned)(2 * sp + e), 16u);
-                for (int xx = 0; xx < 2; ++xx) macro16_apply<true>(L[lane].b[xx][e], T0);
+            {
+                FftTw15 T0, Tb;
+                big_tw15x2(T0, Tb, tw_pair_stage_u(T1i.data(), 1u, 2), tw_pair_stage_u(T1i.data(), 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
+                for (int xx = 0; xx < 2; ++xx) { macro16_apply<true>(L[lane].b[xx][0], T0); macro16_apply<true>(L[lane].b[xx][1], Tb); }
             }
             for (int xx = 0; xx < 2; ++xx)
                 for (int j = 0; j < 16; ++j) {
