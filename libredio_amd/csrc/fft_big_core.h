@@ -237,4 +237,117 @@ RD_HD constexpr long pw_first_st(int L, int qq, int sp, int x, int j)
     return 256l * ((long)((2 * (qq & 1) + x)) * (1l << (2 * (L - 5))) + (long)(qq >> 1) * (1l << (2 * (L - 6)))) + 16 * j + 2 * sp;
 }
 
+
+// =============================================================================================================================
+// G128: the gather pass of N = 2 * 4^L' points (32768, 131072 ...) with FOUR stages -- kissfft's radix-2 stage (sub-length 1) and the
+// radix-4 stages of sub-length 2, 8 and 32 -- on tiles of 128 rows x 32 source columns, one wavefront per tile, in the pair layout.
+// (fftbig_first2_kernel does the first three of them, 32 rows; with the fourth in the same pass 2^15 points are this pass plus ONE
+// four-stage in-place pass, 2^17 points this pass plus one five-stage pass, and the overlap-save of 32768-point blocks gets the
+// three-pass scheme of the 65536-point blocks: the forward in-place pass, the spectrum product and this pass of the INVERSE transform
+// on one tile.)
+//
+// Leaf position P = 128 h + (b0 + 2 d1 + 8 d2 + 32 d3) holds input n = column + S (d3 + 4 d2 + 16 d1 + 64 b0), S = N / 128, h = digit
+// reversal of the column.  lane = cp + 16 q: columns 2 cp, 2 cp + 1 (cp = 0..15) of source rows with d3 = q.
+//   phase A  a[e][d2][b0 + 2 d1]: the stages on b0, d1, d2 run inside the lane (the register program of fftbig_first2_kernel)
+//   phase B  lane = kp + 8 cg: b[r][x][e][d3] = position kk = 16 r + 2 kp + e (+ 32 d3) of column cg + 8 x   (r = 0, 1; x = 0..3):
+//            the stage on d3, then every store instruction writes eight 128-byte runs (rows kk, kk + 1 of eight lanes are contiguous)
+// The regrouping goes through a 16 KiB wave-private image in two rounds (kk below 16, then the rest), b128 both ways, swizzled
+// conflict-free for the documented lane groups of ds_read_b128 and for sixteen consecutive lanes on the write side.
+// =============================================================================================================================
+constexpr int PW_G_UNITS = 1024;
+// unit of (column gamma = 0..31, d3, kp = 0..7): rows 2 kp, 2 kp + 1 (+ 16 r) of that column and d3
+RD_HD constexpr int pw_unit_g(int gamma, int d3, int kp) { return 16 * ((gamma & 1) + 2 * kp + 16 * d3) + (((gamma >> 1) ^ (((kp & 3) << 2) | ((gamma & 1) << 1))) & 15); }
+template <int R>
+RD_HD void pw_g_write(const float2 (&a)[2][4][8], float4 *Lw, int lane)
+{
+    const int cp = lane & 15, q = lane >> 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < 2; ++e)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int kp = 0; kp < 8; ++kp) { // kk = 16 R + 2 kp (+1) = position (kk & 7) of d2 = kk >> 3
+            const float2 v0 = a[e][2 * R + (kp >> 2)][2 * (kp & 3)], v1 = a[e][2 * R + (kp >> 2)][2 * (kp & 3) + 1];
+            Lw[pw_unit_g(2 * cp + e, q, kp)] = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
+}
+template <int R>
+RD_HD void pw_g_read(float2 (&b)[2][4][2][4], const float4 *Lw, int lane)
+{
+    const int kp = lane & 7, cg = lane >> 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int x = 0; x < 4; ++x)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int d3 = 0; d3 < 4; ++d3) {
+            const float4 v = Lw[pw_unit_g(cg + 8 * x, d3, kp)];
+            b[R][x][0][d3] = make_float2(v.x, v.y);
+            b[R][x][1][d3] = make_float2(v.z, v.w);
+        }
+}
+// the plan's ordered twiddle copy for this pass, 128 entries: [0] tw[0] (radix-2 stage); [2 + (n-1) 2 + k] sub-length 2 (table stride N / 8);
+// [8 + (n-1) 8 + k] sub-length 8 (N / 32); [32 + (n-1) 32 + k] sub-length 32 (N / 128)
+constexpr int PW_G_TABLE = 128;
+RD_HD void pw_g_table_entry(const float2 *tw, unsigned N, int i, float2 &out)
+{
+    if (i < 2) { out = tw[0]; return; }
+    const int m = i < 8 ? 2 : i < 32 ? 8 : 32, r = i - m, n = r / m + 1, k = r - (n - 1) * m;
+    out = tw[(size_t)n * k * (N / (4u * m))];
+}
+// the three stages a lane runs on its own 32 rows of one column: a[d2][b0 + 2 d1] -> position (b0 + 2 d1) + 8 d2 in a[d2'][k]
+template <bool INV>
+RD_HD void pw_g_inlane(float2 (&a)[4][8], const float2 *Tg)
+{
+    const float2 w0 = Tg[0], w1 = Tg[2 + 1], w2 = Tg[2 + 2 + 1], w3 = Tg[2 + 4 + 1]; // sub-length 2, k = b0 = 1: n = 1, 2, 3
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int d2 = 0; d2 < 4; ++d2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int d1 = 0; d1 < 4; ++d1) bfly2(a[d2][2 * d1], a[d2][2 * d1 + 1], w0);
+        bfly4x2<INV>(a[d2][0], a[d2][2], a[d2][4], a[d2][6], w0, w0, w0, a[d2][1], a[d2][3], a[d2][5], a[d2][7], w1, w2, w3);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k += 2) // stage on d2: sub-length 8, k = b0 + 2 d1
+        bfly4x2<INV>(a[0][k], a[1][k], a[2][k], a[3][k], Tg[8 + k], Tg[16 + k], Tg[24 + k],
+                     a[0][k + 1], a[1][k + 1], a[2][k + 1], a[3][k + 1], Tg[8 + k + 1], Tg[16 + k + 1], Tg[24 + k + 1]);
+}
+// the stage on d3 (sub-length 32, twiddle index kk = 16 r + 2 kp + e) on the lane's sixteen four-point groups
+template <bool INV>
+RD_HD void pw_g_last(float2 (&b)[2][4][2][4], const float2 *Tg, int kp)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 2; ++r) {
+        const float4 q1 = *reinterpret_cast<const float4 *>(Tg + 32 + 16 * r + 2 * kp), q2 = *reinterpret_cast<const float4 *>(Tg + 64 + 16 * r + 2 * kp),
+                     q3 = *reinterpret_cast<const float4 *>(Tg + 96 + 16 * r + 2 * kp);
+        const float2 a1 = make_float2(q1.x, q1.y), b1 = make_float2(q1.z, q1.w), a2 = make_float2(q2.x, q2.y), b2 = make_float2(q2.z, q2.w),
+                     a3 = make_float2(q3.x, q3.y), b3 = make_float2(q3.z, q3.w);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int x = 0; x < 4; ++x)
+            bfly4x2<INV>(b[r][x][0][0], b[r][x][0][1], b[r][x][0][2], b[r][x][0][3], a1, a2, a3, b[r][x][1][0], b[r][x][1][1], b[r][x][1][2], b[r][x][1][3], b1, b2, b3);
+    }
+}
+// source of phase A (cf32 offset from in_blk + 32 ctile): row S (q + 4 d2 + 16 d1 + 64 b0), jb = b0 + 2 d1; lane part f(q, cp, 0, 0) + uniform part f(0, 0, d2, jb)
+RD_HD constexpr long pw_g_ld(long S, int q, int cp, int d2, int jb) { return S * (q + 4 * d2 + 16 * (jb >> 1) + 64 * (jb & 1)) + 2 * cp; }
+// destination of phase B, stand-alone pass: column 32 ctile + (cg + 8 x) of nd base-4 digits -> 128 h + 32 d3 + 16 r + 2 kp; the caller adds
+// 128 * (2 (ctile & 1) 4^(nd-3) + rev(ctile >> 1)).  Lane part f(cg, kp, 0, 0, 0) + uniform part f(0, 0, x, r, d3)
+RD_HD constexpr long pw_g_st(int nd, int cg, int kp, int x, int r, int d3)
+{
+    return 128l * ((long)(cg & 3) * (1l << (2 * (nd - 1))) + (long)((cg >> 2) + 2 * (x & 1)) * (1l << (2 * (nd - 2))) + (long)(x >> 1) * (1l << (2 * (nd - 3)))) +
+           32 * d3 + 16 * r + 2 * kp;
+}
+
 } // namespace redio

@@ -1483,6 +1483,31 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
     fftbig_first_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), tw, L, c, lane, Ls + w * F64W_REGION, mulH, T1);
 }
 
+// G128 gather pass (N = 2 * 4^L'; fft_pair.h): one wavefront per tile of 128 source rows x 32 source columns
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_g128_kernel(const float2 *in, float2 *out, long in_stride, long ntiles, int lgN,
+                                                          const float2 *__restrict__ mulH, const float2 *__restrict__ Tg)
+{
+    __shared__ float4 Lg[4 * PW_G_UNITS];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    const long xf = tile >> (lgN - 12);
+    const unsigned ctile = (unsigned)(tile & ((1u << (lgN - 12)) - 1)); // source columns 32 ctile .. + 31
+    pw_g128_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << lgN), lgN, ctile, lane, Lg + w * PW_G_UNITS, mulH, Tg);
+}
+// overlap-save with 32768-point blocks, middle pass (fft_pair.h): eight tiles of 256 rows x 16 columns per block
+__global__ __launch_bounds__(256, 2) void ovsave32k_mid_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out, const float2 *__restrict__ Tf,
+                                                            const float2 *__restrict__ Tgi, const float2 *__restrict__ Hc, long ntiles)
+{
+    __shared__ float4 Lg[4 * PW_G_UNITS];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = f64w_first_tile() + w;
+    if (tile >= ntiles) return;
+    const long xf = tile >> 3;
+    pw_ovsave32k_mid_tile(a_in + xf * 32768, b_out + xf * 32768, Tf, Tgi, Hc, (int)(tile & 7), lane, Lg + w * PW_G_UNITS);
+}
+
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_mid_kernel(float2 *data, const float2 *__restrict__ T, long ntiles, int lgN, int lm, float2 *__restrict__ vout = nullptr,
                                                          long hop = 0, float scale = 1.0f, int rev = 0)
@@ -2087,6 +2112,15 @@ static size_t fftbig_five_elems(int lgN)
 // every 4^L size: the gather pass's ordered copy (sub-lengths 1, 4, 16, 64, 256), at the very end of the tables
 static size_t fftbig_first_elems(int lgN) { return (lgN & 1) ? 0 : 1023; }
 static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24) && (nfft & (nfft - 1)) == 0 && nfft != 16384; }
+// Plan G (round 4; pair builds): 2^15 and 2^17 points run the FOUR-stage gather pass G128 (fft_big_core.h) and ONE in-place pass on rows
+// 128 apart -- four stages (2^15) or five (2^17) -- instead of the three-stage gather pass plus a five-stage pass / two more passes.
+// Its tables sit at the very end of the plan's tables: the G128 copy (128 entries), then the in-place pass's ordered copy.
+static bool fftbig_plan_g(int lgN) { return REDIO_TILE_PAIR && (lgN == 15 || lgN == 17); }
+static size_t fftbig_g_elems(int lgN)
+{
+    if (!fftbig_plan_g(lgN)) return 0;
+    return (size_t)PW_G_TABLE + ((size_t)(lgN == 15 ? FFTBIG_MID4_ELEMS : 1023) << 7);
+}
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
     if (lgN & 1) { lm = 5; left = (lgN - 5) / 2; } // 2 * 4^L: the gather pass did the radix-2 stage and two radix-4 stages
@@ -2106,7 +2140,13 @@ size_t fftbig_tables_elems(int nfft)
     size_t total = 0;
     for (; left >= 4; lm += 8, left -= 4) total += (size_t)FFTBIG_MID4_ELEMS << lm;
     if (left == 3) total += (size_t)15 << (lgN - 6);
-    return total + fftbig_five_elems(lgN) + fftbig_first_elems(lgN);
+    return total + fftbig_five_elems(lgN) + fftbig_first_elems(lgN) + fftbig_g_elems(lgN);
+}
+__global__ __launch_bounds__(128) void fftbig_g_table_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned N)
+{
+    float2 v;
+    pw_g_table_entry(tw, N, (int)threadIdx.x, v);
+    T[threadIdx.x] = v;
 }
 hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s)
 {
@@ -2147,7 +2187,11 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
             lmb += 2 * pb.mid[i];
         }
     }
-    if (fftbig_first_elems(lgN)) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(4), dim3(256), 0, s, tw, T, 1u, 5, (unsigned)nfft);
+    if (fftbig_first_elems(lgN)) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(4), dim3(256), 0, s, tw, T, 1u, 5, (unsigned)nfft); T += fftbig_first_elems(lgN); }
+    if (fftbig_plan_g(lgN)) {
+        hipLaunchKernelGGL(fftbig_g_table_kernel, dim3(1), dim3(128), 0, s, tw, T, (unsigned)nfft);
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T + PW_G_TABLE, 1u << 7, lgN == 15 ? 4 : 5, (unsigned)nfft);
+    }
     return hipGetLastError();
 }
 
@@ -2165,10 +2209,17 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     const long ntiles = nbatch << (lgN - 12);
     int rev = 0; // direction of the pass before (the gather pass walks forward)
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
-    const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_first_elems(lgN)) : nullptr;
+    const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN) - fftbig_first_elems(lgN)) : nullptr;
+    if (fftbig_plan_g(lgN)) { // G128 + one in-place pass on rows 128 apart
+        const float2 *Tg = tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN)), *Tm = Tg + PW_G_TABLE;
+        hipLaunchKernelGGL(fftbig_g128_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, in_stride, ntiles, lgN, mulH, Tg);
+        if (lgN == 15) hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, Tm, ntiles, lgN, 7, vout, hop, scale, 1);
+        else hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)(nbatch << (lgN - 14))), dim3(256), 0, s, out, Tm, nbatch << (lgN - 14), lgN, 7, vout, hop, scale, 1);
+        return hipGetLastError();
+    }
     BigPlanB pb;
     if (fftbig_plan_b(lgN, pb)) {
-        const float2 *T = tables + (fftbig_tables_elems(1 << lgN) - fftbig_first_elems(lgN) - fftbig_five_elems(lgN));
+        const float2 *T = tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN) - fftbig_first_elems(lgN) - fftbig_five_elems(lgN));
         const long ngroups = nbatch << (lgN - 14);
         if (pb.first == 2) {
             const long nt2 = nbatch << (lgN - 11);
@@ -2226,6 +2277,16 @@ hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const f
 {
     if (!ovsave_big_size(fw.nfft) || fw.nfft != bw.nfft || !fw.tw_pass || !bw.tw_pass) return hipErrorInvalidValue;
     const int lgN = __builtin_ctz((unsigned)fw.nfft);
+    if (lgN == 15 && fftbig_plan_g(lgN)) { // three passes: G128 forward; [forward in-place pass x conj H x inverse G128] on one tile; inverse in-place pass
+        const size_t goff = fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN);
+        const float2 *Tgf = fw.tw_pass + goff, *Tgi = bw.tw_pass + goff;
+        const long ntiles = nblk << 3;
+        const unsigned grid = (unsigned)((ntiles + 3) / 4);
+        hipLaunchKernelGGL(fftbig_g128_kernel<false>, dim3(grid), dim3(256), 0, s, x, a, hop, ntiles, lgN, (const float2 *)nullptr, Tgf);
+        hipLaunchKernelGGL(ovsave32k_mid_kernel, dim3(grid), dim3(256), 0, s, a, b, Tgf + PW_G_TABLE, Tgi, Hc, ntiles);
+        hipLaunchKernelGGL(fftbig_mid_kernel<true>, dim3(grid), dim3(256), 0, s, b, Tgi + PW_G_TABLE, ntiles, lgN, 7, out, hop, scale, 0);
+        return hipGetLastError();
+    }
     hipError_t e = launch_fftbig<false>(x, a, fw.tw, fw.tw_pass, nblk, hop, lgN, s);
     if (e != hipSuccess) return e;
     return launch_fftbig<true>(a, b, bw.tw, bw.tw_pass, nblk, (long)fw.nfft, lgN, s, Hc, out, hop, scale);

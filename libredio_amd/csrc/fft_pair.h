@@ -248,4 +248,106 @@ __device__ __forceinline__ void pw_ovsave64k_last_tile(const float2 *__restrict_
         }
 }
 
+
+// ---- G128: gather pass of N = 2 * 4^L' points with four stages (fft_big_core.h) -----------------------------------------------------------
+// the part after phase A's registers are in place: in-lane stages, regrouping, stage on d3; b[r][x][e][d3] on return
+template <bool INV>
+__device__ __forceinline__ void pw_g128_stages(float2 (&a)[2][4][8], float2 (&b)[2][4][2][4], const float2 *__restrict__ Tg, float4 *Lw, int lane)
+{
+    pw_g_inlane<INV>(a[0], Tg);
+    pw_g_inlane<INV>(a[1], Tg);
+    pw_g_write<0>(a, Lw, lane); wave_lds_fence(); pw_g_read<0>(b, Lw, lane); wave_lds_fence();
+    pw_g_write<1>(a, Lw, lane); wave_lds_fence(); pw_g_read<1>(b, Lw, lane); wave_lds_fence();
+    pw_g_last<INV>(b, Tg, lane & 7);
+}
+// in_blk + 32 ctile: source columns 32 ctile .. + 31 (of S = N / 128); out_blk: the working order
+template <bool INV>
+__device__ __forceinline__ void pw_g128_tile(const float2 *in_blk, float2 *out_blk, int lgN, unsigned ctile, int lane, float4 *Lw,
+                                             const float2 *__restrict__ mulH, const float2 *__restrict__ Tg)
+{
+    const long S = 1l << (lgN - 7);
+    const int nd = (lgN - 7) / 2; // base-4 digits of a source column
+    const int cp = lane & 15, q = lane >> 4;
+    const float2 *src = in_blk + 32 * ctile;
+    float2 a[2][4][8], b[2][4][2][4];
+    const unsigned lo_src = (unsigned)pw_g_ld(S, q, cp, 0, 0);
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            const float4 v = pw_ld_once((src + pw_g_ld(S, 0, 0, d2, jb)) + lo_src);
+            a[0][d2][jb] = make_float2(v.x, v.y); a[1][d2][jb] = make_float2(v.z, v.w);
+        }
+    if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
+        const float2 *hsrc = mulH + 32 * ctile;
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) {
+            float4 hv[8];
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) hv[jb] = pw_ld((hsrc + pw_g_ld(S, 0, 0, d2, jb)) + lo_src);
+            RD_SCHED_BARRIER();
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                a[0][d2][jb] = cmul_rn(a[0][d2][jb], make_float2(hv[jb].x, hv[jb].y));
+                a[1][d2][jb] = cmul_rn(a[1][d2][jb], make_float2(hv[jb].z, hv[jb].w));
+            }
+        }
+    }
+    RD_SCHED_BARRIER();
+    pw_g128_stages<INV>(a, b, Tg, Lw, lane);
+    unsigned hc = 0; // digits of ctile >> 1 reversed (nd - 3 of them), behind the digit whose high bit is ctile & 1
+    for (int d = 0, cc = (int)(ctile >> 1); d < nd - 3; ++d, cc >>= 2) hc = (hc << 2) | (cc & 3);
+    float2 *dst = out_blk + 128l * (((long)(2 * (ctile & 1))) * (1l << (2 * (nd - 3))) + hc);
+    const int kp = lane & 7, cg = lane >> 3;
+    const unsigned lo_dst = (unsigned)pw_g_st(nd, cg, kp, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int d3 = 0; d3 < 4; ++d3) pw_st((dst + pw_g_st(nd, 0, 0, x, r, d3)) + lo_dst, b[r][x][0][d3], b[r][x][1][d3]);
+}
+
+// ---- overlap-save, 32768-point blocks: the 65536-point scheme with this gather pass ------------------------------------------------------
+// middle pass: the forward in-place pass (rows 128 apart), x conj H, and the INVERSE transform's G128 pass on the same tile.  After
+// the forward stages lane (cp, q) holds rows s + 16 j, s = q + 8 x, of tile columns 2 cp + e, i.e. spectrum positions
+// n = (16 c + 2 cp + e) + 128 (s + 16 j).  For the inverse's gather pass n = column' + 256 rho: column' = 16 c + 2 cp + e + 128 (q & 1),
+// rho = (q >> 1) + 4 (x + 2 j) -- its d3 = q >> 1 and all of (d2, d1, b0) = the base-4 / binary digits of x + 2 j: exactly the rows
+// one lane of pw_g128_tile holds for G128 column gamma = 2 (lane & 15) + e, with d3 = lane >> 4.  The inverse starts from registers.
+__device__ __forceinline__ void pw_ovsave32k_mid_tile(const float2 *__restrict__ a_blk, float2 *__restrict__ b_blk, const float2 *__restrict__ Tf,
+                                                      const float2 *__restrict__ Tgi, const float2 *__restrict__ Hc, int c, int lane, float4 *Lw)
+{
+    const int cp = lane & 7, q = lane >> 3;
+    float2 f[2][2][16], a[2][4][8], b[2][4][2][4];
+    pw_mid_stages<false>(f, a_blk + 16 * c, 128l, (unsigned)(16 * c), Tf, Lw, lane);
+    const float2 *hc = Hc + 16 * c;
+    const unsigned lo = (unsigned)pw_mid_st(128l, q, cp, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        float4 h[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h[j] = pw_ld((hc + pw_mid_st(128l, 0, 0, x, j)) + lo);
+        RD_SCHED_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { // x + 2 j = d2 + 4 d1 + 16 b0: d2 = x + 2 (j & 1), d1 = (j >> 1) & 3, b0 = j >> 3
+            const int d2 = x + 2 * (j & 1), jb = (j >> 3) + 2 * ((j >> 1) & 3);
+            a[0][d2][jb] = cmul_rn(f[x][0][j], make_float2(h[j].x, h[j].y));
+            a[1][d2][jb] = cmul_rn(f[x][1][j], make_float2(h[j].z, h[j].w));
+        }
+    }
+    pw_g128_stages<true>(a, b, Tgi, Lw, lane);
+    // G128 column gamma = cg + 8 x' is spectrum column' = 16 c + (gamma & 15) + 128 (gamma >> 4), four base-4 digits: gamma & 3, (gamma >> 2) & 3,
+    // c & 3, (c >> 2) + 2 (gamma >> 4) -> position 128 h + 32 d3 + kk with h the digits reversed
+    const int kp = lane & 7, cg = lane >> 3;
+    float2 *dst = b_blk + 128l * (4 * (c & 3) + (c >> 2));
+    const unsigned lo_dst = (unsigned)(128 * (64 * (cg & 3) + 16 * (cg >> 2)) + 2 * kp);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int d3 = 0; d3 < 4; ++d3)
+                pw_st((dst + (128 * (32 * (x & 1) + 2 * (x >> 1)) + 32 * d3 + 16 * r)) + lo_dst, b[r][x][0][d3], b[r][x][1][d3]);
+}
+
 } // namespace redio

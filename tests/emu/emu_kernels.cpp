@@ -630,3 +630,165 @@ extern "C" int emu_pair_bank_conflicts(void)
             }
     return worst;
 }
+
+// ---- G128: the four-stage gather pass of N = 2 * 4^L' points (fft_big_core.h; device side pw_g128_tile / pw_ovsave32k_mid_tile) ----------
+namespace {
+struct GLane { float2 a[2][4][8], b[2][4][2][4]; };
+std::vector<float2> g_table(const std::vector<float2> &tw, unsigned N)
+{
+    std::vector<float2> T(PW_G_TABLE);
+    for (int i = 0; i < PW_G_TABLE; ++i) pw_g_table_entry(tw.data(), N, i, T[i]);
+    return T;
+}
+template <bool INV> void g128_stages(std::vector<GLane> &L, const float2 *Tg, std::vector<float4> &img)
+{
+    for (int lane = 0; lane < 64; ++lane) { pw_g_inlane<INV>(L[lane].a[0], Tg); pw_g_inlane<INV>(L[lane].a[1], Tg); }
+    for (int lane = 0; lane < 64; ++lane) pw_g_write<0>(L[lane].a, img.data(), lane);
+    for (int lane = 0; lane < 64; ++lane) pw_g_read<0>(L[lane].b, img.data(), lane);
+    for (int lane = 0; lane < 64; ++lane) pw_g_write<1>(L[lane].a, img.data(), lane);
+    for (int lane = 0; lane < 64; ++lane) pw_g_read<1>(L[lane].b, img.data(), lane);
+    for (int lane = 0; lane < 64; ++lane) pw_g_last<INV>(L[lane].b, Tg, lane & 7);
+}
+template <bool INV> void g128_tile(const float2 *in_blk, float2 *out_blk, int lgN, unsigned ctile, const float2 *Tg, std::vector<float4> &img)
+{
+    const long S = 1l << (lgN - 7);
+    const int nd = (lgN - 7) / 2;
+    std::vector<GLane> L(64);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int cp = lane & 15, q = lane >> 4;
+        for (int d2 = 0; d2 < 4; ++d2)
+            for (int jb = 0; jb < 8; ++jb) {
+                const float2 *p = in_blk + 32 * ctile + pw_g_ld(S, 0, 0, d2, jb) + pw_g_ld(S, q, cp, 0, 0);
+                L[lane].a[0][d2][jb] = p[0]; L[lane].a[1][d2][jb] = p[1];
+            }
+    }
+    g128_stages<INV>(L, Tg, img);
+    unsigned hc = 0;
+    for (int d = 0, cc = (int)(ctile >> 1); d < nd - 3; ++d, cc >>= 2) hc = (hc << 2) | (cc & 3);
+    float2 *dst = out_blk + 128l * (((long)(2 * (ctile & 1))) * (1l << (2 * (nd - 3))) + hc);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int kp = lane & 7, cg = lane >> 3;
+        for (int r = 0; r < 2; ++r)
+            for (int x = 0; x < 4; ++x)
+                for (int d3 = 0; d3 < 4; ++d3) {
+                    float2 *p = dst + pw_g_st(nd, 0, 0, x, r, d3) + pw_g_st(nd, cg, kp, 0, 0, 0);
+                    p[0] = L[lane].b[r][x][0][d3]; p[1] = L[lane].b[r][x][1][d3];
+                }
+    }
+}
+} // namespace
+
+// N = 2^lgN (odd lgN >= 15): G128 through the pair program's maps, then the remaining radix-4 stages with the generic in-place stage
+// (lgN = 15: through the pair program's four-stage in-place pass on rows 128 apart instead, as the plan runs it)
+extern "C" int emu_pair_g128_fft(int lgN, const float2 *in, float2 *out, int inverse)
+{
+    const unsigned N = 1u << lgN;
+    FftStage st[32];
+    const int ns = fft_plan_stages((int)N, st, 32);
+    if (ns < 5 || st[ns - 1].p != 2) return -1;
+    std::vector<float2> tw = make_tw((int)N, inverse), Tg = g_table(tw, N);
+    std::vector<float4> img(PW_G_UNITS);
+    for (unsigned ct = 0; ct < (N >> 12); ++ct) {
+        if (inverse) g128_tile<true>(in, out, lgN, ct, Tg.data(), img);
+        else g128_tile<false>(in, out, lgN, ct, Tg.data(), img);
+    }
+    if (lgN == 15) {
+        std::vector<float2> Tm = pair_ordered_table(tw, 128u, 4, N);
+        std::vector<float4> img2(PW_UNITS);
+        for (unsigned c = 0; c < 8; ++c) {
+            if (inverse) pair_mid_tile<true>(out + 16 * c, 128l, 16 * c, Tm.data(), img2);
+            else pair_mid_tile<false>(out + 16 * c, 128l, 16 * c, Tm.data(), img2);
+        }
+        return ns;
+    }
+    for (int s = ns - 5; s >= 0; --s)
+        for (unsigned b = 0; b < N / 4; ++b) {
+            if (inverse) fft_stage_butterfly<true>(out, tw.data(), st[s], (int)b);
+            else fft_stage_butterfly<false>(out, tw.data(), st[s], (int)b);
+        }
+    return ns;
+}
+
+// one 32768-point overlap-save block through the three passes of the plan: G128 forward; [in-place forward pass x conj H x inverse G128] per tile;
+// inverse in-place pass with the masked, scaled store
+extern "C" void emu_pair_ovsave32k(const float2 *x, const float2 *Hc, float2 *out, long hop)
+{
+    const unsigned N = 32768;
+    std::vector<float2> twf = make_tw((int)N, 0), twi = make_tw((int)N, 1);
+    std::vector<float2> Tgf = g_table(twf, N), Tgi = g_table(twi, N), Tf = pair_ordered_table(twf, 128u, 4, N), Ti = pair_ordered_table(twi, 128u, 4, N);
+    std::vector<float4> img(PW_G_UNITS);
+    std::vector<float2> A(N), B(N);
+    for (unsigned ct = 0; ct < 8; ++ct) g128_tile<false>(x, A.data(), 15, ct, Tgf.data(), img);
+    for (int c = 0; c < 8; ++c) { // pw_ovsave32k_mid_tile
+        std::vector<PairLane> F(64);
+        std::vector<GLane> L(64);
+        pair_mid_stages<false>(F, A.data() + 16 * c, 128l, (unsigned)(16 * c), Tf.data(), img);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int cp = lane & 7, q = lane >> 3;
+            for (int xx = 0; xx < 2; ++xx)
+                for (int j = 0; j < 16; ++j) {
+                    const float2 *h = Hc + 16 * c + pw_mid_st(128l, 0, 0, xx, j) + pw_mid_st(128l, q, cp, 0, 0);
+                    const int d2 = xx + 2 * (j & 1), jb = (j >> 3) + 2 * ((j >> 1) & 3);
+                    L[lane].a[0][d2][jb] = cmul_rn(F[lane].b[xx][0][j], h[0]);
+                    L[lane].a[1][d2][jb] = cmul_rn(F[lane].b[xx][1][j], h[1]);
+                }
+        }
+        g128_stages<true>(L, Tgi.data(), img);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int kp = lane & 7, cg = lane >> 3;
+            float2 *dst = B.data() + 128l * (4 * (c & 3) + (c >> 2)) + (128 * (64 * (cg & 3) + 16 * (cg >> 2)) + 2 * kp);
+            for (int r = 0; r < 2; ++r)
+                for (int xx = 0; xx < 4; ++xx)
+                    for (int d3 = 0; d3 < 4; ++d3) {
+                        float2 *p = dst + (128 * (32 * (xx & 1) + 2 * (xx >> 1)) + 32 * d3 + 16 * r);
+                        p[0] = L[lane].b[r][xx][0][d3]; p[1] = L[lane].b[r][xx][1][d3];
+                    }
+        }
+    }
+    const float scale = 1.0f / 32768.0f;
+    std::vector<float4> img2(PW_UNITS);
+    for (int c = 0; c < 8; ++c) { // the inverse in-place pass (pw_mid_tile with vout)
+        std::vector<PairLane> L(64);
+        pair_mid_stages<true>(L, B.data() + 16 * c, 128l, (unsigned)(16 * c), Ti.data(), img2);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int cp = lane & 7, q = lane >> 3;
+            for (int xx = 0; xx < 2; ++xx)
+                for (int j = 0; j < 16; ++j)
+                    for (int e = 0; e < 2; ++e) {
+                        const long pos = 16 * c + pw_mid_st(128l, 0, 0, xx, j) + pw_mid_st(128l, q, cp, 0, 0) + e;
+                        if (pos < hop) out[pos] = make_float2(mul_rn(L[lane].b[xx][e][j].x, scale), mul_rn(L[lane].b[xx][e][j].y, scale));
+                    }
+        }
+    }
+}
+
+extern "C" int emu_pair_g128_bank_conflicts(void)
+{
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int worst = 1;
+    auto tally = [&](const int *lanes, auto unit_of, int acc) {
+        int cnt[16] = {0};
+        for (int t = 0; t < 16; ++t) cnt[unit_of(lanes[t], acc) % 16]++;
+        for (int b = 0; b < 16; ++b) if (cnt[b] > worst) worst = cnt[b];
+    };
+    auto wr = [](int l, int acc) { return pw_unit_g(2 * (l & 15) + (acc >> 3), l >> 4, acc & 7); };           // acc = 8 e + kp
+    auto rd = [](int l, int acc) { return pw_unit_g((l >> 3) + 8 * (acc >> 2), acc & 3, l & 7); };            // acc = 4 x + d3
+    for (int acc = 0; acc < 16; ++acc)
+        for (int half = 0; half < 2; ++half)
+            for (int g = 0; g < 2; ++g) {
+                int lanes[16], seq[16];
+                for (int t = 0; t < 16; ++t) { lanes[t] = grp[g][t] + 32 * half; seq[t] = 16 * (2 * half + g) + t; }
+                tally(lanes, rd, acc);  // ds_read_b128: the documented lane groups
+                tally(lanes, wr, acc);  // ds_write_b128: the same groups ...
+                tally(seq, wr, acc);    // ... and sixteen consecutive lanes
+            }
+    bool seen[PW_G_UNITS] = {false};
+    for (int g = 0; g < 32; ++g)
+        for (int d = 0; d < 4; ++d)
+            for (int k = 0; k < 8; ++k) {
+                const int u = pw_unit_g(g, d, k);
+                if (u < 0 || u >= PW_G_UNITS || seen[u]) return 99;
+                seen[u] = true;
+            }
+    return worst;
+}

@@ -156,3 +156,36 @@ def test_pair_tile_program_overlap_save_block(emu, oracle, k):
 
 def test_pair_lds_images_are_bank_conflict_free(emu):
     assert emu.emu_pair_bank_conflicts() == 1
+
+
+@pytest.mark.parametrize("lgn", [15, 17])
+@pytest.mark.parametrize("inv", [0, 1])
+def test_pair_g128_gather_pass(emu, oracle, lgn, inv):
+    """The four-stage gather pass of N = 2 * 4^L' points (radix-2 stage + three radix-4 stages on 128 rows x 32 columns per wavefront)
+    through its lane maps and LDS image, followed by the plan's in-place pass (2^15) or the remaining generic stages (2^17): kiss_fft."""
+    emu.emu_pair_g128_fft.argtypes = [C.c_int, c64, c64, C.c_int]
+    n = 1 << lgn
+    x = oracle.synth_iq(300 + lgn + inv, 0, n)
+    y = np.empty_like(x)
+    assert emu.emu_pair_g128_fft(lgn, x, y, inv) == len(oracle.kiss_factors(n))
+    assert np.array_equal(bits(y), bits(oracle.fft(x, inverse=bool(inv))))
+
+
+@pytest.mark.parametrize("k", [127, 4097, 4096])
+def test_pair_overlap_save_32768_block(emu, oracle, k):
+    """One 32768-point overlap-save block through the three passes (G128 forward; forward in-place pass x conj H x inverse G128 on one
+    tile; inverse in-place pass with the masked, scaled store): orc_overlap_save, bit for bit."""
+    emu.emu_pair_ovsave32k.argtypes = [c64, c64, c64, C.c_long]
+    n = 32768
+    x = oracle.synth_iq(6, 0, n)
+    h = oracle.lpf_corrected(k, 0.1)
+    hp = np.zeros(n, np.complex64); hp[:k] = h
+    Hc = np.conj(oracle.fft(hp)).astype(np.complex64)
+    hop = n - k + 1
+    out = np.zeros(hop, np.complex64)
+    emu.emu_pair_ovsave32k(x, np.ascontiguousarray(Hc), out, hop)
+    assert np.array_equal(bits(out), bits(oracle.overlap_save(x, h, n)))
+
+
+def test_pair_g128_image_is_bank_conflict_free(emu):
+    assert emu.emu_pair_g128_bank_conflicts() == 1
