@@ -1425,13 +1425,13 @@ __device__ __forceinline__ void fftbig_first_stages(float2 (&a)[4][16], float2 (
 }
 
 // one 256 x 16 tile of the gather pass: block at in_blk (source columns 16c .. 16c + 15) -> working order at out_blk
-template <bool INV>
+template <bool INV, bool MULH = true>
 __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *out_blk, const float2 *__restrict__ tw, int L, unsigned c,
                                                   int lane, float2 *Lw, const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
 {
 #if REDIO_TILE_PAIR
     (void)tw;
-    pw_first_tile<INV>(in_blk, out_blk, L, c, lane, reinterpret_cast<float4 *>(Lw), mulH, T1);
+    pw_first_tile<INV, MULH>(in_blk, out_blk, L, c, lane, reinterpret_cast<float4 *>(Lw), mulH, T1);
     return;
 #endif
     const unsigned N = 1u << (2 * L), S = N >> 8; // S: source row stride
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void fftbig_first_tile(const float2 *in_blk, float2 *
         for (int j = 0; j < 16; ++j) (dst + 256l * (hx * x + rc) + 16 * j)[lo_dst] = b[x][j];
 }
 
-template <bool INV>
+template <bool INV, bool MULH = true> // MULH = false: the pass without the spectrum product (mulH is ignored): no registers kept for that branch
 __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, long in_stride,
                                                            long ntiles, int L, const float2 *__restrict__ mulH = nullptr, const float2 *__restrict__ T1 = nullptr)
 {
@@ -1480,11 +1480,11 @@ __global__ __launch_bounds__(256, 2) void fftbig_first_kernel(const float2 *in, 
     if (tile >= ntiles) return;
     const long xf = tile >> (2 * (L - 6));
     const unsigned c = (unsigned)(tile & ((1u << (2 * (L - 6))) - 1)); // source columns 16c .. 16c + 15
-    fftbig_first_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), tw, L, c, lane, Ls + w * F64W_REGION, mulH, T1);
+    fftbig_first_tile<INV, MULH>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), tw, L, c, lane, Ls + w * F64W_REGION, mulH, T1);
 }
 
 // G128 gather pass (N = 2 * 4^L'; fft_pair.h): one wavefront per tile of 128 source rows x 32 source columns
-template <bool INV>
+template <bool INV, bool MULH = true>
 __global__ __launch_bounds__(256, 2) void fftbig_g128_kernel(const float2 *in, float2 *out, long in_stride, long ntiles, int lgN,
                                                           const float2 *__restrict__ mulH, const float2 *__restrict__ Tg)
 {
@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void fftbig_g128_kernel(const float2 *in, f
     if (tile >= ntiles) return;
     const long xf = tile >> (lgN - 12);
     const unsigned ctile = (unsigned)(tile & ((1u << (lgN - 12)) - 1)); // source columns 32 ctile .. + 31
-    pw_g128_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << lgN), lgN, ctile, lane, Lg + w * PW_G_UNITS, mulH, Tg);
+    pw_g128_tile<INV, MULH>(in + xf * in_stride, out + xf * (long)(1u << lgN), lgN, ctile, lane, Lg + w * PW_G_UNITS, mulH, Tg);
 }
 // overlap-save with 32768-point blocks, middle pass (fft_pair.h): eight tiles of 256 rows x 16 columns per block
 __global__ __launch_bounds__(256, 2) void ovsave32k_mid_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out, const float2 *__restrict__ Tf,
@@ -2212,7 +2212,8 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN) - fftbig_first_elems(lgN)) : nullptr;
     if (fftbig_plan_g(lgN)) { // G128 + one in-place pass on rows 128 apart
         const float2 *Tg = tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN)), *Tm = Tg + PW_G_TABLE;
-        hipLaunchKernelGGL(fftbig_g128_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, in_stride, ntiles, lgN, mulH, Tg);
+        if (mulH) hipLaunchKernelGGL((fftbig_g128_kernel<INV, true>), dim3(grid), dim3(256), 0, s, in, out, in_stride, ntiles, lgN, mulH, Tg);
+        else hipLaunchKernelGGL((fftbig_g128_kernel<INV, false>), dim3(grid), dim3(256), 0, s, in, out, in_stride, ntiles, lgN, mulH, Tg);
         if (lgN == 15) hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, Tm, ntiles, lgN, 7, vout, hop, scale, 1);
         else hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)(nbatch << (lgN - 14))), dim3(256), 0, s, out, Tm, nbatch << (lgN - 14), lgN, 7, vout, hop, scale, 1);
         return hipGetLastError();
@@ -2225,7 +2226,7 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
             const long nt2 = nbatch << (lgN - 11);
             hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN, mulH);
         } else if (pb.first == 4) {
-            hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1);
+            { if (mulH) hipLaunchKernelGGL((fftbig_first_kernel<INV, true>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1); else hipLaunchKernelGGL((fftbig_first_kernel<INV, false>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1); }
         } else {
             hipLaunchKernelGGL(fftbig_first5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, in, out, tw, T1, in_stride, ngroups, lgN / 2, mulH);
         }
@@ -2249,7 +2250,7 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
         const long nt2 = nbatch << (lgN - 11);
         hipLaunchKernelGGL(fftbig_first2_kernel<INV>, dim3((unsigned)((nt2 + 3) / 4)), dim3(256), 0, s, in, out, tw, in_stride, nt2, lgN, mulH);
     } else {
-        hipLaunchKernelGGL(fftbig_first_kernel<INV>, dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1);
+        { if (mulH) hipLaunchKernelGGL((fftbig_first_kernel<INV, true>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1); else hipLaunchKernelGGL((fftbig_first_kernel<INV, false>), dim3(grid), dim3(256), 0, s, in, out, tw, in_stride, ntiles, lgN / 2, mulH, T1); }
     }
     int lm, left;
     fftbig_after_first(lgN, lm, left);
@@ -2282,7 +2283,7 @@ hipError_t launch_ovsave_big(const FftPlanDev &fw, const FftPlanDev &bw, const f
         const float2 *Tgf = fw.tw_pass + goff, *Tgi = bw.tw_pass + goff;
         const long ntiles = nblk << 3;
         const unsigned grid = (unsigned)((ntiles + 3) / 4);
-        hipLaunchKernelGGL(fftbig_g128_kernel<false>, dim3(grid), dim3(256), 0, s, x, a, hop, ntiles, lgN, (const float2 *)nullptr, Tgf);
+        hipLaunchKernelGGL((fftbig_g128_kernel<false, false>), dim3(grid), dim3(256), 0, s, x, a, hop, ntiles, lgN, (const float2 *)nullptr, Tgf);
         hipLaunchKernelGGL(ovsave32k_mid_kernel, dim3(grid), dim3(256), 0, s, a, b, Tgf + PW_G_TABLE, Tgi, Hc, ntiles);
         hipLaunchKernelGGL(fftbig_mid_kernel<true>, dim3(grid), dim3(256), 0, s, b, Tgi + PW_G_TABLE, ntiles, lgN, 7, out, hop, scale, 0);
         return hipGetLastError();
@@ -2313,7 +2314,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_last_first_kernel(const floa
     const long tile = wg * 4 + w;
     if (first) {
         if (tile >= ntiles_first) return;
-        fftbig_first_tile<false>(x_next + (tile >> 4) * hop, a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr, T1);
+        fftbig_first_tile<false, false>(x_next + (tile >> 4) * hop, a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr, T1);
     } else {
         if (tile >= ntiles_last) return;
         ovsave64k_last_tile(b_in + (tile >> 4) * (long)F64K_N, out + (tile >> 4) * hop, Ti, hop, scale, (int)(tile & 15), lane, Lw);
@@ -2362,7 +2363,7 @@ __global__ __launch_bounds__(256, 2) void ovsave64k_step_kernel(Ovs64kStep st, c
         ovsave64k_last_tile(st.b_in + (tile >> 4) * (long)F64K_N, st.out + (tile >> 4) * hop, Ti, hop, scale, (int)(tile & 15), lane, Lw);
     } else {
         if (tile >= st.nt_first) return;
-        fftbig_first_tile<false>(st.x_next + (tile >> 4) * hop, st.a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr, T1);
+        fftbig_first_tile<false, false>(st.x_next + (tile >> 4) * hop, st.a_out + (tile >> 4) * (long)F64K_N, tw_f, 8, (unsigned)(tile & 15), lane, Lw, nullptr, T1);
     }
 }
 
@@ -2376,7 +2377,7 @@ hipError_t launch_ovsave64k(const float2 *x, long hop, float2 *a, float2 *b, con
 #if REDIO_TILE_PAIR // the pair program's middle tile reads the inverse gather pass's twiddles from the INVERSE plan's ordered copy, not from the table
     tw_i = Ti + (fftbig_tables_elems(F64K_N) - fftbig_first_elems(16));
 #endif
-    hipLaunchKernelGGL(fftbig_first_kernel<false>, dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8, nullptr, T1);
+    hipLaunchKernelGGL((fftbig_first_kernel<false, false>), dim3((unsigned)((tiles(0) + 3) / 4)), dim3(256), 0, s, x, a, tw_f, hop, tiles(0), 8, nullptr, T1);
     static const bool fused3 = !measure_env("REDIO_OVS_NO_STEP"); // measurement knob: the two-launch form below
     if (fused3 && doubled) { // a, b hold TWO chunks each
         const long nchunks = (nblk + chunk - 1) / chunk, half = chunk * (long)F64K_N;

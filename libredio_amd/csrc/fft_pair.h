@@ -117,7 +117,7 @@ __device__ __forceinline__ void pw_mid_tile(float2 *base, long m_lo, unsigned l0
 
 // ---- gather pass of a 4^L-point transform: digit-reversed load, stages 0-1, transposed regrouping, stages 2-3, working-order store -----
 // in_blk + 16 c: source columns 16 c .. 16 c + 15; T1: the gather pass's ordered twiddle copy (sub-lengths 1 .. 256)
-template <bool INV>
+template <bool INV, bool MULH = true>
 __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_blk, int L, unsigned c, int lane, float4 *Lw,
                                               const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
 {
@@ -133,7 +133,7 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
             const float4 v = pw_ld_once((src + pw_first_ld(S, 0, 0, i, j)) + lo_src);
             a[i][0][j] = make_float2(v.x, v.y); a[i][1][j] = make_float2(v.z, v.w);
         }
-    if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
+    if (MULH && mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch; MULH = false: a build of the pass without it)
         const float2 *hsrc = mulH + 16 * c;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -190,17 +190,19 @@ __device__ __forceinline__ void pw_ovsave64k_mid_tile(const float2 *__restrict__
     const float2 *hc = Hc + 16 * c;
     const unsigned lo = (unsigned)pw_mid_st(256l, q, cp, 0, 0);
 #pragma unroll
-    for (int x = 0; x < 2; ++x) { // sixteen pairs of spectrum taps as one batch of loads
-        float4 h[16];
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) h[j] = pw_ld((hc + pw_mid_st(256l, 0, 0, x, j)) + lo);
-        RD_SCHED_BARRIER();
+        for (int jh = 0; jh < 16; jh += 8) { // eight pairs of spectrum taps as one batch of loads (sixteen spill: 128 sample registers are live)
+            float4 h[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { // row s + 16 j = digit reversal of 16 rev2(s) + rev2(j)
-            a[x][0][pw_rev2(j)] = cmul_rn(b[x][0][j], make_float2(h[j].x, h[j].y));
-            a[x][1][pw_rev2(j)] = cmul_rn(b[x][1][j], make_float2(h[j].z, h[j].w));
+            for (int j = 0; j < 8; ++j) h[j] = pw_ld((hc + pw_mid_st(256l, 0, 0, x, jh + j)) + lo);
+            RD_SCHED_BARRIER();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { // row s + 16 j = digit reversal of 16 rev2(s) + rev2(j)
+                a[x][0][pw_rev2(jh + j)] = cmul_rn(b[x][0][jh + j], make_float2(h[j].x, h[j].y));
+                a[x][1][pw_rev2(jh + j)] = cmul_rn(b[x][1][jh + j], make_float2(h[j].z, h[j].w));
+            }
         }
-    }
     {
         FftTw15 T0; // the inverse's sub-lengths 1 and 4: wave-uniform
         big_tw15(T0, tw_ordered_stage(T1i, 1u, 0), tw_ordered_stage(T1i, 1u, 1), 0u, 1u, 0u, 1u);
@@ -261,7 +263,7 @@ __device__ __forceinline__ void pw_g128_stages(float2 (&a)[2][4][8], float2 (&b)
     pw_g_last<INV>(b, Tg, lane & 7);
 }
 // in_blk + 32 ctile: source columns 32 ctile .. + 31 (of S = N / 128); out_blk: the working order
-template <bool INV>
+template <bool INV, bool MULH = true>
 __device__ __forceinline__ void pw_g128_tile(const float2 *in_blk, float2 *out_blk, int lgN, unsigned ctile, int lane, float4 *Lw,
                                              const float2 *__restrict__ mulH, const float2 *__restrict__ Tg)
 {
@@ -278,7 +280,7 @@ __device__ __forceinline__ void pw_g128_tile(const float2 *in_blk, float2 *out_b
             const float4 v = pw_ld_once((src + pw_g_ld(S, 0, 0, d2, jb)) + lo_src);
             a[0][d2][jb] = make_float2(v.x, v.y); a[1][d2][jb] = make_float2(v.z, v.w);
         }
-    if (mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
+    if (MULH && mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch)
         const float2 *hsrc = mulH + 32 * ctile;
 #pragma unroll
         for (int d2 = 0; d2 < 4; ++d2) {
@@ -323,18 +325,20 @@ __device__ __forceinline__ void pw_ovsave32k_mid_tile(const float2 *__restrict__
     const float2 *hc = Hc + 16 * c;
     const unsigned lo = (unsigned)pw_mid_st(128l, q, cp, 0, 0);
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        float4 h[16];
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) h[j] = pw_ld((hc + pw_mid_st(128l, 0, 0, x, j)) + lo);
-        RD_SCHED_BARRIER();
+        for (int jh = 0; jh < 16; jh += 8) {
+            float4 h[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { // x + 2 j = d2 + 4 d1 + 16 b0: d2 = x + 2 (j & 1), d1 = (j >> 1) & 3, b0 = j >> 3
-            const int d2 = x + 2 * (j & 1), jb = (j >> 3) + 2 * ((j >> 1) & 3);
-            a[0][d2][jb] = cmul_rn(f[x][0][j], make_float2(h[j].x, h[j].y));
-            a[1][d2][jb] = cmul_rn(f[x][1][j], make_float2(h[j].z, h[j].w));
+            for (int j = 0; j < 8; ++j) h[j] = pw_ld((hc + pw_mid_st(128l, 0, 0, x, jh + j)) + lo);
+            RD_SCHED_BARRIER();
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { // x + 2 j = d2 + 4 d1 + 16 b0: d2 = x + 2 (j & 1), d1 = (j >> 1) & 3, b0 = j >> 3
+                const int j = jh + jj, d2 = x + 2 * (j & 1), jb = (j >> 3) + 2 * ((j >> 1) & 3);
+                a[0][d2][jb] = cmul_rn(f[x][0][j], make_float2(h[jj].x, h[jj].y));
+                a[1][d2][jb] = cmul_rn(f[x][1][j], make_float2(h[jj].z, h[jj].w));
+            }
         }
-    }
     pw_g128_stages<true>(a, b, Tgi, Lw, lane);
     // G128 column gamma = cg + 8 x' is spectrum column' = 16 c + (gamma & 15) + 128 (gamma >> 4), four base-4 digits: gamma & 3, (gamma >> 2) & 3,
     // c & 3, (c >> 2) + 2 (gamma >> 4) -> position 128 h + 32 d3 + kk with h the digits reversed
