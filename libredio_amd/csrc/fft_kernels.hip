@@ -269,23 +269,12 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, TwPtr tw, int tid)
     }
 }
 
+// every stage of the transforms of one workgroup image in LDS (leaf order in, natural order out); ends with a workgroup barrier
 template <int LOG2N, bool INV>
-__global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ Tord,
-                                                     long nbatch, long in_stride)
+__device__ __forceinline__ void fftp2_lds_stages(float2 *Ls, const float2 *__restrict__ tw, const float2 *__restrict__ Tord, int tid)
 {
     using F = FftP2<LOG2N>;
-    constexpr int N = F::N, E = F::E, T = F::T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *Ls = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x;
-    const long b0 = (long)blockIdx.x * T;
-#pragma unroll 4
-    for (int e = tid; e < E; e += 256) {
-        const int xf = e / N, n = e % N;
-        const long b = (b0 + xf < nbatch) ? b0 + xf : nbatch - 1;
-        Ls[F::phys(xf * N + F::leaf_pos(n))] = in[b * in_stride + n];
-    }
-    __syncthreads();
+    constexpr int N = F::N, E = F::E;
     if constexpr (!F::ODD) {
         fftp2_rest<LOG2N, INV, 1>(Ls, tw, tid); // powers of four: stages m = 1, 4, ... straight away
     } else if constexpr (N == 2) {
@@ -315,6 +304,26 @@ __global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *o
         if constexpr (LOG2N == 9) fftp2_rest<LOG2N, INV, 8>(Ls, TwProgram<512, 2>{Tord}, tid); // 512: the stage-ordered copy (+6 %; nothing below)
         else fftp2_rest<LOG2N, INV, 8>(Ls, tw, tid);
     }
+}
+
+template <int LOG2N, bool INV>
+__global__ __launch_bounds__(256) void fft_p2_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ Tord,
+                                                     long nbatch, long in_stride)
+{
+    using F = FftP2<LOG2N>;
+    constexpr int N = F::N, E = F::E, T = F::T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *Ls = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const long b0 = (long)blockIdx.x * T;
+#pragma unroll 4
+    for (int e = tid; e < E; e += 256) {
+        const int xf = e / N, n = e % N;
+        const long b = (b0 + xf < nbatch) ? b0 + xf : nbatch - 1;
+        Ls[F::phys(xf * N + F::leaf_pos(n))] = in[b * in_stride + n];
+    }
+    __syncthreads();
+    fftp2_lds_stages<LOG2N, INV>(Ls, tw, Tord, tid);
 #pragma unroll 4
     for (int e = tid; e < E; e += 256) {
         const int xf = e / N;
@@ -339,6 +348,126 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
     if (inv) hipLaunchKernelGGL(ki, dim3(grid), dim3(256), lds, s, in, out, tw, Tord, nbatch, in_stride);
     else hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, s, in, out, tw, Tord, nbatch, in_stride);
     return hipGetLastError();
+}
+
+// ---- polyphase channelizer with M = 32, 128, 256, 512 or 1024 channels in ONE kernel (round 4): branch filters into the LDS image, then the
+// M-point transform of fft_p2_kernel on the image, then the rows out -- 16 bytes per sample through HBM instead of the 32 of the two-pass
+// form (pfb_api.hip: pfb_branch_kernel + the plan's transform).  v[t][m] = fold_p x[(t + p) M + m] * h[M p + m] (ascending p: dsputils.rs:31),
+// kissfft's M-point forward transform across the branches of each row: the bits of oracle orc_pfb_channelizer.
+// A workgroup iteration is 4096 points.  Up to 256 channels: 16 rows of each of its G = 256 / M row streams, thread (m, g) walks stream g;
+// above: 4096 / M rows of ONE stream, a thread owns M / 256 channels.  A stream is a contiguous range of rows whose P - 1 rows of filter
+// history are carried in registers, so an input row is loaded once (M * 8 contiguous bytes), and the next iteration's rows are requested
+// before this one's arithmetic.
+template <int LOG2M, int P, bool FUSED>
+__global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ x, const float *__restrict__ h, const float2 *__restrict__ tw,
+                                                     const float2 *__restrict__ Tord, float2 *__restrict__ out, long rows, long rps, int ngroups)
+{
+    using F = FftP2<LOG2M>;
+    constexpr int M = F::N, G = M <= 256 ? 256 / M : 1, CPT = M <= 256 ? 1 : M / 256, TR = 16 / CPT, MT = M / CPT; // MT: threads per row
+    static_assert(F::E == 4096 && G * TR * M == 4096 && P >= 2 && P <= 16, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *Ls = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, m = tid % MT, g = tid / MT;
+    const long s0 = (long)blockIdx.x * G;                 // first stream of this workgroup: the one with the most rows
+    const long t0 = (s0 + g) * rps, last_in_row = rows + P - 2;
+    const long rows0 = (s0 * rps + rps < rows ? rps : rows - s0 * rps);
+    const int iters = (int)((rows0 + TR - 1) / TR);       // workgroup-uniform
+    float gt[CPT][P];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int p = 0; p < P; ++p) gt[c][p] = h[M * p + m + 256 * c];
+    const float2 *col = x + m;
+    auto ld = [&](long r, int c) { return col[(long)M * (r < last_in_row ? r : last_in_row) + 256 * c]; }; // rows past the stream's end: clamped (their outputs are never stored)
+    float2 hist[CPT][P - 1], cur[CPT][TR], nx[CPT][TR];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+#pragma unroll
+        for (int p = 0; p < P - 1; ++p) hist[c][p] = ld(t0 + p, c);
+#pragma unroll
+        for (int ti = 0; ti < TR; ++ti) cur[c][ti] = ld(t0 + P - 1 + ti, c);
+    }
+    const int cpg = M / ngroups;
+    for (int it = 0; it < iters; ++it) {
+        const long tb = t0 + (long)TR * it;
+        if (it + 1 < iters) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                for (int ti = 0; ti < TR; ++ti) nx[c][ti] = ld(tb + TR + P - 1 + ti, c);
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int lp = (TR * g) * M + F::leaf_pos(m + 256 * c);
+#pragma unroll
+            for (int ti = 0; ti < TR; ++ti) { // output row tb + ti: input rows tb + ti + p, p = 0 .. P - 1 (the window is [hist | cur])
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc = mac<FUSED>(ti + p < P - 1 ? hist[c][ti + p] : cur[c][ti + p - (P - 1)], gt[c][p], acc);
+                Ls[F::phys(lp + ti * M)] = acc;
+            }
+            float2 hn[P - 1]; // the last P - 1 rows of [hist | cur]
+#pragma unroll
+            for (int p = 0; p < P - 1; ++p) hn[p] = p + TR < P - 1 ? hist[c][p + TR] : cur[c][p + TR - (P - 1)];
+#pragma unroll
+            for (int p = 0; p < P - 1; ++p) hist[c][p] = hn[p];
+        }
+        __syncthreads();
+        fftp2_lds_stages<LOG2M, false>(Ls, tw, Tord, tid);
+#pragma unroll 2
+        for (int e = 2 * tid; e < 4096; e += 512) { // two neighbouring channels per thread: one 16-byte store
+            const int xf = e / M, n = e % M, gg = xf / TR, ti = xf % TR;
+            const long sbase = (s0 + gg) * rps, row = sbase + (long)TR * it + ti, rend = sbase + rps < rows ? sbase + rps : rows;
+            if (row < rend) {
+                const float2 v0 = Ls[F::phys(e)], v1 = Ls[F::phys(e + 1)];
+                if (ngroups == 1) *reinterpret_cast<float4 *>(out + row * M + n) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                else if (cpg >= 2) *reinterpret_cast<float4 *>(out + (long)(n / cpg) * rows * cpg + row * cpg + (n % cpg)) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                else { out[(long)n * rows + row] = v0; out[(long)(n + 1) * rows + row] = v1; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+#pragma unroll
+            for (int ti = 0; ti < TR; ++ti) cur[c][ti] = nx[c][ti];
+    }
+}
+
+bool pfb_p2_supported(int nchan, int taps_per_branch)
+{
+    return (nchan == 32 || nchan == 128 || nchan == 256 || nchan == 512 || nchan == 1024) && (taps_per_branch == 4 || taps_per_branch == 8 || taps_per_branch == 16);
+}
+template <int LOG2M, int P>
+static hipError_t launch_pfb_p2_t(const float2 *x, const float *h, const float2 *tw, const float2 *Tord, float2 *out, long rows, int ngroups, bool fused,
+                                  hipStream_t s)
+{
+    using F = FftP2<LOG2M>;
+    constexpr int G = F::N <= 256 ? 256 / F::N : 1, TR = F::N <= 256 ? 16 : 4096 / F::N;
+    if (LOG2M == 9 && !Tord) return hipErrorInvalidValue;
+    // contiguous row ranges per stream, a multiple of the iteration's rows; about four workgroups per CU; at least 64 rows (the P - 1 row prologue)
+    long streams = 4L * num_cus() * G;
+    long rps = (rows + streams - 1) / streams;
+    rps = ((rps + TR - 1) / TR) * TR;
+    if (rps < 64) rps = 64;
+    const long nstreams = (rows + rps - 1) / rps;
+    const unsigned grid = (unsigned)((nstreams + G - 1) / G);
+    const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
+    if (fused) hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, true>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
+    else hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, false>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
+    return hipGetLastError();
+}
+// out: [row][M] (ngroups == 1) or [group][row][M / ngroups]; tw: the M-entry forward table; Tord: the 512-point plan's stage-ordered copy (512 channels only)
+hipError_t launch_pfb_p2(const float2 *x, const float *h, const float2 *tw, const float2 *Tord, float2 *out, long rows, int nchan, int taps_per_branch,
+                         int ngroups, bool fused, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    if (!pfb_p2_supported(nchan, taps_per_branch) || ngroups < 1 || nchan % ngroups) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return hipErrorNotSupported; // 16-byte stores
+#define REDIO_PFB_P2(L, Q) if (nchan == (1 << L) && taps_per_branch == Q) return launch_pfb_p2_t<L, Q>(x, h, tw, Tord, out, rows, ngroups, fused, s);
+    REDIO_PFB_P2(5, 4) REDIO_PFB_P2(5, 8) REDIO_PFB_P2(5, 16) REDIO_PFB_P2(7, 4) REDIO_PFB_P2(7, 8) REDIO_PFB_P2(7, 16) REDIO_PFB_P2(8, 4) REDIO_PFB_P2(8, 8) REDIO_PFB_P2(8, 16)
+    REDIO_PFB_P2(9, 4) REDIO_PFB_P2(9, 8) REDIO_PFB_P2(9, 16) REDIO_PFB_P2(10, 4) REDIO_PFB_P2(10, 8) REDIO_PFB_P2(10, 16)
+#undef REDIO_PFB_P2
+    return hipErrorNotSupported;
 }
 
 // ---- every 2^a 3^b 5^c size up to 8192 without a kernel of its own (the sizes kiss_fft_next_fast_size returns; see the

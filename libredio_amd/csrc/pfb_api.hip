@@ -12,6 +12,10 @@ hipError_t launch_pfb_u8(const void *bytes, const float *h, const float2 *tw64, 
                          hipStream_t s);
 hipError_t launch_pfb(const float2 *x, const float *h, const float2 *tw64, float2 *out, long rows, int taps_per_branch,
                       int ngroups, bool fused, hipStream_t s);
+// fft_kernels.hip: 32, 128, 256, 512 or 1024 channels with 4, 8 or 16 taps per branch in one kernel (branch filters + the M-point transform in LDS)
+bool pfb_p2_supported(int nchan, int taps_per_branch);
+hipError_t launch_pfb_p2(const float2 *x, const float *h, const float2 *tw, const float2 *Tord, float2 *out, long rows, int nchan, int taps_per_branch,
+                         int ngroups, bool fused, hipStream_t s);
 
 // ---- any channel count / branch length: branch filters, then the plan's M-point transform per row ----------
 // v[t][m] = fold_p x[(t + p) M + m] * h[M p + m] (ascending p, the reference's fold).  The transform of each row is then one batched call of the FFT plan for M points.
@@ -175,6 +179,11 @@ extern "C" int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, vo
     if (ngroups < 1 || h->nchan % ngroups) return REDIO_ERR_ARG;
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_rc(e);
+    if (!h->fused_kernel && pfb_p2_supported(h->nchan, h->taps_per_branch)) { // one kernel for these shapes too (16-byte aligned output)
+        e = launch_pfb_p2((const float2 *)d_in, h->d_h, h->d_tw, redio_fft_twiddles_pass_dev(h->fft), (float2 *)d_out, (long)rows, h->nchan,
+                          h->taps_per_branch, ngroups, (h->flags & REDIO_FIR_FUSED) != 0, (hipStream_t)stream);
+        if (e != hipErrorNotSupported) return hip_rc(e);
+    }
     if (!h->fused_kernel) {
         const size_t total = rows * (size_t)h->nchan;
         hipStream_t st = (hipStream_t)stream;

@@ -37,7 +37,8 @@ def test_channelizer_short_inputs(gpu, redio, oracle):
     assert plan.nrows(64 * 15 + 63) == 0 and plan.nrows(64 * 16) == 1
 
 
-@pytest.mark.parametrize("M,P", [(32, 16), (16, 3), (128, 8), (100, 5), (64, 5), (1024, 4), (7, 2), (1, 1)])
+@pytest.mark.parametrize("M,P", [(32, 16), (16, 3), (128, 8), (100, 5), (64, 5), (1024, 4), (7, 2), (1, 1), (256, 16), (256, 4), (128, 16), (32, 4), (32, 8), (128, 4),
+                                 (256, 8), (512, 8), (128, 5)])
 @pytest.mark.parametrize("fused", [True, False])
 def test_channelizer_any_channel_count(gpu, redio, oracle, M, P, fused):
     # shapes without a fused kernel: branch filters + the M-point transform per row, same bits as the oracle
@@ -53,6 +54,26 @@ def test_channelizer_any_channel_count(gpu, redio, oracle, M, P, fused):
         if M % g == 0:
             grp = plan(d, ngroups=g).cpu().numpy()            # [g][row][M/g]
             assert np.array_equal(bits(grp.transpose(1, 0, 2).reshape(want.shape)), bits(want))
+
+
+@pytest.mark.parametrize("M,P,rows", [(32, 16, 9000 + 5), (128, 8, 5000), (256, 16, 2100 + 7), (128, 4, 64 * 2 * 3), (32, 4, 17), (256, 8, 1), (512, 8, 1300 + 3),
+                                      (1024, 4, 700 + 1), (1024, 16, 130), (512, 16, 5)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_channelizer_one_kernel_shapes_many_rows(gpu, redio, oracle, M, P, rows, fused):
+    """32, 128, 256, 512 and 1024 channels with 4, 8 or 16 taps per branch run as ONE kernel (pfb_p2_kernel: branch filters into the LDS image, the
+    M-point transform on it): several workgroups, several iterations per row stream, a last stream that is shorter than the others and
+    ends inside an iteration, in the natural and the grouped output layout -- the oracle's bits."""
+    h = oracle.synth_f32(11, 0, M * P)
+    x = oracle.synth_iq(0x5EED0004, 7, M * (rows + P - 1) + 5)
+    plan = redio.Channelizer(h, M, P, fused=fused)
+    d = gpu.from_numpy(x).cuda()
+    want = oracle.pfb_channelizer(x, h, M, P, fused)
+    got = plan(d).cpu().numpy()
+    assert got.shape == want.shape == (rows, M)
+    assert np.array_equal(bits(got), bits(want))
+    for g in (8, M):
+        grp = plan(d, ngroups=g).cpu().numpy()                # [g][row][M/g]
+        assert np.array_equal(bits(grp.transpose(1, 0, 2).reshape(want.shape)), bits(want)), g
 
 
 def test_channelizer_tone_lands_in_its_channel(gpu, redio, oracle):

@@ -228,7 +228,7 @@ if "srcgen" in which:
             print(f"resample ratio {ratio:.5f} x{nch} ch, {frames} frames ({name}; epochs periodic/general {per}/{gen}): {best*1e3:.2f} ms  "
                   f"{nch*used/best/1e9:.3f} GS/s in, {best*1e9/(nch*used):.3f} ns per input frame, {out.shape[1]} out per channel")
 if "c4gen" in which:
-    for M, P in ((64, 16), (32, 16), (128, 16), (256, 8), (1024, 4), (64, 12)):
+    for M, P in ((64, 16), (32, 16), (128, 16), (256, 16), (256, 8), (128, 8), (32, 4), (512, 8), (1024, 4), (64, 12)):
         h = R.dsputils.lpf_corrected(M * P, 0.45 / M)
         x = R.synth_iq(0x5EED0004, 0, n)
         plan = R.Channelizer(h, M, P)
