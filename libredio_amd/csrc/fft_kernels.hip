@@ -358,16 +358,21 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
 // above: 4096 / M rows of ONE stream, a thread owns M / 256 channels.  A stream is a contiguous range of rows whose P - 1 rows of filter
 // history are carried in registers, so an input row is loaded once (M * 8 contiguous bytes), and the next iteration's rows are requested
 // before this one's arithmetic.
-template <int LOG2M, int P, bool FUSED>
+// PAIR: a thread owns two NEIGHBOURING channels (2 m, 2 m + 1) and loads them with one 16-byte access (M / 2 threads per row, so more
+// row streams per workgroup and 8 rows per iteration); otherwise one channel per thread (or M / 256 channels, 256 apart), 8-byte loads.
+template <int LOG2M, int P, bool FUSED, bool PAIR>
 __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ x, const float *__restrict__ h, const float2 *__restrict__ tw,
                                                      const float2 *__restrict__ Tord, float2 *__restrict__ out, long rows, long rps, int ngroups)
 {
     using F = FftP2<LOG2M>;
-    constexpr int M = F::N, G = M <= 256 ? 256 / M : 1, CPT = M <= 256 ? 1 : M / 256, TR = 16 / CPT, MT = M / CPT; // MT: threads per row
-    static_assert(F::E == 4096 && G * TR * M == 4096 && P >= 2 && P <= 16, "shape");
+    constexpr int M = F::N;
+    constexpr int NP = PAIR ? (M <= 512 ? 1 : M / 512) : (M <= 256 ? 1 : M / 256); // loads per thread and row
+    constexpr int CPT = PAIR ? 2 * NP : NP, MT = M / CPT, G = 256 / MT, TR = 16 / CPT; // channels per thread, threads per row, streams, rows per iteration
+    static_assert(F::E == 4096 && G * TR * M == 4096 && P >= 2 && P <= 16 && MT <= 256, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *Ls = reinterpret_cast<float2 *>(smem);
     const int tid = threadIdx.x, m = tid % MT, g = tid / MT;
+    auto chan = [&](int c) { return PAIR ? 2 * m + (c & 1) + 512 * (c >> 1) : m + 256 * c; }; // channel of slot c
     const long s0 = (long)blockIdx.x * G;                 // first stream of this workgroup: the one with the most rows
     const long t0 = (s0 + g) * rps, last_in_row = rows + P - 2;
     const long rows0 = (s0 * rps + rps < rows ? rps : rows - s0 * rps);
@@ -376,29 +381,33 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
 #pragma unroll
     for (int c = 0; c < CPT; ++c)
 #pragma unroll
-        for (int p = 0; p < P; ++p) gt[c][p] = h[M * p + m + 256 * c];
-    const float2 *col = x + m;
-    auto ld = [&](long r, int c) { return col[(long)M * (r < last_in_row ? r : last_in_row) + 256 * c]; }; // rows past the stream's end: clamped (their outputs are never stored)
+        for (int p = 0; p < P; ++p) gt[c][p] = h[M * p + chan(c)];
     float2 hist[CPT][P - 1], cur[CPT][TR], nx[CPT][TR];
+    // rows past the stream's end are clamped (their outputs are never stored)
+    auto ld_row = [&](long r, float2 *dst /* [CPT], stride given by `step` */, int step) {
+        const float2 *rowp = x + (long)M * (r < last_in_row ? r : last_in_row);
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
+        for (int q = 0; q < NP; ++q) {
+            if (PAIR) {
+                const float4 v = *reinterpret_cast<const float4 *>(rowp + 2 * m + 512 * q);
+                dst[(2 * q) * step] = make_float2(v.x, v.y); dst[(2 * q + 1) * step] = make_float2(v.z, v.w);
+            } else dst[q * step] = rowp[m + 256 * q];
+        }
+    };
 #pragma unroll
-        for (int p = 0; p < P - 1; ++p) hist[c][p] = ld(t0 + p, c);
+    for (int p = 0; p < P - 1; ++p) ld_row(t0 + p, &hist[0][p], P - 1);
 #pragma unroll
-        for (int ti = 0; ti < TR; ++ti) cur[c][ti] = ld(t0 + P - 1 + ti, c);
-    }
+    for (int ti = 0; ti < TR; ++ti) ld_row(t0 + P - 1 + ti, &cur[0][ti], TR);
     const int cpg = M / ngroups;
     for (int it = 0; it < iters; ++it) {
         const long tb = t0 + (long)TR * it;
         if (it + 1 < iters) {
 #pragma unroll
-            for (int c = 0; c < CPT; ++c)
-#pragma unroll
-                for (int ti = 0; ti < TR; ++ti) nx[c][ti] = ld(tb + TR + P - 1 + ti, c);
+            for (int ti = 0; ti < TR; ++ti) ld_row(tb + TR + P - 1 + ti, &nx[0][ti], TR);
         }
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const int lp = (TR * g) * M + F::leaf_pos(m + 256 * c);
+            const int lp = (TR * g) * M + F::leaf_pos(chan(c));
 #pragma unroll
             for (int ti = 0; ti < TR; ++ti) { // output row tb + ti: input rows tb + ti + p, p = 0 .. P - 1 (the window is [hist | cur])
                 float2 acc = make_float2(0.f, 0.f);
@@ -437,12 +446,12 @@ bool pfb_p2_supported(int nchan, int taps_per_branch)
 {
     return (nchan == 32 || nchan == 128 || nchan == 256 || nchan == 512 || nchan == 1024) && (taps_per_branch == 4 || taps_per_branch == 8 || taps_per_branch == 16);
 }
-template <int LOG2M, int P>
+template <int LOG2M, int P, bool PAIR>
 static hipError_t launch_pfb_p2_t(const float2 *x, const float *h, const float2 *tw, const float2 *Tord, float2 *out, long rows, int ngroups, bool fused,
                                   hipStream_t s)
 {
     using F = FftP2<LOG2M>;
-    constexpr int G = F::N <= 256 ? 256 / F::N : 1, TR = F::N <= 256 ? 16 : 4096 / F::N;
+    constexpr int M = F::N, NP = PAIR ? (M <= 512 ? 1 : M / 512) : (M <= 256 ? 1 : M / 256), CPT = PAIR ? 2 * NP : NP, G = 256 / (M / CPT), TR = 16 / CPT;
     if (LOG2M == 9 && !Tord) return hipErrorInvalidValue;
     // contiguous row ranges per stream, a multiple of the iteration's rows; about four workgroups per CU; at least 64 rows (the P - 1 row prologue)
     long streams = 4L * num_cus() * G;
@@ -452,8 +461,8 @@ static hipError_t launch_pfb_p2_t(const float2 *x, const float *h, const float2 
     const long nstreams = (rows + rps - 1) / rps;
     const unsigned grid = (unsigned)((nstreams + G - 1) / G);
     const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
-    if (fused) hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, true>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
-    else hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, false>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
+    if (fused) hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, true, PAIR>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
+    else hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, false, PAIR>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
     return hipGetLastError();
 }
 // out: [row][M] (ngroups == 1) or [group][row][M / ngroups]; tw: the M-entry forward table; Tord: the 512-point plan's stage-ordered copy (512 channels only)
@@ -463,7 +472,14 @@ hipError_t launch_pfb_p2(const float2 *x, const float *h, const float2 *tw, cons
     if (rows <= 0) return hipSuccess;
     if (!pfb_p2_supported(nchan, taps_per_branch) || ngroups < 1 || nchan % ngroups) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return hipErrorNotSupported; // 16-byte stores
-#define REDIO_PFB_P2(L, Q) if (nchan == (1 << L) && taps_per_branch == Q) return launch_pfb_p2_t<L, Q>(x, h, tw, Tord, out, rows, ngroups, fused, s);
+    // 16-byte row loads (two neighbouring channels per thread, 16-byte aligned input) where a thread owns several channels anyway: 512 channels
+    // 0.993 -> 0.972 ms, 1024 channels 1.031 -> 0.957 ms per 2^28 samples; up to 256 channels the second channel's window costs more registers
+    // than the wider load saves (256 channels, 16 taps: 0.96 -> 1.57 ms), so those keep one channel per thread (profiles/r04_channelizer_pair_loads_ab.txt).
+    // Measurement builds: REDIO_PFB_NO_PAIR forces the 8-byte form, REDIO_PFB_PAIR the 16-byte form
+    const bool pair = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (nchan >= 512 || measure_env("REDIO_PFB_PAIR")) && !measure_env("REDIO_PFB_NO_PAIR");
+#define REDIO_PFB_P2(L, Q)                                                                                                    \
+    if (nchan == (1 << L) && taps_per_branch == Q)                                                                            \
+        return pair ? launch_pfb_p2_t<L, Q, true>(x, h, tw, Tord, out, rows, ngroups, fused, s) : launch_pfb_p2_t<L, Q, false>(x, h, tw, Tord, out, rows, ngroups, fused, s);
     REDIO_PFB_P2(5, 4) REDIO_PFB_P2(5, 8) REDIO_PFB_P2(5, 16) REDIO_PFB_P2(7, 4) REDIO_PFB_P2(7, 8) REDIO_PFB_P2(7, 16) REDIO_PFB_P2(8, 4) REDIO_PFB_P2(8, 8) REDIO_PFB_P2(8, 16)
     REDIO_PFB_P2(9, 4) REDIO_PFB_P2(9, 8) REDIO_PFB_P2(9, 16) REDIO_PFB_P2(10, 4) REDIO_PFB_P2(10, 8) REDIO_PFB_P2(10, 16)
 #undef REDIO_PFB_P2

@@ -76,6 +76,20 @@ def test_channelizer_one_kernel_shapes_many_rows(gpu, redio, oracle, M, P, rows,
         assert np.array_equal(bits(grp.transpose(1, 0, 2).reshape(want.shape)), bits(want)), g
 
 
+@pytest.mark.parametrize("M,P", [(512, 8), (1024, 4), (128, 16)])
+def test_channelizer_one_kernel_shapes_unaligned_input(gpu, redio, oracle, M, P):
+    """512 and 1024 channels load two neighbouring channels per thread with one 16-byte access when the stream is 16-byte aligned; a view
+    that starts on an odd sample (8-byte aligned) takes the 8-byte form of the same kernel: same bits."""
+    h = oracle.synth_f32(12, 0, M * P)
+    x = oracle.synth_iq(0x5EED0004, 3, M * (200 + P - 1) + 1)
+    plan = redio.Channelizer(h, M, P, fused=True)
+    d = gpu.from_numpy(x).cuda()
+    want = oracle.pfb_channelizer(x[1:], h, M, P, True)
+    got = plan(d[1:]).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
+    assert np.array_equal(bits(plan(d).cpu().numpy()), bits(oracle.pfb_channelizer(x, h, M, P, True)))
+
+
 def test_channelizer_tone_lands_in_its_channel(gpu, redio, oracle):
     h = oracle.lpf_corrected(1024, 0.45 / 64)
     k = 11

@@ -170,7 +170,7 @@ if "firshapes" in which:
         plan = R.Fir(taps, d, complex_input=cplx, fused=True)
         x = xc if cplx else xr
         out = torch.empty(plan.nout(m), dtype=x.dtype, device="cuda")
-        ms = timeit(lambda: plan(x, out=out), n=5, warm=2)
+        ms = timeit(lambda: plan(x, out=out), n=40 if k < 1000 else 5, warm=40 if k < 1000 else 2)  # past the clock ramp of a burst (the 2^26-sample launches are 0.1-0.5 ms)
         b = (8 if cplx else 4) * (1 + 1 / d)
         fl = (4 if cplx else 2) * k / d
         # min(HBM, VALU) with the binding one named: the shape's floor is the larger of its HBM time (8 TB/s) and its
