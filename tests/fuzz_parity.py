@@ -37,7 +37,7 @@ while time.time() < t_end:
         check("fir", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, cplx, fused, n, off))
     elif which == 1:    # FFT, any size
         smooth = lambda lim: int(min(2 ** int(rng.integers(0, 15)) * 3 ** int(rng.integers(0, 9)) * 5 ** int(rng.integers(0, 6)), lim))
-        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 21)), 3 * 2 ** int(rng.integers(0, 12)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 8)),
+        n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 21)), 2 ** int(rng.integers(15, 19)), 3 * 2 ** int(rng.integers(0, 12)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 8)),
                             smooth(16384), smooth(16384), int(rng.integers(3000, 70000))]))
         inv = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 70 if n < 4000 else 4))
         x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n * nb)
@@ -65,7 +65,7 @@ while time.time() < t_end:
         want = O.chain_fir_fft(O.data_to_samples(raw[off:]), taps, dd, nfc, fused=fused)
         check("chain_u8", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, nfc, fused, nb, extra, off))
     elif which == 3:    # overlap-save
-        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 8192, 8192, 32768, 65536, 1000, int(rng.integers(2, 12000))]))
+        nfft = int(rng.choice([64, 256, 1024, 4096, 16384, 2048, 8192, 8192, 32768, 32768, 65536, 65536, 131072, 1000, int(rng.integers(2, 12000))]))  # 32768 / 65536: the three-pass tile schemes, 131072: four passes
         k = int(rng.integers(1, nfft + 1)); hop = nfft - k + 1
         n = nfft + int(rng.integers(0, 6)) * hop + int(rng.integers(0, hop))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
@@ -74,13 +74,18 @@ while time.time() < t_end:
         want = O.overlap_save(x, taps, nfft)
         check("ovsave", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nfft, k, n))
     elif which == 4:    # channelizer, any M / P
-        M = int(rng.choice([64, 32, 16, 128, 100, 7, int(rng.integers(1, 300)), int(rng.integers(300, 9000))])); P = int(rng.choice([4, 8, 16, int(rng.integers(1, 20))]))
+        M = int(rng.choice([64, 32, 16, 128, 256, 512, 1024, 100, 7, int(rng.integers(1, 300)), int(rng.integers(300, 9000))])); P = int(rng.choice([4, 8, 16, int(rng.integers(1, 20))]))
         fused = bool(rng.integers(0, 2)); rows = int(rng.integers(0, 200 if M < 300 else 12))
+        if M in (32, 128, 256, 512, 1024) and P in (4, 8, 16): rows = int(rng.integers(0, 3000000 // M))  # the one-kernel shapes (pfb_p2_kernel): several workgroups and iterations, ragged last stream
         h = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, M * P)
         x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, M * (P - 1 + rows) + int(rng.integers(0, M)))
         got = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.pfb_channelizer(x, h, M, P, fused)
         check("pfb", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows))
+        g = int(rng.choice([2, 4, 8, M]))
+        if M % g == 0 and rows > 0:  # the per-destination layout the exchange sends: [group][row][M / g]
+            grp = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda(), ngroups=g).cpu().numpy()
+            check("pfb_grouped", np.array_equal(bits(grp.transpose(1, 0, 2).reshape(want.shape)), bits(want)), (M, P, fused, rows, g))
         off = int(rng.integers(0, 4))   # the same plan from u8 I/Q bytes (redio_pfb_enqueue_u8), any byte alignment
         raw = rng.integers(0, 256, 2 * len(x) + off, dtype=np.uint8)
         got = R.Channelizer(h, M, P, fused=fused).from_bytes(torch.from_numpy(raw).cuda()[off:]).cpu().numpy()
