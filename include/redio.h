@@ -60,6 +60,9 @@ int redio_host_free(void *host);
 int redio_stream_create(void **stream);
 int redio_stream_destroy(void *stream);
 int redio_stream_sync(void *stream); /* NULL = default stream */
+/* writes `value` to the 32-bit word at d_word (device-addressable memory, e.g. the device alias of a redio_host_alloc buffer) when the stream
+ * reaches this point: a host thread polling the word sees the work enqueued before it finished, without hipStreamSynchronize */
+int redio_stream_signal(void *stream, void *d_word, uint32_t value);
 /* Launch graphs for launch-bound pipelines (many small messages): every *_enqueue below only launches
  * kernels on the given stream -- no allocation, no synchronisation -- so a sequence of them can be
  * recorded once between redio_graph_begin/end on a stream created by redio_stream_create and replayed

@@ -70,6 +70,7 @@ def lib():
     _sig(L.redio_stream_create, i, C.POINTER(vp))
     _sig(L.redio_stream_destroy, i, vp)
     _sig(L.redio_stream_sync, i, vp)
+    _sig(L.redio_stream_signal, i, vp, vp, C.c_uint32)
     _sig(L.redio_event_create, i, C.POINTER(vp))
     _sig(L.redio_event_destroy, i, vp)
     _sig(L.redio_event_record, i, vp, vp)

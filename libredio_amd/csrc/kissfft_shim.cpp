@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
 
 struct kiss_fft_state {
     int nfft;
@@ -17,6 +18,10 @@ struct kiss_fft_state {
     kiss_fft_cpx *gather; // host scratch for strided input
     // small transforms: pinned, device-addressable message buffers (zero-copy) instead of two staged copies
     void *pin_in, *pin_in_dev, *pin_out, *pin_out_dev;
+    // completion word in pinned memory, written by the stream behind the kernel (redio_stream_signal): the call polls it instead of
+    // entering hipStreamSynchronize
+    void *flag, *flag_dev;
+    uint32_t seq;
 };
 enum { KISS_ZERO_COPY_MAX = 8192 };
 
@@ -33,7 +38,7 @@ extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, siz
     }
     if (!st) return NULL;
     st->nfft = nfft; st->inverse = inverse_fft; st->plan = NULL; st->d_buf = NULL; st->stream = NULL; st->gather = NULL;
-    st->pin_in = st->pin_in_dev = st->pin_out = st->pin_out_dev = NULL;
+    st->pin_in = st->pin_in_dev = st->pin_out = st->pin_out_dev = NULL; st->flag = st->flag_dev = NULL; st->seq = 0;
     if (nfft <= 0) { if (st->on_heap) free(st); return NULL; }
     int rc = redio_fft_create(&st->plan, nfft, inverse_fft);
     if (rc == REDIO_OK) rc = redio_malloc(&st->d_buf, (size_t)nfft * sizeof(kiss_fft_cpx));
@@ -44,7 +49,9 @@ extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, siz
             redio_host_alloc(&st->pin_out, &st->pin_out_dev, (size_t)nfft * sizeof(kiss_fft_cpx)) != REDIO_OK) {
             redio_host_free(st->pin_in); redio_host_free(st->pin_out);
             st->pin_in = st->pin_in_dev = st->pin_out = st->pin_out_dev = NULL;
-        }
+        } else if (redio_host_alloc(&st->flag, &st->flag_dev, 64) == REDIO_OK) {
+            *(volatile uint32_t *)st->flag = 0;
+        } else st->flag = st->flag_dev = NULL;
     }
     if (rc != REDIO_OK) {
         fprintf(stderr, "kiss_fft_alloc(%d): %s\n", nfft, redio_strerror(rc));
@@ -69,7 +76,16 @@ extern "C" void kiss_fft_stride(kiss_fft_cfg st, const kiss_fft_cpx *fin, kiss_f
     if (st->pin_out) { // the kernel reads and writes the pinned message buffers across PCIe itself
         memcpy(st->pin_in, src, bytes);
         int rc0 = redio_fft_enqueue(st->plan, st->pin_in_dev, st->pin_out_dev, 1, st->stream);
-        if (rc0 == REDIO_OK) rc0 = redio_stream_sync(st->stream);
+        if (rc0 == REDIO_OK) {
+            const uint32_t seq = ++st->seq;
+            volatile uint32_t *word = (volatile uint32_t *)st->flag;
+            if (word && redio_stream_signal(st->stream, st->flag_dev, seq) == REDIO_OK) {
+                long spins = 0; // the word lands a few microseconds after the kernel; bounded, then the ordinary wait
+                while (*word != seq && ++spins < 4000000) __builtin_ia32_pause();
+                if (*word != seq) rc0 = redio_stream_sync(st->stream);
+                else __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            } else rc0 = redio_stream_sync(st->stream);
+        }
         if (rc0 == REDIO_OK) { memcpy(fout, st->pin_out, bytes); return; }
         fprintf(stderr, "kiss_fft: %s\n", redio_strerror(rc0));
         for (int i = 0; i < st->nfft; ++i) fout[i].r = fout[i].i = NAN;
@@ -107,6 +123,7 @@ extern "C" void kiss_fft_free(kiss_fft_cfg st)
     redio_free(st->d_buf);
     redio_host_free(st->pin_in);
     redio_host_free(st->pin_out);
+    redio_host_free(st->flag);
     redio_stream_destroy(st->stream);
     free(st->gather);
     if (st->on_heap) free(st);

@@ -97,6 +97,14 @@ extern "C" int redio_stream_create(void **stream)
 }
 extern "C" int redio_stream_destroy(void *stream) { return stream ? hip_rc(hipStreamDestroy((hipStream_t)stream)) : REDIO_OK; }
 extern "C" int redio_stream_sync(void *stream) { return hip_rc(hipStreamSynchronize((hipStream_t)stream)); }
+// A 32-bit value written to device-addressable memory (e.g. the device alias of a redio_host_alloc buffer) when the stream reaches this
+// point: a host thread that polls the word learns that everything enqueued before has finished without entering hipStreamSynchronize --
+// what the per-message drop-ins (kiss_fft, src_process) wait on.
+extern "C" int redio_stream_signal(void *stream, void *d_word, uint32_t value)
+{
+    if (!d_word) return REDIO_ERR_ARG;
+    return hip_rc(hipStreamWriteValue32((hipStream_t)stream, d_word, value, 0));
+}
 // ---- launch graphs: record the *_enqueue calls of a block pipeline once, replay them with one submission ----
 struct redio_graph {
     hipGraph_t graph;

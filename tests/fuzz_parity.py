@@ -83,7 +83,7 @@ while time.time() < t_end:
         want = O.pfb_channelizer(x, h, M, P, fused)
         check("pfb", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows))
         g = int(rng.choice([2, 4, 8, M]))
-        if M % g == 0 and rows > 0:  # the per-destination layout the exchange sends: [group][row][M / g]
+        if g > 1 and M % g == 0 and rows > 0:  # the per-destination layout the exchange sends: [group][row][M / g]
             grp = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda(), ngroups=g).cpu().numpy()
             check("pfb_grouped", np.array_equal(bits(grp.transpose(1, 0, 2).reshape(want.shape)), bits(want)), (M, P, fused, rows, g))
         off = int(rng.integers(0, 4))   # the same plan from u8 I/Q bytes (redio_pfb_enqueue_u8), any byte alignment
@@ -198,20 +198,25 @@ while time.time() < t_end:
         conv = int(rng.integers(0, 5)); ch = int(rng.choice([1, 1, 2, 3]))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 2.0, 0.25, 1.0884, 48000 / 44100, 1.5, 0.3, float(rng.uniform(0.01, 3.0))]))
         st, ref, ok = samplerate.State(conv, ch), O.Resampler(conv, ch), True
-        nmsg = int(rng.integers(1, 5)); flush = bool(rng.integers(0, 2)); sizes = []
+        nmsg = int(rng.integers(1, 5)); flush = bool(rng.integers(0, 2)); sizes = []; seeds = []; detail = []
         for i in range(nmsg):
             m = int(rng.integers(1, 20000)) if rng.integers(0, 4) else int(rng.integers(1, 6))   # now and then a message of a few frames
-            x = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, m * ch)
+            sd = int(rng.integers(1, 1 << 30)); seeds.append(sd)
+            x = O.synth_f32(sd, 0, m * ch)
             eoi = int(flush and i + 1 == nmsg)                      # the last message may carry end_of_input: the converter drains its tail
             if i and not rng.integers(0, 3):                        # a new ratio now and then: the library glides to it inside the message
                 ratio = float(np.clip(ratio * rng.uniform(0.5, 2.0), 0.01, 3.0))
             cap = int(ratio * m + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
             e1, a, u1 = st.process(x, ratio, cap, eoi)
             e2, b, u2 = ref.process(x, ratio, cap, bool(eoi))
-            ok = ok and (e1, u1, len(a)) == (e2, u2, len(b)) and np.array_equal(bits(a), bits(b))
-            sizes.append(m)
+            same = (e1, u1, len(a)) == (e2, u2, len(b)) and np.array_equal(bits(a), bits(b))
+            if not same:  # everything needed to replay the message sequence: per message (frames, seed, ratio as hex, capacity, eoi), device / oracle (error, used, generated), first differing output
+                nd = np.nonzero(bits(a[: min(len(a), len(b))]) != bits(b[: min(len(a), len(b))]))[0]
+                detail.append((i, (e1, u1, len(a)), (e2, u2, len(b)), int(nd[0]) if len(nd) else -1, len(nd)))
+            ok = ok and same
+            sizes.append((m, sd, float(ratio).hex(), cap, eoi))
         st.close()
-        check("srcdrop", ok, (conv, ch, ratio, sizes, flush))
+        check("srcdrop", ok, (conv, ch, sizes, flush, detail))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 5))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 48000 / 44100, 1.5, 0.3, 4 / 3, 0.75, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
