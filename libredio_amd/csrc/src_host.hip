@@ -79,8 +79,14 @@ struct redio_src {
     // converter state (shared by every channel)
     double last_ratio, last_position;
     int b_current, b_end, b_real_end, b_len;
-    // device mirror of the library's buffer: two images of [nchan][b_len + 1]
-    float *d_buf[2];
+    // device mirror of the library's buffer: two images of [nchan][buf_stride], buf_stride = front + b_len + 1: `front` zero floats that
+    // nothing ever writes sit in front of index 0 of every row (d_buf points at index 0 of row 0; d_buf_base is the allocation).
+    // DEFINED where the published code is not: when the ratio DECREASES between two calls the filter widens while b_current still
+    // sits where the narrower filter left it, and the left wing's data index b_current - coeff_count (and prepare_data's move source
+    // b_current - half) can be negative -- libsamplerate 0.1.8 reads the words in front of its buffer there.  Oracle and device read
+    // +0.0f (silence before the stream); such a call (front_short) runs the per-lane kernel only, whose reads are not clamped.
+    float *d_buf[2], *d_buf_base[2];
+    int front, front_short;
     int cur; // which image is live
     long buf_stride;
     // per-call scratch
@@ -134,8 +140,8 @@ extern "C" int redio_src_reset(redio_src *s)
     s->b_current = s->b_end = 0;
     s->b_real_end = -1;
     s->cur = 0;
-    SRC_TRY(hipMemset(s->d_buf[0], 0, (size_t)s->nchan * s->buf_stride * sizeof(float)));
-    SRC_TRY(hipMemset(s->d_buf[1], 0, (size_t)s->nchan * s->buf_stride * sizeof(float)));
+    SRC_TRY(hipMemset(s->d_buf_base[0], 0, ((size_t)s->front + (size_t)s->nchan * s->buf_stride) * sizeof(float)));
+    SRC_TRY(hipMemset(s->d_buf_base[1], 0, ((size_t)s->front + (size_t)s->nchan * s->buf_stride) * sizeof(float)));
     SRC_TRY(hipStreamSynchronize(nullptr)); // later work runs on non-blocking streams, which do not wait for the default stream
     return REDIO_OK;
 }
@@ -156,7 +162,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     s->device = dev; s->converter = converter; s->nchan = nchan;
     s->d_last = nullptr; s->zl_reset = 1; s->d_rows_in = s->d_rows_out = nullptr; s->rows_in_cap = s->rows_out_cap = 0;
     s->coeff_half_len = half; s->index_inc = inc;
-    s->d_coeffs = nullptr; s->d_buf[0] = s->d_buf[1] = nullptr;
+    s->d_coeffs = nullptr; s->d_buf[0] = s->d_buf[1] = s->d_buf_base[0] = s->d_buf_base[1] = nullptr; s->front = 0; s->front_short = 0;
     s->d_pos = s->d_start = s->d_inc = nullptr; s->d_scale = nullptr; s->d_cap = 0;
     s->d_stage_in = s->d_stage_out = nullptr; s->stage_in_cap = s->stage_out_cap = 0; s->host_stream = nullptr;
     s->fast_inc = 0; s->d_cl = s->d_cr = s->d_tabs = nullptr; s->ncl = s->ncr = 0;
@@ -177,11 +183,15 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
     long bl = lrint(2.5 * half / (inc * 1.0) * SRC_MAX_RATIO);
     if (bl < 4096) bl = 4096;
     s->b_len = (int)bl;
-    s->buf_stride = (long)s->b_len + 1;
+    s->front = (int)lrint((half + 2.0) / inc * SRC_MAX_RATIO) + 64; // the widest filter's reach (oracle/oracle_src.c: the same figure)
+    s->front = (s->front + 3) & ~3;                                 // rows keep their 16-byte alignment
+    s->buf_stride = (((long)s->b_len + 1 + 3) & ~3l) + s->front;
     hipError_t e = hipMalloc((void **)&s->d_coeffs, coeffs.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(s->d_coeffs, coeffs.data(), coeffs.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_buf[0], (size_t)nchan * s->buf_stride * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_buf[1], (size_t)nchan * s->buf_stride * sizeof(float));
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc((void **)&s->d_buf_base[i], ((size_t)s->front + (size_t)nchan * s->buf_stride) * sizeof(float));
+        if (e == hipSuccess) s->d_buf[i] = s->d_buf_base[i] + s->front;
+    }
     if (e != hipSuccess) { redio_src_destroy(s); return hip_rc(e); }
     int rc = redio_src_reset(s);
     if (rc) { redio_src_destroy(s); return rc; }
@@ -192,7 +202,7 @@ extern "C" int redio_src_create(redio_src **h, int converter, int nchan)
 extern "C" int redio_src_destroy(redio_src *s)
 {
     if (!s) return REDIO_OK;
-    hipFree(s->d_coeffs); hipFree(s->d_buf[0]); hipFree(s->d_buf[1]);
+    hipFree(s->d_coeffs); hipFree(s->d_buf_base[0]); hipFree(s->d_buf_base[1]);
     hipFree(s->d_pos); hipFree(s->d_start); hipFree(s->d_inc); hipFree(s->d_scale);
     hipFree(s->d_stage_in); hipFree(s->d_stage_out);
     if (s->host_stream) hipStreamDestroy(s->host_stream);
@@ -511,7 +521,7 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
 {
     if (count <= 0) return REDIO_OK;
     // uniform phase? (every start index 0, one increment, positions in arithmetic progression)
-    {
+    if (!f->front_short) { // (front_short: a tap can sit in front of the image -- only the per-lane kernel below reads there unclamped)
         const int inc = f->h_inc[(size_t)first];
         const int S = count > 1 ? f->h_pos[(size_t)first + 1] - f->h_pos[(size_t)first] : 1;
         bool uniform = S >= 1 && S <= 256;
@@ -531,7 +541,7 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
             }
         }
     }
-    if (f->window_ok) { // rational ratios: P sets of coefficients instead of one interpolation per tap
+    if (f->window_ok && !f->front_short) { // rational ratios: P sets of coefficients instead of one interpolation per tap
         const int handled = try_periodic_epoch(f, first, count, d_out, out_stride, st);
         if (handled == 1) return REDIO_OK;
         if (handled != 0) return handled;
@@ -539,7 +549,7 @@ static int flush_epoch(redio_src *f, long first, long count, float *d_out, long 
     ++f->general_launches;
     SRC_TRY(hipMemcpyAsync(f->d_pos + first, f->h_pos + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
     SRC_TRY(hipMemcpyAsync(f->d_start + first, f->h_start + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, st));
-    if (f->window_ok) { // constant increment and scale, positions in order: the LDS-tile form of the general kernel
+    if (f->window_ok && !f->front_short) { // constant increment and scale, positions in order: the LDS-tile form of the general kernel
         const int inc = f->h_inc[(size_t)first];
         const double scale = f->h_scale[(size_t)first];
         bool tile_ok = count >= 64;
@@ -877,7 +887,16 @@ static int src_process_impl(redio_src *f, const SrcInput &in, long input_frames,
     long in_used = 0, out_gen = 0;
     double src_ratio = f->last_ratio;
     if (is_bad_src_ratio(src_ratio)) return REDIO_SRC_ERR_BAD_INTERNAL_STATE;
-    if (f->window_ok) {
+    { // can this call reach in front of the buffer image?  (the ratio fell since the last call: the filter is wider than the history kept)
+        double cnt = (f->coeff_half_len + 2.0) / f->index_inc;
+        const double mr = f->last_ratio < src_ratio_arg ? f->last_ratio : src_ratio_arg;
+        if (mr < 1.0) cnt /= mr;
+        const int half0 = (int)lrint(cnt) + 1;
+        const double ii = f->last_position;
+        const int bc = (f->b_current + (int)lrint(ii - fmod_one(ii))) % f->b_len;
+        f->front_short = (bc != 0 || f->b_end != 0) && bc < half0;
+    }
+    if (f->window_ok && !f->front_short) {
         const int handled = try_uniform_window(f, in, in_count, d_out, out_stride, out_count, src_ratio_arg, end_of_input, in_used_out,
                                                out_gen_out, st);
         if (handled == 1) return REDIO_OK;

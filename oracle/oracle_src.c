@@ -100,6 +100,8 @@ struct orc_src_state {
     int coeff_half_len, index_inc;
     long in_count, in_used, out_count, out_gen;
     int b_current, b_end, b_real_end, b_len;
+    int front;           /* zero floats in front of buffer[0] (never written): see orc_src_new */
+    float *buffer_base;  /* the allocation; buffer = buffer_base + front */
     float *buffer;
     /* channels > 1, sinc: one mono state per channel (the library's multi-channel loops do the same arithmetic per
      * channel on interleaved data; the end-of-input rule follows the mono loop).  Converters 3 / 4: src_zoh.c / src_linear.c. */
@@ -153,7 +155,15 @@ orc_src_state *orc_src_new(int converter_type, int channels, int *error)
     long bl = lrint(2.5 * s->coeff_half_len / (s->index_inc * 1.0) * SRC_MAX_RATIO);
     if (bl < 4096) bl = 4096;
     s->b_len = (int)bl;
-    s->buffer = (float *)calloc((size_t)s->b_len + 1, sizeof(float));
+    /* DEFINED where the published code is not: when the ratio DECREASES between two calls the filter widens (half_filter_chan_len follows
+     * min(last_ratio, src_ratio)) while b_current still sits where the narrower filter left it, so the left wing's data_index =
+     * b_current - coeff_count -- and prepare_data's memmove source b_current - half -- can be NEGATIVE: libsamplerate 0.1.8 then reads the
+     * words in front of buffer[] (the filter struct's own fields).  Here the samples in front of the buffer are +0.0f (silence before the
+     * stream, which is what those positions hold until the first move): the buffer is allocated with half_max zero floats in front of
+     * index 0 that nothing ever writes.  The device images carry the same pad (src_host.hip). */
+    s->front = (int)lrint((s->coeff_half_len + 2.0) / s->index_inc * SRC_MAX_RATIO) + 64;
+    s->buffer_base = (float *)calloc((size_t)s->front + (size_t)s->b_len + 1, sizeof(float));
+    s->buffer = s->buffer_base + s->front;
     orc_src_reset(s);
     return s;
 }
@@ -163,7 +173,7 @@ void orc_src_delete(orc_src_state *s)
     if (!s) return;
     if (s->sub) { for (int c = 0; c < s->channels; ++c) orc_src_delete(s->sub[c]); free(s->sub); }
     free(s->last_value);
-    free(s->buffer);
+    free(s->buffer_base);
     free(s);
 }
 

@@ -447,3 +447,34 @@ def test_linear_converter_three_channels_ratio_glide(gpu, redio, oracle):
                     assert (e1, u1, len(a)) == (e2, u2, len(b)), (conv, ch, sizes, m)
                     assert np.array_equal(bits(a), bits(b)), (conv, ch, sizes, m)
                 st.close()
+
+
+# the message sequence tests/fuzz_parity.py found in round 4 (seed 40426): the ratio falls between two calls, so the filter is wider than the
+# history the library's buffer retains and the left wing reaches IN FRONT of the buffer (libsamplerate 0.1.8 reads the filter struct's own
+# fields there).  Oracle and device define those samples as +0.0f (include/samplerate.h); the call runs the unclamped per-lane kernel.
+RATIO_FALLS = [(1086, 708690820, '0x1.47ae147ae147bp-6', 22), (7842, 861348262, '0x1.e43d5e17e519ap-7', 116), (1103, 139141258, '0x1.e43d5e17e519ap-7', 17),
+               (2719, 811523618, '0x1.ee08c42c7828dp-7', 41)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv", [0, 1, 2])
+def test_ratio_decrease_reaches_in_front_of_the_buffer(gpu, redio, oracle, conv):
+    from libredio_amd import samplerate
+    for mode in ("dropin", redio.Src.EXACT, redio.Src.EPOCHS):
+        st = samplerate.State(conv, 1) if mode == "dropin" else redio.Src(1, conv, mode=mode)
+        ref = oracle.Resampler(conv, 1)
+        total = 0
+        for m, seed, rh, cap in RATIO_FALLS:
+            x = oracle.synth_f32(seed, 0, m); ratio = float.fromhex(rh)
+            e2, want, u2 = ref.process(x, ratio, cap, False)
+            if mode == "dropin":
+                e1, got, u1 = st.process(x, ratio, cap, 0)
+            else:
+                a, u1 = st.process(gpu.from_numpy(x).cuda().view(1, -1), ratio, output_frames=cap, end_of_input=False)
+                e1, got = 0, a.cpu().numpy()[0]
+            assert (e1, u1, len(got)) == (e2, u2, len(want)), (conv, mode)
+            assert np.array_equal(bits(got), bits(want)), (conv, mode, m)
+            assert np.all(np.abs(want) < 4.0)          # samples are in [-1, 1): nothing from in front of the buffer leaks in
+            total += len(want)
+        if conv == 0:
+            assert total > 40                           # the widened best-quality filter did produce outputs in the calls that reach back

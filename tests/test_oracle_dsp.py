@@ -89,3 +89,22 @@ def test_chain_matches_float64(oracle):
     y = np.correlate(x.astype(np.complex128), taps.astype(np.float64), "valid")[::5][: 3 * 1024].reshape(3, 1024)
     ref = np.fft.fft(y, axis=1)
     assert np.linalg.norm(s - ref) / np.linalg.norm(ref) < 2e-6
+
+
+def test_resampler_ratio_decrease_reads_silence_in_front_of_the_buffer(oracle):
+    """libsamplerate 0.1.8 reads in front of its buffer when the ratio falls between two calls (the filter widens beyond the retained
+    history: negative data_index in calc_output_single); the oracle DEFINES those samples as +0.0f.  The sequence the randomised run found
+    (round 4) must be finite, bounded by the input range times the filter gain, and reproducible from a fresh state."""
+    msgs = [(1086, 708690820, '0x1.47ae147ae147bp-6', 22), (7842, 861348262, '0x1.e43d5e17e519ap-7', 116), (1103, 139141258, '0x1.e43d5e17e519ap-7', 17),
+            (2719, 811523618, '0x1.ee08c42c7828dp-7', 41)]
+    runs = []
+    for _ in range(2):
+        ref, outs = oracle.Resampler(0, 1), []
+        for m, seed, rh, cap in msgs:
+            err, y, used = ref.process(oracle.synth_f32(seed, 0, m), float.fromhex(rh), cap, False)
+            assert err == 0 and used == m
+            outs.append(y)
+        y = np.concatenate(outs)
+        assert len(y) == 48 and np.all(np.isfinite(y)) and np.all(np.abs(y) < 4.0)
+        runs.append(y)
+    assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32))
