@@ -2260,11 +2260,22 @@ static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24
 // Plan G (round 4; pair builds): 2^15 and 2^17 points run the FOUR-stage gather pass G128 (fft_big_core.h) and ONE in-place pass on rows
 // 128 apart -- four stages (2^15) or five (2^17) -- instead of the three-stage gather pass plus a five-stage pass / two more passes.
 // Its tables sit at the very end of the plan's tables: the G128 copy (128 entries), then the in-place pass's ordered copy.
-static bool fftbig_plan_g(int lgN) { return REDIO_TILE_PAIR && (lgN == 15 || lgN == 17); }
+static bool fftbig_plan_g(int lgN)
+{
+    if (!REDIO_TILE_PAIR || !(lgN & 1) || lgN < 15 || lgN > 23) return false;
+    if (lgN >= 19 && measure_env("REDIO_FFT_NO_PLAN_G")) return false; // measurement builds: 2^19 / 2^21 / 2^23 through the three-stage gather pass as before
+    return true;
+}
+// after G128 (rows 128 apart): `left` radix-4 stages to go = 4 (2^15: one four-stage pass), 5 (2^17: one five-stage pass), 6 (2^19: four-stage
+// pass + two register-only stages), 7 (2^21: four + three), 8 (2^23: two four-stage passes)
 static size_t fftbig_g_elems(int lgN)
 {
     if (!fftbig_plan_g(lgN)) return 0;
-    return (size_t)PW_G_TABLE + ((size_t)(lgN == 15 ? FFTBIG_MID4_ELEMS : 1023) << 7);
+    const int left = (lgN - 7) / 2;
+    size_t n = (size_t)PW_G_TABLE + ((size_t)(left == 5 ? 1023 : FFTBIG_MID4_ELEMS) << 7);
+    if (left == 7) n += (size_t)15 << (lgN - 6);
+    if (left == 8) n += (size_t)FFTBIG_MID4_ELEMS << 15;
+    return n;
 }
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
@@ -2334,8 +2345,13 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
     }
     if (fftbig_first_elems(lgN)) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(4), dim3(256), 0, s, tw, T, 1u, 5, (unsigned)nfft); T += fftbig_first_elems(lgN); }
     if (fftbig_plan_g(lgN)) {
+        const int left = (lgN - 7) / 2;
         hipLaunchKernelGGL(fftbig_g_table_kernel, dim3(1), dim3(128), 0, s, tw, T, (unsigned)nfft);
-        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T + PW_G_TABLE, 1u << 7, lgN == 15 ? 4 : 5, (unsigned)nfft);
+        T += PW_G_TABLE;
+        hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << 7, left == 5 ? 5 : 4, (unsigned)nfft);
+        T += (size_t)(left == 5 ? 1023 : FFTBIG_MID4_ELEMS) << 7;
+        if (left == 7) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft);
+        if (left == 8) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << 15, 4, (unsigned)nfft);
     }
     return hipGetLastError();
 }
@@ -2355,12 +2371,20 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     int rev = 0; // direction of the pass before (the gather pass walks forward)
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
     const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN) - fftbig_first_elems(lgN)) : nullptr;
-    if (fftbig_plan_g(lgN)) { // G128 + one in-place pass on rows 128 apart
+    if (fftbig_plan_g(lgN)) { // G128, then in-place passes on rows 128 (and 32768) apart
         const float2 *Tg = tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN)), *Tm = Tg + PW_G_TABLE;
+        const int left = (lgN - 7) / 2;
         if (mulH) hipLaunchKernelGGL((fftbig_g128_kernel<INV, true>), dim3(grid), dim3(256), 0, s, in, out, in_stride, ntiles, lgN, mulH, Tg);
         else hipLaunchKernelGGL((fftbig_g128_kernel<INV, false>), dim3(grid), dim3(256), 0, s, in, out, in_stride, ntiles, lgN, mulH, Tg);
-        if (lgN == 15) hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, Tm, ntiles, lgN, 7, vout, hop, scale, 1);
-        else hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)(nbatch << (lgN - 14))), dim3(256), 0, s, out, Tm, nbatch << (lgN - 14), lgN, 7, vout, hop, scale, 1);
+        if (left == 5) {
+            hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)(nbatch << (lgN - 14))), dim3(256), 0, s, out, Tm, nbatch << (lgN - 14), lgN, 7, vout, hop, scale, 1);
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, Tm, ntiles, lgN, 7, left == 4 ? vout : nullptr, hop, scale, 1);
+        const float2 *T2 = Tm + ((size_t)FFTBIG_MID4_ELEMS << 7);
+        if (left == 6) hipLaunchKernelGGL((fftbig_last_kernel<INV, 2>), dim3(grid), dim3(256), 0, s, out, tw, T2, ntiles, lgN, vout, hop, scale, 0);
+        else if (left == 7) hipLaunchKernelGGL((fftbig_last_kernel<INV, 3>), dim3(grid), dim3(256), 0, s, out, tw, T2, ntiles, lgN, vout, hop, scale, 0);
+        else if (left == 8) hipLaunchKernelGGL(fftbig_mid_kernel<INV>, dim3(grid), dim3(256), 0, s, out, T2, ntiles, lgN, 15, vout, hop, scale, 0);
         return hipGetLastError();
     }
     BigPlanB pb;

@@ -158,7 +158,7 @@ def test_pair_lds_images_are_bank_conflict_free(emu):
     assert emu.emu_pair_bank_conflicts() == 1
 
 
-@pytest.mark.parametrize("lgn", [15, 17])
+@pytest.mark.parametrize("lgn", [15, 17, 19])
 @pytest.mark.parametrize("inv", [0, 1])
 def test_pair_g128_gather_pass(emu, oracle, lgn, inv):
     """The four-stage gather pass of N = 2 * 4^L' points (radix-2 stage + three radix-4 stages on 128 rows x 32 columns per wavefront)

@@ -28,7 +28,7 @@ for nfft, k in ((65536, 8193), (65536, 127), (65536, 8192), (32768, 127), (13107
     b = 8 * nfft / (nfft - k + 1) + 8
     print(f"[{tag}] overlap-save N={nfft} K={k}: {ms:.3f} ms  {out.numel()/ms/1e6:.1f} GS/s out  ({b*out.numel()/ms/1e6/8000:.1%} of 8 TB/s)", flush=True)
     del plan, out
-for lg, nn in ((16, 28), (16, 26), (18, 26), (20, 26), (22, 26), (24, 26), (15, 26), (17, 26)):
+for lg, nn in ((16, 28), (16, 26), (18, 26), (20, 26), (22, 26), (24, 26), (15, 26), (17, 26), (19, 26), (21, 26), (23, 26)):
     nfft = 1 << lg
     xx = x[: 1 << nn]
     plan = R.Fft(nfft)
