@@ -2263,7 +2263,10 @@ static bool fftbig_size(int nfft) { return nfft >= (1 << 15) && nfft <= (1 << 24
 static bool fftbig_plan_g(int lgN)
 {
     if (!REDIO_TILE_PAIR || !(lgN & 1) || lgN < 15 || lgN > 23) return false;
-    if (lgN >= 19 && measure_env("REDIO_FFT_NO_PLAN_G")) return false; // measurement builds: 2^19 / 2^21 / 2^23 through the three-stage gather pass as before
+    // per 2^26 points (profiles/r04_plan_g_large_sizes_ab.txt): 2^19 0.661 -> 0.581 ms, 2^23 0.690 -> 0.667 ms; 2^21 (four-stage pass + three
+    // register-only stages) 0.611 -> 0.639 ms: that size keeps the three-stage gather pass and two four-stage passes
+    if (lgN == 21 && !measure_env("REDIO_FFT_PLAN_G_21")) return false;
+    if (lgN >= 19 && measure_env("REDIO_FFT_NO_PLAN_G")) return false; // measurement builds: 2^19 / 2^23 through the three-stage gather pass as before
     return true;
 }
 // after G128 (rows 128 apart): `left` radix-4 stages to go = 4 (2^15: one four-stage pass), 5 (2^17: one five-stage pass), 6 (2^19: four-stage
