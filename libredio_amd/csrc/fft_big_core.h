@@ -350,4 +350,67 @@ RD_HD constexpr long pw_g_st(int nd, int cg, int kp, int x, int r, int d3)
            32 * d3 + 16 * r + 2 * kp;
 }
 
+
+// =============================================================================================================================
+// Fifth stage of the five-stage passes in the pair layout.  A tile of 1024 rows x 16 columns belongs to a workgroup of four wavefronts:
+// wavefront n runs the four-stage pair program on the quarter of the rows that forms one 256-row sub-transform, then the fifth stage
+// combines position r of the four quarters.  The regrouping goes through a workgroup image of 32 KiB (2048 units of 16 bytes) in four
+// rounds; round (x, jh) moves rows j = 8 jh .. 8 jh + 7 of phase B's slot x: wavefront n WRITES its eight units (n, q, jj, cp) -- two
+// neighbouring columns (rows, on the transposed side of the gather pass) of one row each -- and wavefront w READS, for the rows
+// jj = 2 w, 2 w + 1, the four quarters: v[jj'][n][e].  Writer and reader use the same lane -> (cp, q) map, so one swizzle (the q & 1
+// bit picks the half of a 256-byte bank line) keeps both ds_write_b128 and ds_read_b128 conflict-free.  Two images alternate, so a round
+// needs ONE workgroup barrier (between its writes and its reads); image 0 is the union of the four wave-private 8 KiB images of the
+// four-stage program (wavefront n's slice is its own private image: it is written again only after its owner is done with it).
+// =============================================================================================================================
+constexpr int PW_X5_UNITS = 2048;
+RD_HD constexpr int pw_unit_x5(int n, int q, int jj, int cp) { return 16 * (32 * n + 8 * (q >> 1) + jj) + 8 * (q & 1) + cp; }
+template <int X, int JH>
+RD_HD void pw_x5_write(const float2 (&b)[2][2][16], float4 *Xi, int lane, int n)
+{
+    const int cp = lane & 7, q = lane >> 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jj = 0; jj < 8; ++jj) {
+        const int j = 8 * JH + jj;
+        Xi[pw_unit_x5(n, q, jj, cp)] = make_float4(b[X][0][j].x, b[X][0][j].y, b[X][1][j].x, b[X][1][j].y);
+    }
+}
+RD_HD void pw_x5_read(float2 (&v)[2][4][2], const float4 *Xi, int lane, int w)
+{
+    const int cp = lane & 7, q = lane >> 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jp = 0; jp < 2; ++jp)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int n = 0; n < 4; ++n) {
+            const float4 t = Xi[pw_unit_x5(n, q, 2 * w + jp, cp)];
+            v[jp][n][0] = make_float2(t.x, t.y);
+            v[jp][n][1] = make_float2(t.z, t.w);
+        }
+}
+// the stage itself on the lane's four groups: v[jp][.][e] with the twiddles of index k (e = 0) and k + 1 (e = 1), k = k0 + dk jp
+template <bool INV, typename TP>
+RD_HD void pw_x5_stage(float2 (&v)[2][4][2], TP t4, unsigned k0, unsigned dk)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jp = 0; jp < 2; ++jp) {
+        float2 a1, a2, a3, b1, b2, b3;
+        t4.get3x2(k0 + dk * (unsigned)jp, a1, a2, a3, b1, b2, b3);
+        bfly4x2<INV>(v[jp][0][0], v[jp][1][0], v[jp][2][0], v[jp][3][0], a1, a2, a3, v[jp][0][1], v[jp][1][1], v[jp][2][1], v[jp][3][1], b1, b2, b3);
+    }
+}
+// gather pass with five stages (4^L points): source column 16 c + (2 qq + x) of the N / 1024 source columns -> column h (L - 5 digits
+// reversed) of the working array, 1024 positions each: 256 n + (2 sp + e) + 16 j.  Lane part f(qq, sp, 0, 0, 0) + uniform part f(0, 0, x, n, j); the
+// caller adds 1024 * rev(c)
+RD_HD constexpr long pw_first5_st(int L, int qq, int sp, int x, int n, int j)
+{
+    return 1024l * ((long)(2 * (qq & 1) + x) * (1l << (2 * (L - 6))) + (long)(qq >> 1) * (1l << (2 * (L - 7)))) + 256 * n + 16 * j + 2 * sp;
+}
+
 } // namespace redio

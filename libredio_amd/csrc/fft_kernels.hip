@@ -1711,6 +1711,21 @@ template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_mid5_kernel(float2 *data, const float2 *__restrict__ T, long ngroups, int lgN, int lm,
                                                           float2 *__restrict__ vout = nullptr, long hop = 0, float scale = 1.0f, int rev = 0)
 {
+#if REDIO_TILE_PAIR // the pair form (fft_pair.h: pw_mid5_tile): two images of 32 KiB, image 0 = the four wave-private images of the four-stage program
+    __shared__ float4 Lx[2 * PW_X5_UNITS];
+    {
+        const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const long group = f64w_first_tile(rev) >> 2;
+        if (group >= ngroups) return; // whole workgroup
+        const unsigned N = 1u << lgN, m_lo = 1u << lm;
+        const long xf = group >> (lgN - 14);
+        const unsigned gg = (unsigned)(group & ((1u << (lgN - 14)) - 1));
+        const unsigned c = gg & ((m_lo >> 4) - 1), H = gg >> (lm - 4);
+        float2 *tile = data + xf * (long)N + (long)H * 1024 * m_lo + 16 * c;
+        pw_mid5_tile<INV>(tile, (long)m_lo, 16 * c, T, Lx, lane, w, vout ? vout + xf * hop : nullptr, (long)H * 1024 * m_lo + 16 * c, hop, scale);
+        return;
+    }
+#endif
     __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     __shared__ F5Image X;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1774,6 +1789,20 @@ template <bool INV>
 __global__ __launch_bounds__(256, 2) void fftbig_first5_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T1,
                                                             long in_stride, long ngroups, int L, const float2 *__restrict__ mulH = nullptr)
 {
+#if REDIO_TILE_PAIR // the pair form (fft_pair.h: pw_first5_tile)
+    __shared__ float4 Lx[2 * PW_X5_UNITS];
+    {
+        const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const long group = f64w_first_tile() >> 2;
+        if (group >= ngroups) return;
+        const long xf = group >> (2 * (L - 7));
+        const unsigned c = (unsigned)(group & ((1u << (2 * (L - 7))) - 1));
+        (void)tw;
+        if (mulH) pw_first5_tile<INV, true>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), L, c, lane, w, Lx, mulH, T1);
+        else pw_first5_tile<INV, false>(in + xf * in_stride, out + xf * (long)(1u << (2 * L)), L, c, lane, w, Lx, nullptr, T1);
+        return;
+    }
+#endif
     __shared__ __attribute__((aligned(16))) float2 Ls[4 * F64W_REGION];
     __shared__ F5Image X;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -26,6 +26,15 @@ __device__ __forceinline__ float4 pw_ld_once(const float2 *p)
 #endif
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// the same 16 bytes with the default cache policy to a caller-owned (8-byte aligned) address: the valid outputs of the overlap-save sizes whose passes
+// run launch after launch over a chunk (32768, 131072 ...) -- measured: non-temporal stores there 3.18 against 2.74 ms (32768-point blocks) and 3.86
+// against 3.37 (131072), while the 65536-point scheme, whose step launches keep two chunks of intermediates in flight, loses 17 % WITHOUT them
+// (profiles/r04_ovsave_output_store_policy_ab.txt)
+__device__ __forceinline__ void pw_st_out(float2 *p, float2 lo, float2 hi)
+{
+    const pw_v4u v = {lo.x, lo.y, hi.x, hi.y};
+    *reinterpret_cast<pw_v4u *>(p) = v;
+}
 __device__ __forceinline__ void pw_st_once(float2 *p, float2 lo, float2 hi)
 {
     const pw_v4u v = {lo.x, lo.y, hi.x, hi.y};
@@ -109,22 +118,21 @@ __device__ __forceinline__ void pw_mid_tile(float2 *base, long m_lo, unsigned l0
                 const long e = e0 + pw_mid_st(m_lo, 0, 0, x, j) + lo;
                 const float2 v0 = make_float2(mul_rn(b[x][0][j].x, scale), mul_rn(b[x][0][j].y, scale));
                 const float2 v1 = make_float2(mul_rn(b[x][1][j].x, scale), mul_rn(b[x][1][j].y, scale));
-                if (e + 1 < hop) pw_st_once(vout_blk + e, v0, v1);
-                else if (e < hop) big_st_once(vout_blk + e, v0);
+                if (e + 1 < hop) pw_st_out(vout_blk + e, v0, v1);
+                else if (e < hop) vout_blk[e] = v0;
             } else pw_st((base + pw_mid_st(m_lo, 0, 0, x, j)) + lo, b[x][0][j], b[x][1][j]);
         }
 }
 
 // ---- gather pass of a 4^L-point transform: digit-reversed load, stages 0-1, transposed regrouping, stages 2-3, working-order store -----
 // in_blk + 16 c: source columns 16 c .. 16 c + 15; T1: the gather pass's ordered twiddle copy (sub-lengths 1 .. 256)
-template <bool INV, bool MULH = true>
-__device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_blk, int L, unsigned c, int lane, float4 *Lw,
-                                              const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
+// the part up to phase B: src = the tile's source origin (row 0, column 0), S = source row stride, hsrc = the spectrum at the same origin or null
+template <bool INV, bool MULH>
+__device__ __forceinline__ void pw_first_stages(float2 (&b)[2][2][16], const float2 *src, const float2 *__restrict__ hsrc, long S, const float2 *__restrict__ T1,
+                                                float4 *Lw, int lane)
 {
-    const long S = 1l << (2 * L - 8); // source row stride
     const int cp = lane & 7, q = lane >> 3;
-    const float2 *src = in_blk + 16 * c;
-    float2 a[2][2][16], b[2][2][16];
+    float2 a[2][2][16];
     const unsigned lo_src = (unsigned)pw_first_ld(S, q, cp, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -133,8 +141,7 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
             const float4 v = pw_ld_once((src + pw_first_ld(S, 0, 0, i, j)) + lo_src);
             a[i][0][j] = make_float2(v.x, v.y); a[i][1][j] = make_float2(v.z, v.w);
         }
-    if (MULH && mulH) { // overlap-save: the spectrum product on the way in (wave-uniform branch; MULH = false: a build of the pass without it)
-        const float2 *hsrc = mulH + 16 * c;
+    if (MULH && hsrc) { // overlap-save: the spectrum product on the way in (wave-uniform branch; MULH = false: a build of the pass without it)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -160,7 +167,7 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
             for (int e = 0; e < 2; ++e) macro16_apply<INV>(a[i][e], T0);
     }
     pw_exchange_tr<PwGroupsLinear>(a, b, Lw, lane);
-    const int sp = lane & 7, qq = lane >> 3;
+    const int sp = lane & 7;
     {
         FftTw15 T0, Tb; // sub-lengths 16 and 64: index = the row inside the 256-row transform, 2 sp + e (+ 16 u): neighbouring entries
         big_tw15x2(T0, Tb, tw_pair_stage_u(T1, 1u, 2), tw_pair_stage_u(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
@@ -168,6 +175,15 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
 #pragma unroll
         for (int x = 0; x < 2; ++x) { macro16_apply<INV>(b[x][0], T0); macro16_apply<INV>(b[x][1], Tb); }
     }
+}
+template <bool INV, bool MULH = true>
+__device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_blk, int L, unsigned c, int lane, float4 *Lw,
+                                              const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
+{
+    const long S = 1l << (2 * L - 8); // source row stride
+    float2 b[2][2][16];
+    pw_first_stages<INV, MULH>(b, in_blk + 16 * c, mulH ? mulH + 16 * c : nullptr, S, T1, Lw, lane);
+    const int sp = lane & 7, qq = lane >> 3;
     unsigned rc = 0; // digit reversal of c over L - 6 digits
     for (int d = 0, cc = (int)c; d < L - 6; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
     float2 *dst = out_blk + 256l * rc;
@@ -176,6 +192,78 @@ __device__ __forceinline__ void pw_first_tile(const float2 *in_blk, float2 *out_
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int j = 0; j < 16; ++j) pw_st((dst + pw_first_st(L, 0, 0, x, j)) + lo_dst, b[x][0][j], b[x][1][j]);
+}
+
+// ---- fifth stage across the four wavefronts of a workgroup (fft_big_core.h): four rounds, one workgroup barrier each -----------------------
+// X: two images of PW_X5_UNITS; t4: the stage's ordered twiddle copy; k0_of(x, jh): twiddle index of the lane's first row of the round
+// (the second is dk further); store(x, jh, v): v[jp][n][e] = quarter n' = n of row jp after the stage
+template <bool INV, typename TP, typename KFn, typename StFn>
+__device__ __forceinline__ void pw_x5_rounds(const float2 (&b)[2][2][16], float4 *X, int lane, int w, TP t4, unsigned dk, KFn k0_of, StFn store)
+{
+#define REDIO_X5_ROUND(XX, JH)                                                     \
+    {                                                                              \
+        float4 *Xi = X + ((((2 * XX + JH) & 1) != 0) ? PW_X5_UNITS : 0);           \
+        pw_x5_write<XX, JH>(b, Xi, lane, w);                                       \
+        __syncthreads();                                                           \
+        float2 v[2][4][2];                                                         \
+        pw_x5_read(v, Xi, lane, w);                                                \
+        pw_x5_stage<INV>(v, t4, k0_of(XX, JH), dk);                                \
+        store(XX, JH, v);                                                          \
+    }
+    REDIO_X5_ROUND(0, 0) REDIO_X5_ROUND(0, 1) REDIO_X5_ROUND(1, 0) REDIO_X5_ROUND(1, 1)
+#undef REDIO_X5_ROUND
+}
+
+// in-place five-stage pass on rows m_lo apart: tile = origin of the 1024-row x 16-column tile, wavefront w owns rows 256 w .. 256 w + 255
+template <bool INV>
+__device__ __forceinline__ void pw_mid5_tile(float2 *tile, long m_lo, unsigned l0, const float2 *__restrict__ T, float4 *X, int lane, int w,
+                                             float2 *__restrict__ vout_blk, long e0, long hop, float scale)
+{
+    const int cp = lane & 7, q = lane >> 3;
+    float2 b[2][2][16];
+    pw_mid_stages<INV>(b, tile + 256 * m_lo * w, m_lo, l0, T, X + 512 * w, lane);
+    const unsigned ml = (unsigned)m_lo, lo = (unsigned)(m_lo * q + 2 * cp);
+    pw_x5_rounds<INV>(b, X, lane, w, tw_pair_stage(T, ml, 4), 16u * ml,
+        [&](int x, int jh) { return l0 + 2u * cp + ml * (unsigned)(q + 8 * x + 16 * (8 * jh + 2 * w)); },
+        [&](int x, int jh, float2 (&v)[2][4][2]) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const long r = m_lo * (256 * n + 8 * x + 16 * (8 * jh + 2 * w + jp)); // + the lane's m_lo q + 2 cp
+                    if (vout_blk) { // overlap-save: this was the last pass; 1/N and only the hop valid outputs, packed
+                        const long e = e0 + r + lo;
+                        const float2 v0 = make_float2(mul_rn(v[jp][n][0].x, scale), mul_rn(v[jp][n][0].y, scale));
+                        const float2 v1 = make_float2(mul_rn(v[jp][n][1].x, scale), mul_rn(v[jp][n][1].y, scale));
+                        if (e + 1 < hop) pw_st_out(vout_blk + e, v0, v1);
+                        else if (e < hop) vout_blk[e] = v0;
+                    } else pw_st((tile + r) + lo, v[jp][n][0], v[jp][n][1]);
+                }
+        });
+}
+
+// gather pass with five stages (4^L points): the workgroup's tile is 1024 source rows (N / 1024 apart) x 16 source columns; wavefront w
+// runs the 256-row gather program on source rows 4 rho + w (one 256-point sub-transform), then the fifth stage across the wavefronts
+template <bool INV, bool MULH>
+__device__ __forceinline__ void pw_first5_tile(const float2 *in_blk, float2 *out_blk, int L, unsigned c, int lane, int w, float4 *X,
+                                               const float2 *__restrict__ mulH, const float2 *__restrict__ T1)
+{
+    const long S = 1l << (2 * L - 8), S5 = 1l << (2 * L - 10);
+    float2 b[2][2][16];
+    pw_first_stages<INV, MULH>(b, in_blk + 16 * c + S5 * w, mulH ? mulH + 16 * c + S5 * w : nullptr, S, T1, X + 512 * w, lane);
+    const int sp = lane & 7, qq = lane >> 3;
+    unsigned rc = 0; // digit reversal of c over L - 7 digits
+    for (int d = 0, cc = (int)c; d < L - 7; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
+    float2 *dst = out_blk + 1024l * rc;
+    const unsigned lo_dst = (unsigned)pw_first5_st(L, qq, sp, 0, 0, 0);
+    pw_x5_rounds<INV>(b, X, lane, w, tw_pair_stage_u(T1, 1u, 4), 16u,
+        [&](int x, int jh) { (void)x; return (unsigned)(2 * sp + 16 * (8 * jh + 2 * w)); },
+        [&](int x, int jh, float2 (&v)[2][4][2]) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) pw_st((dst + (pw_first5_st(L, 0, 0, x, n, 0) + 16 * (8 * jh + 2 * w + jp))) + lo_dst, v[jp][n][0], v[jp][n][1]);
+        });
 }
 
 // ---- overlap-save, 65536-point blocks: middle pass = forward pass 1, x conj H, inverse pass 0 on the same tile -----------------------------

@@ -792,3 +792,142 @@ extern "C" int emu_pair_g128_bank_conflicts(void)
             }
     return worst;
 }
+
+// ---- the five-stage passes in the pair layout (pw_mid5_tile / pw_first5_tile): four "wavefronts" per tile, the fifth stage across them ----
+namespace {
+template <bool INV, typename TP, typename KFn, typename StFn>
+void pair_x5_rounds(std::vector<PairLane> (&L)[4], std::vector<float4> &X, TP t4, unsigned dk, KFn k0_of, StFn store)
+{
+    auto round = [&](auto wr, int x, int jh) {
+        float4 *Xi = X.data() + ((((2 * x + jh) & 1) != 0) ? PW_X5_UNITS : 0);
+        for (int w = 0; w < 4; ++w)
+            for (int lane = 0; lane < 64; ++lane) wr(L[w][lane].b, Xi, lane, w);
+        for (int w = 0; w < 4; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                float2 v[2][4][2];
+                pw_x5_read(v, Xi, lane, w);
+                pw_x5_stage<INV>(v, t4, k0_of(x, jh, lane, w), dk);
+                store(x, jh, lane, w, v);
+            }
+    };
+    round([](const float2 (&b)[2][2][16], float4 *Xi, int lane, int w) { pw_x5_write<0, 0>(b, Xi, lane, w); }, 0, 0);
+    round([](const float2 (&b)[2][2][16], float4 *Xi, int lane, int w) { pw_x5_write<0, 1>(b, Xi, lane, w); }, 0, 1);
+    round([](const float2 (&b)[2][2][16], float4 *Xi, int lane, int w) { pw_x5_write<1, 0>(b, Xi, lane, w); }, 1, 0);
+    round([](const float2 (&b)[2][2][16], float4 *Xi, int lane, int w) { pw_x5_write<1, 1>(b, Xi, lane, w); }, 1, 1);
+}
+template <bool INV> void pair_mid5_tile(float2 *tile, long m_lo, unsigned l0, const float2 *T, std::vector<float4> &X)
+{
+    std::vector<PairLane> L[4];
+    std::vector<float4> img(PW_UNITS);
+    const unsigned ml = (unsigned)m_lo;
+    for (int w = 0; w < 4; ++w) { L[w].resize(64); pair_mid_stages<INV>(L[w], tile + 256 * m_lo * w, m_lo, l0, T, img); }
+    pair_x5_rounds<INV>(L, X, tw_pair_stage(T, ml, 4), 16u * ml,
+        [&](int x, int jh, int lane, int w) { const int cp = lane & 7, q = lane >> 3; return l0 + 2u * cp + ml * (unsigned)(q + 8 * x + 16 * (8 * jh + 2 * w)); },
+        [&](int x, int jh, int lane, int w, float2 (&v)[2][4][2]) {
+            const int cp = lane & 7, q = lane >> 3;
+            for (int jp = 0; jp < 2; ++jp)
+                for (int n = 0; n < 4; ++n) {
+                    float2 *p = tile + m_lo * (256 * n + 8 * x + 16 * (8 * jh + 2 * w + jp)) + (m_lo * q + 2 * cp);
+                    p[0] = v[jp][n][0]; p[1] = v[jp][n][1];
+                }
+        });
+}
+// pw_first_stages for one "wavefront"
+template <bool INV> void pair_first_stages(std::vector<PairLane> &L, const float2 *src, long S, const float2 *T1, std::vector<float4> &img)
+{
+    for (int lane = 0; lane < 64; ++lane) {
+        const int cp = lane & 7, q = lane >> 3;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 16; ++j) {
+                const float2 *p = src + pw_first_ld(S, 0, 0, i, j) + pw_first_ld(S, q, cp, 0, 0);
+                L[lane].a[i][0][j] = p[0]; L[lane].a[i][1][j] = p[1];
+            }
+        FftTw15 T0;
+        big_tw15(T0, tw_ordered_stage(T1, 1u, 0), tw_ordered_stage(T1, 1u, 1), 0u, 1u, 0u, 1u);
+        for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 2; ++e) macro16_apply<INV>(L[lane].a[i][e], T0);
+    }
+    pair_exchange_tr<PwGroupsLinear>(L, img);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int sp = lane & 7;
+        FftTw15 T0, Tb;
+        big_tw15x2(T0, Tb, tw_pair_stage_u(T1, 1u, 2), tw_pair_stage_u(T1, 1u, 3), 0u, 1u, (unsigned)(2 * sp), 16u);
+        for (int x = 0; x < 2; ++x) { macro16_apply<INV>(L[lane].b[x][0], T0); macro16_apply<INV>(L[lane].b[x][1], Tb); }
+    }
+}
+template <bool INV> void pair_first5_tile(const float2 *in_blk, float2 *out_blk, int Lg, unsigned c, const float2 *T1, std::vector<float4> &X)
+{
+    const long S = 1l << (2 * Lg - 8), S5 = 1l << (2 * Lg - 10);
+    std::vector<PairLane> L[4];
+    std::vector<float4> img(PW_UNITS);
+    for (int w = 0; w < 4; ++w) { L[w].resize(64); pair_first_stages<INV>(L[w], in_blk + 16 * c + S5 * w, S, T1, img); }
+    unsigned rc = 0;
+    for (int d = 0, cc = (int)c; d < Lg - 7; ++d, cc >>= 2) rc = (rc << 2) | (cc & 3);
+    float2 *dst = out_blk + 1024l * rc;
+    pair_x5_rounds<INV>(L, X, tw_pair_stage_u(T1, 1u, 4), 16u,
+        [&](int x, int jh, int lane, int w) { (void)x; return (unsigned)(2 * (lane & 7) + 16 * (8 * jh + 2 * w)); },
+        [&](int x, int jh, int lane, int w, float2 (&v)[2][4][2]) {
+            const int sp = lane & 7, qq = lane >> 3;
+            for (int jp = 0; jp < 2; ++jp)
+                for (int n = 0; n < 4; ++n) {
+                    float2 *p = dst + pw_first5_st(Lg, 0, 0, x, n, 0) + 16 * (8 * jh + 2 * w + jp) + pw_first5_st(Lg, qq, sp, 0, 0, 0);
+                    p[0] = v[jp][n][0]; p[1] = v[jp][n][1];
+                }
+        });
+}
+} // namespace
+
+// 2^18 = four-stage gather pass + five-stage in-place pass; 2^20 = five-stage gather pass + five-stage in-place pass (plan B), all in the pair layout
+extern "C" int emu_pair_fft_five(int lgN, const float2 *in, float2 *out, int inverse)
+{
+    if (lgN != 18 && lgN != 20) return -1;
+    const unsigned N = 1u << lgN;
+    const int Lg = lgN / 2;
+    std::vector<float2> tw = make_tw((int)N, inverse);
+    std::vector<float2> T1 = pair_ordered_table(tw, 1u, 5, N);
+    std::vector<float4> img(PW_UNITS), X(2 * PW_X5_UNITS);
+    int lm;
+    if (lgN == 18) {
+        for (unsigned c = 0; c < (N >> 12); ++c) { if (inverse) pair_first_tile<true>(in, out, Lg, c, T1.data(), img); else pair_first_tile<false>(in, out, Lg, c, T1.data(), img); }
+        lm = 8;
+    } else {
+        for (unsigned c = 0; c < (N >> 14); ++c) { if (inverse) pair_first5_tile<true>(in, out, Lg, c, T1.data(), X); else pair_first5_tile<false>(in, out, Lg, c, T1.data(), X); }
+        lm = 10;
+    }
+    const unsigned m_lo = 1u << lm;
+    std::vector<float2> T = pair_ordered_table(tw, m_lo, 5, N);
+    for (unsigned g = 0; g < (N >> 14); ++g) { // tiles of 1024 rows x 16 columns
+        const unsigned c = g & ((m_lo >> 4) - 1), H = g >> (lm - 4);
+        float2 *tile = out + (long)H * 1024 * m_lo + 16 * c;
+        if (inverse) pair_mid5_tile<true>(tile, (long)m_lo, 16 * c, T.data(), X); else pair_mid5_tile<false>(tile, (long)m_lo, 16 * c, T.data(), X);
+    }
+    return 0;
+}
+
+extern "C" int emu_pair_x5_bank_conflicts(void)
+{
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int worst = 1;
+    for (int n = 0; n < 4; ++n)
+        for (int jj = 0; jj < 8; ++jj)
+            for (int half = 0; half < 2; ++half)
+                for (int g = 0; g < 2; ++g) {
+                    int cnt[16] = {0}, cnt2[16] = {0};
+                    for (int t = 0; t < 16; ++t) {
+                        const int l = grp[g][t] + 32 * half, l2 = 16 * (2 * half + g) + t;
+                        cnt[pw_unit_x5(n, l >> 3, jj, l & 7) % 16]++;
+                        cnt2[pw_unit_x5(n, l2 >> 3, jj, l2 & 7) % 16]++;
+                    }
+                    for (int b = 0; b < 16; ++b) { if (cnt[b] > worst) worst = cnt[b]; if (cnt2[b] > worst) worst = cnt2[b]; }
+                }
+    bool seen[PW_X5_UNITS] = {false};
+    for (int n = 0; n < 4; ++n)
+        for (int q = 0; q < 8; ++q)
+            for (int jj = 0; jj < 8; ++jj)
+                for (int cp = 0; cp < 8; ++cp) {
+                    const int u = pw_unit_x5(n, q, jj, cp);
+                    if (u < 0 || u >= PW_X5_UNITS || seen[u] || (u >> 9) != n) return 99; // slice n = wavefront n's private image
+                    seen[u] = true;
+                }
+    return worst;
+}

@@ -189,3 +189,20 @@ def test_pair_overlap_save_32768_block(emu, oracle, k):
 
 def test_pair_g128_image_is_bank_conflict_free(emu):
     assert emu.emu_pair_g128_bank_conflicts() == 1
+
+
+@pytest.mark.parametrize("lgn", [18, 20])
+@pytest.mark.parametrize("inv", [0, 1])
+def test_pair_five_stage_passes(emu, oracle, lgn, inv):
+    """The five-stage passes in the pair layout (four wavefronts per 1024-row tile, the fifth stage across them through the workgroup
+    image): 2^18 = four-stage gather pass + five-stage in-place pass, 2^20 = five-stage gather pass + five-stage in-place pass; kiss_fft."""
+    emu.emu_pair_fft_five.argtypes = [C.c_int, c64, c64, C.c_int]
+    n = 1 << lgn
+    x = oracle.synth_iq(500 + lgn + inv, 0, n)
+    y = np.empty_like(x)
+    assert emu.emu_pair_fft_five(lgn, x, y, inv) == 0
+    assert np.array_equal(bits(y), bits(oracle.fft(x, inverse=bool(inv))))
+
+
+def test_pair_fifth_stage_image_is_bank_conflict_free(emu):
+    assert emu.emu_pair_x5_bank_conflicts() == 1
