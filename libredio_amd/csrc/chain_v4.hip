@@ -176,7 +176,7 @@ template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg, long dbg_cap = 0)
 {
-    static_assert(WPS == 2, "chain_v4_blocks_per_wave assumes two wavefronts per SIMD");
+    static_assert(WPS == 2 || WPS == 3, "chain_v4_blocks_per_wave assumes two wavefronts per SIMD (three: measurement builds only)");
     using G = FirGeomV<K, D, 4>;
     constexpr int ELEMS = G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS;
     constexpr size_t LDS_NEED = (size_t)ELEMS * sizeof(float2);
@@ -199,6 +199,9 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
 {
     // (three wavefronts per SIMD were measured again in round 3 with the new access policy: the transform's registers spill at
     // 168 per lane, 0.56-0.60 against 0.517 ms)
+#ifdef REDIO_MEASURE // three wavefronts per SIMD without the resident last-stage twiddles (168 registers, 80 bytes of scratch): measured in round 4, see DESIGN.md 5.1
+    if (measure_env("REDIO_CHAIN_WPS3")) return launch_v4_t<127, 5, 3, 8, false, false>(x, taps, tw, out, nblocks, fused, s, dbg, dbg_cap);
+#endif
     return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg, dbg_cap); // last-stage twiddles resident
 }
 
