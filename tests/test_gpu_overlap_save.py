@@ -72,6 +72,24 @@ def test_overlap_save_65536_across_the_chunk_loop(gpu, redio, oracle, k):
     assert gpu.equal(y, y2) and s1 == gpu.view_as_real(y2).view(gpu.int32).sum(dtype=gpu.int64).item()
 
 
+@pytest.mark.parametrize("nfft,k,nblk", [(32768, 127, 256 + 5), (32768, 4097, 257), (131072, 127, 64 + 3), (131072, 16385, 65)])
+def test_overlap_save_big_blocks_across_the_chunk_loop(gpu, redio, oracle, nfft, k, nblk):
+    """32768-point blocks (round 4: three passes -- G128 forward; forward in-place pass x conj H x inverse G128 on one tile; inverse in-place
+    pass) and 131072-point blocks (four passes) over more blocks than one 64 MiB chunk of the work buffers: first block, the blocks on both
+    sides of the chunk seam and the last block against the oracle on their own windows; even and odd hops."""
+    taps = oracle.lpf_corrected(k, 0.06)
+    hop = nfft - k + 1
+    n = nfft + (nblk - 1) * hop + 7
+    x = redio.synth_iq(0x5EED0005, 0, n)
+    plan = redio.OverlapSave(taps, nfft)
+    assert plan.nout(n) == nblk * hop
+    out = plan(x)
+    chunk = (64 << 20) // (nfft * 8)
+    for b in sorted({0, 1, chunk - 1, chunk, chunk + 1, nblk - 1}):
+        want = oracle.overlap_save(oracle.synth_iq(0x5EED0005, b * hop, nfft), taps, nfft)
+        assert np.array_equal(bits(out[b * hop:(b + 1) * hop].cpu().numpy()), bits(want)), (nfft, k, b)
+
+
 @pytest.mark.parametrize("nblk", [1, 2, 127, 128, 129, 255, 256])
 def test_overlap_save_65536_step_launch_edges(gpu, redio, oracle, nblk):
     """The chunk-step launches of the 65536-point scheme (fft_kernels.hip launch_ovsave64k: middle pass of chunk k, last pass of
