@@ -15,6 +15,19 @@ typedef float pw_v4 __attribute__((ext_vector_type(4)));
 typedef float pw_v4u __attribute__((ext_vector_type(4), aligned(8)));
 
 __device__ __forceinline__ float4 pw_ld(const float2 *p) { return *reinterpret_cast<const float4 *>(p); }
+// an intermediate that a pass reads exactly once (the work buffers of the multi-pass schemes): -DREDIO_EXP_PW_NT_MID=1 reads it non-temporally
+#ifndef REDIO_EXP_PW_NT_MID
+#define REDIO_EXP_PW_NT_MID 0
+#endif
+__device__ __forceinline__ float4 pw_ld_mid(const float2 *p)
+{
+#if REDIO_EXP_PW_NT_MID
+    const pw_v4 v = __builtin_nontemporal_load(reinterpret_cast<const pw_v4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
 __device__ __forceinline__ void pw_st(float2 *p, float2 lo, float2 hi) { *reinterpret_cast<float4 *>(p) = make_float4(lo.x, lo.y, hi.x, hi.y); }
 // data touched ONCE by a multi-pass transform (the caller's input / output): non-temporal, like big_ld_once / big_st_once
 __device__ __forceinline__ float4 pw_ld_once(const float2 *p)
@@ -79,7 +92,7 @@ __device__ __forceinline__ void pw_mid_stages(float2 (&b)[2][2][16], const float
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float4 v = pw_ld((base + pw_mid_ld(m_lo, 0, 0, i, j)) + lo);
+            const float4 v = pw_ld_mid((base + pw_mid_ld(m_lo, 0, 0, i, j)) + lo);
             a[i][0][j] = make_float2(v.x, v.y); a[i][1][j] = make_float2(v.z, v.w);
         }
     RD_SCHED_BARRIER();

@@ -85,7 +85,7 @@ def test_overlap_save_big_blocks_across_the_chunk_loop(gpu, redio, oracle, nfft,
     assert plan.nout(n) == nblk * hop
     out = plan(x)
     chunk = (64 << 20) // (nfft * 8)
-    for b in sorted({0, 1, chunk - 1, chunk, chunk + 1, nblk - 1}):
+    for b in sorted(b for b in {0, 1, chunk - 1, chunk, chunk + 1, nblk - 1} if b < nblk):
         want = oracle.overlap_save(oracle.synth_iq(0x5EED0005, b * hop, nfft), taps, nfft)
         assert np.array_equal(bits(out[b * hop:(b + 1) * hop].cpu().numpy()), bits(want)), (nfft, k, b)
 
