@@ -1269,6 +1269,64 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
 // leaves F_q[k], k = 1024 d5 + 256 d4 + 64 d3 + lane, in its registers.  The last kissfft stage (m = 4096) needs the four
 // F_q[k] of one k in one thread: four rounds (d3 = r) through a 32 KiB LDS image, after which thread (wave w, lane) owns
 // k = 1024 w + 256 d4 + 64 r + lane and stores X[k + 4096 rr] (512-byte runs).
+#ifndef REDIO_F16K_LDS_DEAL
+#define REDIO_F16K_LDS_DEAL 1
+#endif
+// Input of the four-wave kernels (16384 = 4 x 4096, 8192 = 4 x 2048 points): wave q transforms x[4 n + q].  Read by wave q itself that
+// is 16 cache lines per 512 useful bytes and wave instruction.  Instead the four waves read the block in 512-byte runs (wave w: samples
+// 256 t + 64 w + lane of each round) and DEAL the samples to their sub-sequences through LDS: sample e = 4 n + q goes to plane q, cell n;
+// wave q then reads its positions lane-contiguous.  Two rounds of half a block; the plane stride is 8 mod 16 cells, so the four planes
+// start 16 banks apart and the 32 lanes of a half-wave (8 cells in each plane) write 64 different banks.  Round 4: 16384 points
+// 52.0 -> 55.5 %, 8192 points 57.8 -> 60.5 % (16384 fed contiguous rows of the wrong samples: 59.3 %); 8192-point overlap-save
+// 1.45 -> 1.43 ms, 16384-point overlap-save 1.63 -> 1.66 ms: kept on the strided reads (profiles/r04_four_wave_deal_loads.txt).
+#ifndef REDIO_OV16K_LDS_DEAL
+#define REDIO_OV16K_LDS_DEAL 0
+#endif
+constexpr int F16K_PS = 2056, F8K_PS = 1032;
+__device__ __forceinline__ void f16k_deal_load(float2 (&a)[4][16], float2 (&b)[4][16], const float2 *blk, float2 *Ls, int w, int lane)
+{
+    const float2 *row = blk + 64 * w;
+#pragma unroll
+    for (int u = 0; u < 64; ++u) b[u >> 4][u & 15] = (row + 8192 * (u >> 5) + 256 * (u & 31))[(unsigned)lane];
+    RD_SCHED_BARRIER();
+    float2 *cellw = Ls + F16K_PS * (lane & 3) + 16 * w + (lane >> 2);
+    const float2 *cellr = Ls + F16K_PS * w + lane;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int t = 0; t < 32; ++t) cellw[64 * t] = b[(32 * r + t) >> 4][(32 * r + t) & 15];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (((j & 3) >> 1) == r) a[i][j] = cellr[1024 * (j & 1) + 256 * (j >> 2) + 64 * i]; // position 1024 (j & 3) + 256 (j >> 2) + 64 i + lane
+        __syncthreads();
+    }
+}
+// the same for 8192 points: a[d2][j] = position 64 (d2 + 4 (j >> 1) + 16 (j & 1)) + lane of the wave's sub-sequence; round = j & 1
+__device__ __forceinline__ void f8k_deal_load(float2 (&a)[4][8], float2 (&b)[2][16], const float2 *blk, float2 *Ls, int w, int lane)
+{
+    const float2 *row = blk + 64 * w;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) b[u >> 4][u & 15] = (row + 4096 * (u >> 4) + 256 * (u & 15))[(unsigned)lane];
+    RD_SCHED_BARRIER();
+    float2 *cellw = Ls + F8K_PS * (lane & 3) + 16 * w + (lane >> 2);
+    const float2 *cellr = Ls + F8K_PS * w + lane;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) cellw[64 * t] = b[r][t];
+        __syncthreads();
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((j & 1) == r) a[d2][j] = cellr[64 * (d2 + 4 * (j >> 1))];
+        __syncthreads();
+    }
+}
+static_assert(4 * F16K_PS <= 4 * F4W_REGION + 4096 && 4 * F8K_PS <= 4 * F4W_REGION, "the four planes of a round fit the kernels' LDS");
 template <bool INV>
 __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, float2 *out, const float2 *__restrict__ tw, const float2 *__restrict__ T, long in_stride)
 {
@@ -1277,11 +1335,14 @@ __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, f
     const float2 *src = in + (long)blockIdx.x * in_stride + w;
     float2 *dst = out + (long)blockIdx.x * 16384;
     float2 a[4][16], b[4][16];
+    if (REDIO_F16K_LDS_DEAL) f16k_deal_load(a, b, in + (long)blockIdx.x * in_stride, Ls, w, lane);
+    else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
-    RD_SCHED_BARRIER();
+            for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
+        RD_SCHED_BARRIER();
+    }
     fft4k_wave_regs<INV>(a, b, TwProgram<4096, 1>{T}, Ls + w * F4W_REGION, lane);
     float2 *X = Ls + 4 * F4W_REGION; // [q][1024]
 #pragma unroll
@@ -1321,11 +1382,15 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
     float2 *dst = out + (long)blockIdx.x * hop;
     float2 *X = Ls, *Y = Ls + 4096, *Lw = Ls + w * F4W_REGION;
     float2 a[4][16], b[4][16];
+    static_assert(4 * F16K_PS <= 4096 + 4 * OV16W_YS, "the dealt planes fit");
+    if (REDIO_OV16K_LDS_DEAL) f16k_deal_load(a, b, x + (long)blockIdx.x * hop, Ls, w, lane); // measured: 1.655 against 1.631 ms (127 taps): not adopted here
+    else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
-    RD_SCHED_BARRIER();
+            for (int j = 0; j < 16; ++j) a[i][j] = (src + 4 * (1024 * (j & 3) + 256 * (j >> 2) + 64 * i))[4u * lane];
+        RD_SCHED_BARRIER();
+    }
     fft4k_wave_regs<false>(a, b, TwProgram<4096, 1>{Tf}, Lw, lane);
     __syncthreads(); // every wave is done with its private image
 #pragma unroll
@@ -1525,11 +1590,14 @@ __global__ __launch_bounds__(256) void fft8k_wave_kernel(const float2 *in, float
     const float2 *src = in + (long)blockIdx.x * in_stride + w;
     float2 *dst = out + (long)blockIdx.x * 8192;
     float2 a[4][8], b[2][16];
+    if (REDIO_F16K_LDS_DEAL) f8k_deal_load(a, b, in + (long)blockIdx.x * in_stride, Ls, w, lane);
+    else {
 #pragma unroll
-    for (int d2 = 0; d2 < 4; ++d2)
+        for (int d2 = 0; d2 < 4; ++d2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
-    RD_SCHED_BARRIER();
+            for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
+        RD_SCHED_BARRIER();
+    }
     fft2k_wave_regs<INV>(a, b, TwProgram<2048, 2>{T}, Ls + w * F4W_REGION, lane);
     float2 *X = Ls;
 #pragma unroll
@@ -2004,11 +2072,14 @@ __global__ __launch_bounds__(256) void ovsave8k_wave_kernel(const float2 *__rest
     float2 *dst = out + (long)blockIdx.x * hop;
     float2 *X = Ls, *Y = Ls + 2048, *Lw = Ls + w * F4W_REGION;
     float2 a[4][8], b[2][16];
+    if (REDIO_F16K_LDS_DEAL) f8k_deal_load(a, b, x + (long)blockIdx.x * hop, Ls, w, lane);
+    else {
 #pragma unroll
-    for (int d2 = 0; d2 < 4; ++d2)
+        for (int d2 = 0; d2 < 4; ++d2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
-    RD_SCHED_BARRIER();
+            for (int j = 0; j < 8; ++j) a[d2][j] = (src + 4 * 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)))[4u * lane];
+        RD_SCHED_BARRIER();
+    }
     fft2k_wave_regs<false>(a, b, TwProgram<2048, 2>{Tf}, Lw, lane);
     const TwOrdered lf = tw_ordered_stage(Tf, 2u, 5);
 #pragma unroll
