@@ -124,7 +124,8 @@ static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw
                                bool fused, hipStream_t s)
 {
     // contiguous row ranges per wave, a multiple of the 16-row tile; aim for >= 8 waves per CU
-    long waves = 8L * 256;
+    long waves = 8L * 256; // 1024 ... 65536 wavefronts measured within 2 % of each other from 2048 up (profiles/r04_channelizer_64_experiments.txt)
+    if (const char *e = measure_env("REDIO_PFB_WAVES")) { const long v = atol(e); if (v >= 1) waves = v; } // measurement only
     long rpw = (rows + waves - 1) / waves;
     rpw = ((rpw + PFB_TILE - 1) / PFB_TILE) * PFB_TILE;
     if (rpw < 4 * PFB_TILE) rpw = 4 * PFB_TILE; // amortise the P-1 row prologue
