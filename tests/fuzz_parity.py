@@ -11,6 +11,33 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 fails, runs = 0, {}
+SPECIALS = np.array([0.0, -0.0, 1e-40, -1e-40, 1.4e-45, 1e-30, -1e-30, 1e30, -1e30, 3e38, -3e38, np.inf, -np.inf, np.nan, 1.0, -1.0, 2.0 ** -126, 2.0 ** 127], np.float32)
+
+
+def spice(x, p=0.12):
+    """with probability p: signed zeros, subnormals, huge and tiny magnitudes (and, half of those times, inf / NaN) over a random share of the words"""
+    if rng.random() >= p or x.size == 0:
+        return x
+    w = x.view(np.float32).reshape(-1)
+    pool = SPECIALS if rng.random() < 0.5 else SPECIALS[np.isfinite(SPECIALS)]
+    k = max(1, int(len(w) * 10.0 ** -rng.uniform(0.3, 4.0)))
+    w[rng.integers(0, len(w), k)] = pool[rng.integers(0, len(pool), k)]
+    runs["spiced"] = runs.get("spiced", 0) + 1
+    return x
+
+
+def same_nan(got, want):
+    """identical bits wherever the oracle's value is not a NaN, a NaN exactly where it has one (payloads differ between x86 and gfx950)"""
+    got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    if got.shape != want.shape:
+        return False
+    g, w = got.view(np.float32).reshape(-1), want.view(np.float32).reshape(-1)
+    wn = np.isnan(w)
+    if not wn.any():
+        return np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    return np.array_equal(np.isnan(g), wn) and np.array_equal(g.view(np.uint32)[~wn], w.view(np.uint32)[~wn])
+
+
 ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]   # e.g. FUZZ_ONLY=5,9: the two resampler branches only
 
 
@@ -30,23 +57,23 @@ while time.time() < t_end:
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
         cplx, fused = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         n = k - 1 + int(rng.integers(0, 30000 if k < 2000 else 3000)); off = int(rng.integers(0, 4))
-        taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
-        x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, n + off)
+        taps = spice(O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k), 0.05)
+        x = spice((O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, n + off))
         got = R.Fir(taps, d, complex_input=cplx, fused=fused)(torch.from_numpy(x).cuda()[off:]).cpu().numpy()
         want = O.fir(x[off:], taps, d, fused)
-        check("fir", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, d, cplx, fused, n, off))
+        check("fir", same_nan(got, want), (k, d, cplx, fused, n, off))
     elif which == 1:    # FFT, any size
         smooth = lambda lim: int(min(2 ** int(rng.integers(0, 15)) * 3 ** int(rng.integers(0, 9)) * 5 ** int(rng.integers(0, 6)), lim))
         n = int(rng.choice([int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 21)), 2 ** int(rng.integers(15, 19)), 3 * 2 ** int(rng.integers(0, 12)), 5 ** int(rng.integers(0, 5)) * 2 ** int(rng.integers(0, 8)),
                             smooth(16384), smooth(16384), int(rng.integers(3000, 70000))]))
         inv = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 70 if n < 4000 else 4))
-        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n * nb)
+        x = spice(O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n * nb))
         d = torch.from_numpy(x).cuda()
         plan = R.Fft(n, inv)
         got = plan(d).cpu().numpy(); want = O.fft(x, n, inv)
-        ok = np.array_equal(bits(got), bits(want))
+        ok = same_nan(got, want)
         plan(d, out=d)
-        ok = ok and np.array_equal(bits(d.cpu().numpy()), bits(want))
+        ok = ok and same_nan(d.cpu().numpy(), want)
         check("fft", ok, (n, inv, nb))
     elif which == 2:    # chain shapes
         k, dd = [(127, 5), (63, 5), (127, 3), (127, 1), (63, 1), (100, 2), (31, 4)][int(rng.integers(0, 7))]
@@ -54,10 +81,10 @@ while time.time() < t_end:
         fused = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 40 if nfc <= 1024 else 6)); extra = int(rng.integers(0, nfc * dd))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
         n = nb * nfc * dd + (k - dd) + extra
-        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n)
+        x = spice(O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n))
         got = R.Chain(taps, dd, nfc, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.chain_fir_fft(x, taps, dd, nfc, fused=fused)
-        check("chain", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (k, dd, nfc, fused, nb, extra))
+        check("chain", same_nan(got, want), (k, dd, nfc, fused, nb, extra))
         # the same plan from the receiver's u8 I/Q bytes (redio_chain_enqueue_u8), any byte alignment
         off = int(rng.integers(0, 4))
         raw = rng.integers(0, 256, 2 * n + off, dtype=np.uint8)
@@ -69,23 +96,23 @@ while time.time() < t_end:
         k = int(rng.integers(1, nfft + 1)); hop = nfft - k + 1
         n = nfft + int(rng.integers(0, 6)) * hop + int(rng.integers(0, hop))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
-        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n)
+        x = spice(O.synth_iq(int(rng.integers(1, 1 << 30)), 0, n))
         got = R.OverlapSave(taps, nfft)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.overlap_save(x, taps, nfft)
-        check("ovsave", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nfft, k, n))
+        check("ovsave", same_nan(got, want), (nfft, k, n))
     elif which == 4:    # channelizer, any M / P
         M = int(rng.choice([64, 32, 16, 128, 256, 512, 1024, 100, 7, int(rng.integers(1, 300)), int(rng.integers(300, 9000))])); P = int(rng.choice([4, 8, 16, int(rng.integers(1, 20))]))
         fused = bool(rng.integers(0, 2)); rows = int(rng.integers(0, 200 if M < 300 else 12))
         if M in (32, 128, 256, 512, 1024) and P in (4, 8, 16): rows = int(rng.integers(0, 3000000 // M))  # the one-kernel shapes (pfb_p2_kernel): several workgroups and iterations, ragged last stream
         h = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, M * P)
-        x = O.synth_iq(int(rng.integers(1, 1 << 30)), 0, M * (P - 1 + rows) + int(rng.integers(0, M)))
+        x = spice(O.synth_iq(int(rng.integers(1, 1 << 30)), 0, M * (P - 1 + rows) + int(rng.integers(0, M))))
         got = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda()).cpu().numpy()
         want = O.pfb_channelizer(x, h, M, P, fused)
-        check("pfb", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows))
+        check("pfb", same_nan(got, want), (M, P, fused, rows))
         g = int(rng.choice([2, 4, 8, M]))
         if g > 1 and M % g == 0 and rows > 0:  # the per-destination layout the exchange sends: [group][row][M / g]
             grp = R.Channelizer(h, M, P, fused=fused)(torch.from_numpy(x).cuda(), ngroups=g).cpu().numpy()
-            check("pfb_grouped", np.array_equal(bits(grp.transpose(1, 0, 2).reshape(want.shape)), bits(want)), (M, P, fused, rows, g))
+            check("pfb_grouped", same_nan(grp.transpose(1, 0, 2).reshape(want.shape), want), (M, P, fused, rows, g))
         off = int(rng.integers(0, 4))   # the same plan from u8 I/Q bytes (redio_pfb_enqueue_u8), any byte alignment
         raw = rng.integers(0, 256, 2 * len(x) + off, dtype=np.uint8)
         got = R.Channelizer(h, M, P, fused=fused).from_bytes(torch.from_numpy(raw).cuda()[off:]).cpu().numpy()
@@ -186,13 +213,13 @@ while time.time() < t_end:
             outs = [st(draw[2 * lo: 2 * hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
             desc = desc + ("u8",)
         else:
-            x = (O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, max(n, 1))[:n]
+            x = spice((O.synth_iq if cplx else O.synth_f32)(int(rng.integers(1, 1 << 30)), 0, max(n, 1))[:n])
             want = one(x) if n else np.zeros(0, x.dtype)
             st = R.Stream(plan)
             dx = torch.from_numpy(x).cuda() if n else torch.zeros(0, dtype=torch.complex64 if cplx else torch.float32, device="cuda")
             outs = [st(dx[lo:hi]).clone() for lo, hi in zip(cuts[:-1], cuts[1:])]
         got = torch.cat(outs).cpu().numpy() if outs else np.zeros(0, x.dtype)
-        check("stream", got.shape == np.asarray(want).reshape(-1).shape and np.array_equal(bits(got), bits(np.asarray(want).reshape(-1))), desc + (n, cuts))
+        check("stream", same_nan(got, np.asarray(want).reshape(-1)), desc + (n, cuts))
     elif which == 9:    # src_process drop-in (host buffers, one state, random messages)
         from libredio_amd import samplerate
         conv = int(rng.integers(0, 5)); ch = int(rng.choice([1, 1, 2, 3]))
