@@ -16,6 +16,12 @@ namespace redio {
 // IN_U8: `x` is the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162); a lane's 8-byte sample load
 // becomes a 2-byte load, converted when the sample enters the register window: 2 + 8 bytes per sample through HBM instead of 8 + 8
 // (+ 2 + 8 for a conversion kernel in front).
+// Prefetch of the next tile's rows: cf32 rows are requested BEFORE the current tile's arithmetic into a second set of registers; u8 rows
+// AFTER the branch filters, into the registers those have just emptied (164 instead of 180+ registers: 0.765 -> 0.726 ms from bytes; the
+// cf32 kernel measured 0.810 -> 0.825 ms that way and keeps the early request; profiles/r04_channelizer_64_experiments.txt)
+#ifndef REDIO_PFB_LATE_PREFETCH
+#define REDIO_PFB_LATE_PREFETCH IN_U8
+#endif
 template <int P, bool FUSED, bool ROWMAJOR, bool IN_U8 = false>
 __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x, const float *__restrict__ h,
                                                     const float2 *__restrict__ tw, float2 *__restrict__ out, long rows,
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     raw_t cur[PFB_TILE], nx[PFB_TILE];
     load_rows(cur, t0 + P - 1);
     for (long tb = t0; tb < t1; tb += PFB_TILE) {
-        if (tb + PFB_TILE < t1) load_rows(nx, tb + PFB_TILE + P - 1);
+        if (!REDIO_PFB_LATE_PREFETCH && tb + PFB_TILE < t1) load_rows(nx, tb + PFB_TILE + P - 1);
         // branch FIRs: lane = branch, strict fold over p (dsputils.rs:31)
 #pragma unroll
         for (int ti = 0; ti < PFB_TILE; ++ti) {
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
             for (int p = 0; p < P; ++p) acc = mac<FUSED>(win[(ti + p) % P], g[p], acc);
             lds[pfb_x1_store(ti, lane)] = acc;
         }
+        if (REDIO_PFB_LATE_PREFETCH && tb + PFB_TILE < t1) load_rows(cur, tb + PFB_TILE + P - 1); // into the registers the branch filters have just emptied
         wave_lds_fence();
         float2 v[16];
 #pragma unroll
@@ -109,8 +116,10 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
                 }
             }
         }
+        if (!REDIO_PFB_LATE_PREFETCH) {
 #pragma unroll
-        for (int ti = 0; ti < PFB_TILE; ++ti) cur[ti] = nx[ti];
+            for (int ti = 0; ti < PFB_TILE; ++ti) cur[ti] = nx[ti];
+        }
     }
 }
 
