@@ -179,7 +179,58 @@ def converter_cases():
     return out
 
 
-CASES = {"converters": converter_cases, "ovsave": ovsave_cases, "front_end": front_end_cases, "pfb_generic": pfb_generic_cases, "fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
+SPECIALS = np.array([0.0, -0.0, 1e-40, -1e-40, 1.4e-45, 1e-30, -1e-30, 1e30, -1e30, 3e38, -3e38, np.inf, -np.inf, np.nan, 1.0, -1.0, 2.0 ** -126, 2.0 ** 127], np.float32)
+
+
+def _canon(a):
+    """every NaN as the canonical quiet NaN: payloads are what x86 and gfx950 disagree on, and nothing defines them"""
+    a = np.array(a, copy=True)
+    w = a.view(np.float32)
+    w[np.isnan(w)] = np.float32(np.nan)
+    return a
+
+
+def _sprinkle(x, seed, count, finite):
+    w = x.view(np.float32).reshape(-1)
+    rng = np.random.default_rng(seed)
+    pool = SPECIALS[np.isfinite(SPECIALS)] if finite else SPECIALS
+    w[rng.integers(0, len(w), count)] = pool[rng.integers(0, len(pool), count)]
+    if not finite:  # one of each for certain, in the last quarter of the stream
+        w[len(w) - len(w) // 8 + 1], w[len(w) - len(w) // 5], w[len(w) - len(w) // 7] = np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan)
+    return x
+
+
+def special_cases():
+    """signed zeros, subnormals, overflowing / underflowing products (`fin`), and infinities / NaNs (`any`) through the arithmetic paths:
+    IEEE-754 decides them the same way on both sides only if no operation is skipped, merged or reordered"""
+    out = {}
+    taps = O.lpf_corrected(127, 0.08)
+    taps[[0, 31, 64, 126]] = np.array([-0.0, 1e30, 1e-40, 0.0], np.float32)
+    out["fir_taps"] = taps
+    for tag, finite, count in (("fin", True, 400), ("any", False, 3)):
+        x = _sprinkle(O.synth_iq(0x5EED0900, 0, 4096), 1, count, finite)
+        out[f"fir_{tag}_x"] = _canon(x)
+        out[f"fir_{tag}_y"] = _canon(O.fir(x, taps, 5, fused=False))
+        out[f"fir_{tag}_y_fused"] = _canon(O.fir(x, taps, 5, fused=True))
+        for n in (16, 64, 1024, 30):
+            xb = _sprinkle(O.synth_iq(0x5EED0901 + n, 0, 3 * n), 2 + n, max(2, (n // 8 if finite else 2)), finite)
+            xb[:n] = 0
+            xb[n:2 * n] = np.complex64(complex(-0.0, -0.0))
+            out[f"fft{n}_{tag}_x"] = _canon(xb)
+            for inv in (0, 1):
+                out[f"fft{n}_{tag}_X{inv}"] = _canon(O.fft(xb, n, inverse=bool(inv)))
+        xc = _sprinkle(O.synth_iq(0x5EED0902, 0, 5120 + 126), 3, 100 if finite else 2, finite)
+        out[f"chain_{tag}_x"] = _canon(xc)
+        out[f"chain_{tag}_spectra"] = _canon(O.chain_fir_fft(xc, O.lpf_corrected(127, 0.08), 5, 1024, fused=True))
+        xr = _sprinkle(O.synth_f32(0x5EED0903, 0, 8000), 4, 80 if finite else 2, finite)
+        err, yr, used = O.Resampler(1).process(xr, 0.02, 161)
+        assert err == 0 and used == 8000
+        out[f"src_{tag}_x"] = _canon(xr)
+        out[f"src_{tag}_y"] = _canon(yr)
+    return out
+
+
+CASES = {"special": special_cases, "converters": converter_cases, "ovsave": ovsave_cases, "front_end": front_end_cases, "pfb_generic": pfb_generic_cases, "fir": fir_cases, "fft": fft_cases, "chain": chain_cases, "resample": resample_cases, "bits": bit_cases, "pfb": pfb_cases}
 
 
 def generate(outdir=HERE):
