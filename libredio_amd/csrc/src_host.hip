@@ -637,9 +637,11 @@ static int try_uniform_window(redio_src *f, const SrcInput &in, long in_count, f
     if (rc) return rc;
     const bool fast = f->mode == REDIO_SRC_FAST;
     if (fast) { rc = prepare_fast_taps(f, S, scale); if (rc) return rc; }
-    // rebuild [b_current - half, b_end) of the final image into the other buffer
+    // rebuild the final image into the other buffer: [b_current - reach, b_end) with `reach` the WIDEST filter's (ratio 1 / 256), not this
+    // call's -- a later call with a lower ratio reads that far back, and the library's buffer holds the true history there
+    // (round 4: rebuilding only this call's half left stale cells a falling ratio then read; tests/fuzz_parity.py seed 60407)
     const int other = f->cur ^ 1;
-    long j0 = (long)b_current - half, j1 = b_end;
+    long j0 = (long)b_current - f->front, j1 = b_end;
     if (j0 < 0) j0 = 0;
     hipError_t e = launch_src_window(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, f->d_cl, f->ncl, f->d_cr, f->ncr,
                                      f->d_T2, f->nm, f->d_Hp, f->fastp_nc, fast, a_first < 0 ? 0 : a_first, S, scale, d_out, out_stride, out_gen, f->nchan,
@@ -855,9 +857,9 @@ static int try_general_window(redio_src *f, const SrcInput &in, long in_count, f
         if (r != 1) return give_back(r);
         launched = out_gen;
     }
-    // rebuild [b_current - half, b_end) of the final image into the other buffer
+    // rebuild [b_current - widest filter's reach, b_end) of the final image into the other buffer (see try_uniform_window)
     const int other = f->cur ^ 1;
-    long j0 = (long)b_current - half, j1 = b_end;
+    long j0 = (long)b_current - f->front, j1 = b_end;
     if (j0 < 0) j0 = 0;
     SRC_TRY(launch_src_window_image(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, A0, j0, j1, f->d_buf[other], f->nchan, st));
     f->cur = other;
