@@ -14,7 +14,7 @@
  * a converter above 4 or a channel count below 1 returns NULL with the library's error code.  Deviation stated in DESIGN.md: the coefficient tables are not the
  * library's (they cannot be reproduced here), so sample values differ from the real library within
  * its quality class; control flow and frame counts follow the published 0.1.8 algorithm for ONE channel (what the
- * reference uses).  Three stated definitions beyond it: (i) with channels > 1 and a sinc converter every channel runs through
+ * reference uses).  Four stated definitions beyond it: (i) with channels > 1 and a sinc converter every channel runs through
  * its own mono state, so the frame count of the LAST message of a stream (end_of_input = 1) is the mono loop's: the library's
  * multi-channel loops test their end-of-input condition in sample units with >= where the mono loop has >, and can differ from
  * this by one frame there; (ii) a message of a single frame through the zero-order-hold / linear converters interpolates from
@@ -23,7 +23,13 @@
  * b_current still sits where the narrower filter left it, so calc_output_single's left wing (data_index = b_current - coeff_count)
  * and prepare_data's move source (b_current - half_filter_chan_len) can be NEGATIVE: libsamplerate 0.1.8 reads the words in front of
  * its buffer there (the filter struct's own fields).  This library and its oracle read +0.0f, silence before the stream
- * (found by the randomised run of round 4; tests/test_gpu_resample.py::test_ratio_decrease_reaches_in_front_of_the_buffer).
+ * (found by the randomised run of round 4; tests/test_gpu_resample.py::test_ratio_decrease_reaches_in_front_of_the_buffer);
+ * (iv) with end_of_input = 1 and a ratio below about 1 / 213, prepare_data's last move (memmove of half_filter_chan_len + (b_end - b_current)
+ * floats to the start of the buffer) can be LONGER than the buffer, which holds 2.5 half-lengths of the widest filter: libsamplerate 0.1.8
+ * writes past its allocation there and then zero-fills a negative length.  This library and its oracle return
+ * SRC_ERR_SINC_PREPARE_DATA_BAD_LEN (the library's own code for an impossible length) from that call instead, with
+ * input_frames_used = output_frames_gen = 0 (found by the randomised run of round 4, ratios down to 1 / 256;
+ * tests/test_gpu_resample.py::test_end_of_input_at_the_smallest_ratios).  The reference never sets end_of_input (samplerate.rs:73).
  */
 #ifndef SAMPLERATE_H
 #define SAMPLERATE_H

@@ -314,6 +314,7 @@ static int prepare_data(redio_src *f, const SrcInput &in, long in_count, long &i
     if (in_used == in_count && f->b_end - f->b_current < 2 * half && end_of_input) {
         if (f->b_len - f->b_end < half + 5) {
             len = f->b_end - f->b_current;
+            if (half + len > f->b_len) return REDIO_SRC_ERR_SINC_PREPARE_DATA_BAD_LEN; // include/samplerate.h (iv): the library's move would overrun its buffer
             const int other = f->cur ^ 1;
             SRC_TRY(launch_src_copy_rows(f->d_buf[f->cur], f->buf_stride, f->b_current - half, f->d_buf[other], f->buf_stride, 0,
                                          (long)half + len, f->nchan, st));

@@ -218,6 +218,10 @@ static int prepare_data(orc_src_state *f, const orc_src_data *d, int half)
         /* last buffer: pad with zeros so the tail can be flushed */
         if (f->b_len - f->b_end < half + 5) {
             len = f->b_end - f->b_current;
+            /* DEFINED where the published code is not (include/samplerate.h (iv)): below a ratio of about 1 / 213 this move can be longer
+             * than the buffer (len < 2 half, b_len = 2.5 half at the smallest ratio); 0.1.8 writes past its allocation and then
+             * zero-fills a negative length.  Here, and in the device path, the call fails with the library's bad-length code. */
+            if (half + len > f->b_len) return SRC_ERR_SINC_PREPARE_DATA_BAD_LEN;
             memmove(f->buffer, f->buffer + f->b_current - half, (size_t)(half + len) * sizeof(float));
             f->b_current = half;
             f->b_end = f->b_current + len;

@@ -38,6 +38,7 @@ def same_nan(got, want):
     return np.array_equal(np.isnan(g), wn) and np.array_equal(g.view(np.uint32)[~wn], w.view(np.uint32)[~wn])
 
 
+HARD = bool(os.environ.get("FUZZ_SRC_HARD"))   # the resampler drop-in branch changes its ratio on most messages, over [1/256, 256]
 ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]   # e.g. FUZZ_ONLY=5,9: the two resampler branches only
 
 
@@ -49,8 +50,20 @@ def check(name, ok, detail):
         print("FAIL", name, detail, flush=True)
 
 
+# FUZZ_TRACE=file: the generator's state is written there before every case, so that a case that kills the process can be replayed:
+# FUZZ_STATE=file runs exactly that one case
+import json
+TRACE, STATE = os.environ.get("FUZZ_TRACE"), os.environ.get("FUZZ_STATE")
+if STATE:
+    rng.bit_generator.state = json.load(open(STATE))
+    budget = 1e9
+ncases = 0
 t_end = time.time() + budget
-while time.time() < t_end:
+while time.time() < t_end and not (STATE and ncases):
+    ncases += 1
+    if TRACE:
+        with open(TRACE, "w") as fh:
+            json.dump(rng.bit_generator.state, fh); fh.flush(); os.fsync(fh.fileno())
     which = rng.integers(0, 12) if not ONLY else int(rng.choice(ONLY))
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000)), int(rng.integers(2000, 20000))]))
@@ -231,7 +244,10 @@ while time.time() < t_end:
             sd = int(rng.integers(1, 1 << 30)); seeds.append(sd)
             x = O.synth_f32(sd, 0, m * ch)
             eoi = int(flush and i + 1 == nmsg)                      # the last message may carry end_of_input: the converter drains its tail
-            if i and not rng.integers(0, 3):                        # a new ratio now and then: the library glides to it inside the message
+            if HARD and i and rng.integers(0, 4):                   # FUZZ_SRC_HARD=1: most messages change the ratio, by up to 30 x, over the library's whole range
+                ratio = float(np.clip(ratio * 10.0 ** rng.uniform(-1.5, 1.5), 1 / 256, 256.0))
+                if ratio > 8.0: m = min(m, 400)
+            elif i and not rng.integers(0, 3):                      # a new ratio now and then: the library glides to it inside the message
                 ratio = float(np.clip(ratio * rng.uniform(0.5, 2.0), 0.01, 3.0))
             cap = int(ratio * m + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
             e1, a, u1 = st.process(x, ratio, cap, eoi)
@@ -254,15 +270,25 @@ while time.time() < t_end:
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 3)] + ([min(n, int(rng.integers(0, n + 1)) + 1)] if rng.integers(0, 2) else [])))
         ok = True
         dx = torch.from_numpy(x).cuda()
-        flush = bool(rng.integers(0, 2))
+        flush = bool(rng.integers(0, 2)); ratios = []
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             eoi = flush and hi == n
+            if HARD and lo and rng.integers(0, 2):
+                ratio = float(np.clip(ratio * 10.0 ** rng.uniform(-1.0, 1.0), 1 / 256, 256.0 if n < 400 else 8.0))
+            ratios.append(float(ratio).hex())
             cap = int(ratio * (hi - lo) + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
-            a, used = plan.process(dx[:, lo:hi].contiguous(), ratio, output_frames=cap, end_of_input=eoi)
+            try:
+                a, used = plan.process(dx[:, lo:hi].contiguous(), ratio, output_frames=cap, end_of_input=eoi)
+                code = 0
+            except R.RedioError as ex:   # a library error code (include/samplerate.h (iv)): the oracle must report the same, then the stream is over
+                code = ex.code
+            if code:
+                ok = ok and all(refs[c].process(x[c, lo:hi], ratio, cap, eoi)[0] == code for c in range(nch))
+                break
             a = a.cpu().numpy()
             for c in range(nch):
                 err, want, wused = refs[c].process(x[c, lo:hi], ratio, cap, eoi)
                 ok = ok and err == 0 and wused == used and a.shape[1] == len(want) and np.array_equal(bits(a[c]), bits(want))
-        check("src", ok, (nch, conv, ratio, n, cuts, flush))
+        check("src", ok, (nch, conv, ratios, n, cuts, flush))
 print("runs", runs, "failures", fails)
 sys.exit(1 if fails else 0)

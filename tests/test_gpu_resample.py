@@ -486,3 +486,46 @@ def test_ratio_decrease_reaches_in_front_of_the_buffer(gpu, redio, oracle, conv,
             total += len(want)
         if conv == 0 and falls is RATIO_FALLS:
             assert total > 40                           # the widened best-quality filter did produce outputs in the calls that reach back
+
+
+# found by the randomised run with ratios over the library's whole range (round 4): end_of_input at a ratio of 1 / 256 makes prepare_data's
+# last move longer than the buffer (libsamplerate 0.1.8 overruns its allocation); defined as SRC_ERR_SINC_PREPARE_DATA_BAD_LEN (include/samplerate.h (iv))
+EOI_SMALLEST = [(342, 474237719, '0x1.0000000000000p+0', 343, 0), (4, 835049986, '0x1.a074d40eaf3ffp-3', 1, 0),
+                (5594, 866347677, '0x1.9905d40507092p-7', 70, 0), (14858, 933052245, '0x1.0000000000000p-8', 5323, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch", [1, 3])
+def test_end_of_input_at_the_smallest_ratios(gpu, redio, oracle, ch):
+    from libredio_amd import samplerate
+    st, ref = samplerate.State(1, ch), oracle.Resampler(1, ch)
+    errs = []
+    for m, seed, rh, cap, eoi in EOI_SMALLEST:
+        x = oracle.synth_f32(seed, 0, m * ch); ratio = float.fromhex(rh)
+        e1, got, u1 = st.process(x, ratio, cap, eoi)
+        e2, want, u2 = ref.process(x, ratio, cap, bool(eoi))
+        assert (e1, u1, len(got)) == (e2, u2, len(want)), (ch, m)
+        assert np.array_equal(bits(got), bits(want)), (ch, m)
+        errs.append(e1)
+    assert errs == [0, 0, 0, 21]                # SRC_ERR_SINC_PREPARE_DATA_BAD_LEN from the call the library cannot serve, nothing written
+    if ch == 1:                                  # the batched interface reports the same code
+        src, ref = redio.Src(1, 1), oracle.Resampler(1, 1)
+        for m, seed, rh, cap, eoi in EOI_SMALLEST[:3]:
+            x = oracle.synth_f32(seed, 0, m); ratio = float.fromhex(rh)
+            a, u1 = src.process(gpu.from_numpy(x).cuda().view(1, -1), ratio, output_frames=cap, end_of_input=bool(eoi))
+            e2, want, u2 = ref.process(x, ratio, cap, bool(eoi))
+            assert e2 == 0 and u1 == u2 and np.array_equal(bits(a.cpu().numpy()[0]), bits(want))
+        m, seed, rh, cap, eoi = EOI_SMALLEST[3]
+        with pytest.raises(redio.RedioError) as e:
+            src.process(gpu.from_numpy(oracle.synth_f32(seed, 0, m)).cuda().view(1, -1), float.fromhex(rh), output_frames=cap, end_of_input=True)
+        assert e.value.code == 21
+    # the smallest ratio from a fresh state: a whole stream with the flush at its end (whatever the library's flow decides, both sides agree)
+    for n, cap_extra in ((40000, 0), (40000, 300), (70000, 500), (200, 50)):
+        st, ref = samplerate.State(1, ch), oracle.Resampler(1, ch)
+        x = oracle.synth_f32(77 + n, 0, n * ch)
+        for lo, hi, eoi in ((0, n // 3, 0), (n // 3, n, 1)):
+            cap = int((hi - lo) / 256 + 1.0) + (cap_extra if eoi else 0)
+            e1, got, u1 = st.process(x[lo * ch:hi * ch], 1 / 256, cap, eoi)
+            e2, want, u2 = ref.process(x[lo * ch:hi * ch], 1 / 256, cap, bool(eoi))
+            assert (e1, u1, len(got)) == (e2, u2, len(want)), (ch, n, lo)
+            assert np.array_equal(bits(got), bits(want)), (ch, n, lo)
