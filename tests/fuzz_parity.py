@@ -91,6 +91,8 @@ while time.time() < t_end and not (STATE and ncases):
     elif which == 2:    # chain shapes
         k, dd = [(127, 5), (63, 5), (127, 3), (127, 1), (63, 1), (100, 2), (31, 4)][int(rng.integers(0, 7))]
         nfc = int(rng.choice([1024, 1024, 256, 4096, 1000, 64, 2048]))
+        if HARD:  # any tap count, decimation and block size (the FIR and FFT kernels back to back through the plan's intermediate)
+            k, dd, nfc = int(rng.integers(1, 400)), int(rng.integers(1, 17)), int(rng.choice([nfc, int(rng.integers(1, 3000)), 2 ** int(rng.integers(0, 15))]))
         fused = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 40 if nfc <= 1024 else 6)); extra = int(rng.integers(0, nfc * dd))
         taps = O.synth_f32(int(rng.integers(1, 1 << 30)), 0, k)
         n = nb * nfc * dd + (k - dd) + extra
