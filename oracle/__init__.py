@@ -303,6 +303,7 @@ class Trigger:
 
     def __init__(self):
         self._t = lib().orc_trigger_new()
+        self._fed = 0
 
     def __del__(self):
         if getattr(self, "_t", None):
@@ -311,7 +312,8 @@ class Trigger:
     def feed(self, blocks):
         blocks = _f32(blocks)
         nb, bl = blocks.shape
-        cap = nb * bl + 1 + 64
+        self._fed += nb * bl
+        cap = self._fed + nb + 64   # a buffer can carry blocks collected by earlier calls
         out = np.empty(cap, np.float32); lens = np.zeros(nb + 1, np.uint64); tot = C.c_size_t(0)
         ne = lib().orc_trigger_feed(self._t, blocks, nb, bl, out, cap, lens, len(lens), C.byref(tot))
         res, off = [], 0

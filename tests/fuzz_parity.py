@@ -64,7 +64,7 @@ while time.time() < t_end and not (STATE and ncases):
     if TRACE:
         with open(TRACE, "w") as fh:
             json.dump(rng.bit_generator.state, fh); fh.flush(); os.fsync(fh.fileno())
-    which = rng.integers(0, 12) if not ONLY else int(rng.choice(ONLY))
+    which = rng.integers(0, 13) if not ONLY else int(rng.choice(ONLY))
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000)), int(rng.integers(2000, 20000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
@@ -262,6 +262,25 @@ while time.time() < t_end and not (STATE and ncases):
             sizes.append((m, sd, float(ratio).hex(), cap, eoi))
         st.close()
         check("srcdrop", ok, (conv, ch, sizes, flush, detail))
+    elif which == 12:   # bitfount::trigger (bitfount.rs:36-85): quiet noise with bursts, any cut of the block stream into calls
+        from libredio_amd import bitfount as B
+        bl = int(rng.choice([512, 512, 512, 64, 100, 1])); nb = int(rng.integers(1, 2500 if bl >= 64 else 6000))
+        amp = float(10.0 ** rng.uniform(-3, 0.5))
+        blocks = (amp * rng.random((nb, bl))).astype(np.float32)
+        if rng.integers(0, 4) == 0: blocks -= np.float32(amp / 2)   # sums of both signs
+        for _ in range(int(rng.integers(0, 8))):
+            st0 = int(rng.integers(0, nb)); ln = int(rng.choice([1, 2, 3, 10, 49, 50, 51, 60, 200]))
+            blocks[st0:st0 + ln] += np.float32(amp * 10.0 ** rng.uniform(0, 2))
+        cuts = sorted(set([0, nb] + [int(c) for c in rng.integers(0, nb + 1, int(rng.integers(0, 5)))]))
+        dev, ref = B.Trigger(), O.Trigger()
+        got, want = [], []
+        dblocks = torch.from_numpy(blocks).cuda()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            if hi > lo:
+                got += [g.cpu().numpy() for g in dev.feed(dblocks[lo:hi].contiguous())]
+                want += ref.feed(blocks[lo:hi])
+        ok = len(got) == len(want) and all(len(g) == len(w) and np.array_equal(bits(g), bits(w)) for g, w in zip(got, want))
+        check("trigger", ok, (bl, nb, amp, cuts, len(got), len(want)))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 5))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 48000 / 44100, 1.5, 0.3, 4 / 3, 0.75, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
