@@ -281,6 +281,35 @@ def test_kiss_fft_dropin_symbols(gpu, redio, oracle):
     redio.kisslib().kiss_fft_cleanup()
 
 
+def test_kiss_fft_placement_stride_and_helpers(gpu, redio, oracle):
+    """kiss_fft_alloc's mem / lenmem protocol (the reference passes NULL, NULL -- kissfft.rs:19 -- but the C header promises both forms):
+    a size query, a cfg placed in the caller's memory, too small a buffer; kiss_fft_stride; kiss_fft_next_fast_size; kiss_fft_free"""
+    L = redio.kisslib()
+    L.kiss_fft_alloc.restype = C.c_void_p
+    L.kiss_fft_alloc.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.kiss_fft_stride.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.kiss_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kiss_fft_free.argtypes = [C.c_void_p]
+    L.kiss_fft_next_fast_size.restype = C.c_int
+    need = C.c_size_t(0)
+    assert L.kiss_fft_alloc(256, 0, None, C.byref(need)) is None and 0 < need.value < 4096    # size query
+    small = C.create_string_buffer(8); got = C.c_size_t(8)
+    assert L.kiss_fft_alloc(256, 0, small, C.byref(got)) is None and got.value == need.value   # too small: the size comes back
+    mem = C.create_string_buffer(need.value); got = C.c_size_t(need.value)
+    cfg = L.kiss_fft_alloc(256, 1, mem, C.byref(got))
+    assert cfg == C.addressof(mem)                                                            # placed in the caller's memory
+    x = oracle.synth_iq(91, 0, 256); out = np.empty_like(x)
+    L.kiss_fft(cfg, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert same_bits(out, oracle.fft(x, 256, True))
+    wide = oracle.synth_iq(92, 0, 256 * 3)                                                    # every third sample
+    L.kiss_fft_stride(cfg, wide.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 3)
+    assert same_bits(out, oracle.fft(np.ascontiguousarray(wide[::3]), 256, True))
+    L.kiss_fft_free(cfg)                                                                      # releases the device side, not the caller's memory
+    mem[0:4] = b"\0\0\0\0"                                                                    # still ours to write
+    for n, want in ((1, 1), (7, 8), (17, 18), (1000, 1000), (1025, 1080), (4097, 4320)):      # next size with factors 2, 3, 5 only
+        assert L.kiss_fft_next_fast_size(n) == want, n
+
+
 def test_kissfft_block_function(gpu, redio, oracle):
     import queue
     import threading
