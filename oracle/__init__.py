@@ -75,6 +75,7 @@ def lib():
     L.orc_src_delete.argtypes = [C.c_void_p]; L.orc_src_delete.restype = None
     L.orc_src_process.argtypes = [C.c_void_p, C.POINTER(SrcData)]; L.orc_src_process.restype = C.c_int
     L.orc_src_reset.argtypes = [C.c_void_p]; L.orc_src_reset.restype = C.c_int
+    L.orc_src_set_ratio.argtypes = [C.c_void_p, C.c_double]; L.orc_src_set_ratio.restype = C.c_int
     L.orc_src_table.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_src_table.restype = C.c_int
     L.orc_resample_block.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_double, _f32p, C.c_long]
@@ -245,6 +246,10 @@ class Resampler:
         if n < 0:
             raise RuntimeError(f"src_process error {-(n + 1000)}")
         return out[:n].copy()
+
+    def set_ratio(self, ratio):
+        """src_set_ratio (samplerate.rs:40): the next call starts at this ratio instead of gliding to it."""
+        return lib().orc_src_set_ratio(self._s, float(ratio))
 
     def process(self, vin, ratio, out_frames, end_of_input=False):
         """vin: interleaved frames (len = frames * channels); returns (error, interleaved output, input FRAMES used)."""

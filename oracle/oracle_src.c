@@ -111,6 +111,17 @@ struct orc_src_state {
     int zl_reset;
 };
 
+/* src_set_ratio (samplerate.rs:40; libsamplerate 0.1.8 samplerate.c): the next src_process starts AT this ratio instead of gliding to its
+ * src_ratio from the previous one -- it overwrites last_ratio, nothing else */
+int orc_src_set_ratio(orc_src_state *s, double new_ratio)
+{
+    if (!s) return SRC_ERR_BAD_STATE;
+    if (new_ratio < (1.0 / SRC_MAX_RATIO) || new_ratio > (1.0 * SRC_MAX_RATIO)) return SRC_ERR_BAD_SRC_RATIO;
+    s->last_ratio = new_ratio;
+    if (s->sub) for (int c = 0; c < s->channels; ++c) s->sub[c]->last_ratio = new_ratio;
+    return SRC_ERR_NO_ERROR;
+}
+
 int orc_src_reset(orc_src_state *s)
 {
     if (!s) return SRC_ERR_BAD_STATE;

@@ -91,6 +91,7 @@ orc_src_state *orc_src_new(int converter_type, int channels, int *error); /* :61
 void orc_src_delete(orc_src_state *s);
 int  orc_src_process(orc_src_state *s, orc_src_data *d);                  /* :76 */
 int  orc_src_reset(orc_src_state *s);
+int  orc_src_set_ratio(orc_src_state *s, double new_ratio);              /* :40 */
 /* table access so the GPU library and the oracle can be compared coefficient by coefficient */
 int  orc_src_table(int converter_type, const float **coeffs, int *half_len, int *increment);
 /* one message of the resample block: lout = (ratio*len + 1) as usize (:64); returns frames generated */

@@ -252,6 +252,10 @@ while time.time() < t_end and not (STATE and ncases):
             elif i and not rng.integers(0, 3):                      # a new ratio now and then: the library glides to it inside the message
                 ratio = float(np.clip(ratio * rng.uniform(0.5, 2.0), 0.01, 3.0))
             cap = int(ratio * m + 1.0) + (int(rng.integers(0, 6000)) if eoi else 0)
+            stepped = 0
+            if i and not rng.integers(0, 5):                        # src_set_ratio before the call: a step to the new ratio instead of a glide (samplerate.rs:40)
+                sr = ratio if rng.integers(0, 2) else float(np.clip(ratio * rng.uniform(0.5, 2.0), 0.01, 3.0))
+                stepped = 1 if (st.set_ratio(sr), ref.set_ratio(sr)) == (0, 0) else -1
             e1, a, u1 = st.process(x, ratio, cap, eoi)
             e2, b, u2 = ref.process(x, ratio, cap, bool(eoi))
             same = (e1, u1, len(a)) == (e2, u2, len(b)) and np.array_equal(bits(a), bits(b))
@@ -259,7 +263,8 @@ while time.time() < t_end and not (STATE and ncases):
                 nd = np.nonzero(bits(a[: min(len(a), len(b))]) != bits(b[: min(len(a), len(b))]))[0]
                 detail.append((i, (e1, u1, len(a)), (e2, u2, len(b)), int(nd[0]) if len(nd) else -1, len(nd)))
             ok = ok and same
-            sizes.append((m, sd, float(ratio).hex(), cap, eoi))
+            ok = ok and stepped >= 0
+            sizes.append((m, sd, float(ratio).hex(), cap, eoi) + ((float(sr).hex(),) if stepped else ()))
         st.close()
         check("srcdrop", ok, (conv, ch, sizes, flush, detail))
     elif which == 12:   # bitfount::trigger (bitfount.rs:36-85): quiet noise with bursts, any cut of the block stream into calls

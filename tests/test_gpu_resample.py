@@ -529,3 +529,31 @@ def test_end_of_input_at_the_smallest_ratios(gpu, redio, oracle, ch):
             e2, want, u2 = ref.process(x[lo * ch:hi * ch], 1 / 256, cap, bool(eoi))
             assert (e1, u1, len(got)) == (e2, u2, len(want)), (ch, n, lo)
             assert np.array_equal(bits(got), bits(want)), (ch, n, lo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv,ch", [(1, 1), (0, 1), (2, 2), (3, 1), (4, 2)])
+def test_src_set_ratio_steps_instead_of_gliding(gpu, redio, oracle, conv, ch):
+    """src_set_ratio (samplerate.rs:40) overwrites the ratio the next call starts from: a call at the new ratio then runs at it from its
+    first output (no glide); a call at a third ratio glides from the SET one.  Bad arguments return the library's codes."""
+    from libredio_amd import samplerate
+    st, ref = samplerate.State(conv, ch), oracle.Resampler(conv, ch)
+    assert st.set_ratio(300.0) == ref.set_ratio(300.0) == 6 and st.set_ratio(1e-3) == ref.set_ratio(1e-3) == 6   # SRC_ERR_BAD_SRC_RATIO
+    seq = [(3000, 0.5, None), (3000, 0.25, 0.25), (2500, 0.4, 0.3), (1, 0.4, None), (4000, 1.5, 1.5), (3000, 0.02, 0.05), (6000, 0.02, None)]
+    for i, (m, ratio, setr) in enumerate(seq):
+        x = oracle.synth_f32(500 + i, 0, m * ch)
+        if setr is not None:
+            assert st.set_ratio(setr) == ref.set_ratio(setr) == 0
+        cap = int(ratio * m + 1.0)
+        e1, got, u1 = st.process(x, ratio, cap, 0)
+        e2, want, u2 = ref.process(x, ratio, cap, False)
+        assert (e1, u1, len(got)) == (e2, u2, len(want)) and e1 == 0, (conv, ch, i)
+        assert np.array_equal(bits(got), bits(want)), (conv, ch, i)
+    # the step is visible: the same two messages WITHOUT the set glide, and differ
+    if conv < 3:
+        a, b = oracle.Resampler(conv, ch), oracle.Resampler(conv, ch)
+        x0, x1 = oracle.synth_f32(1, 0, 3000 * ch), oracle.synth_f32(2, 0, 3000 * ch)
+        a.process(x0, 0.5, 1501, False); b.process(x0, 0.5, 1501, False)
+        b.set_ratio(0.25)
+        ya, yb = a.process(x1, 0.25, 751, False)[1], b.process(x1, 0.25, 751, False)[1]
+        assert len(ya) != len(yb) or not np.array_equal(bits(ya), bits(yb))
