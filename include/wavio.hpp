@@ -13,6 +13,7 @@
 #include "kpn.hpp"
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,51 +28,65 @@ struct WavInfo {
     uint64_t frames = 0;
 };
 
-// whole file -> interleaved f32 (PCM16 is scaled by 1/32768 as libsndfile's read_f32 does)
+// whole file -> interleaved f32 (PCM16 is scaled by 1/32768 as libsndfile's read_f32 does).  A header this reader cannot serve --
+// not RIFF/WAVE, a format chunk shorter than its 16 fixed bytes or absurdly long, no channels, a sample size other than the two it
+// converts, data before the format -- throws std::runtime_error; a data chunk that claims more bytes than the file holds (streaming
+// writers leave 0xFFFFFFFF there) yields the whole frames that are present, as libsndfile does.  Nothing is read or allocated from an
+// unchecked header field (tests/cpp/kpn_tests.cpp "wavbad", under AddressSanitizer in tests/san_check.sh).
 inline std::vector<float> read_wav(const std::string &fname, WavInfo &info)
 {
-    FILE *f = std::fopen(fname.c_str(), "rb");
+    struct Closer { FILE *f; ~Closer() { if (f) std::fclose(f); } } file{std::fopen(fname.c_str(), "rb")};
+    FILE *f = file.f;
     if (!f) throw std::runtime_error("wavio: cannot open " + fname);
-    auto rd = [&](void *p, size_t n) { if (std::fread(p, 1, n, f) != n) { std::fclose(f); throw std::runtime_error("wavio: short read"); } };
+    auto rd = [&](void *p, size_t n) { if (std::fread(p, 1, n, f) != n) throw std::runtime_error("wavio: short read"); };
     char id[4]; uint32_t sz;
     rd(id, 4); rd(&sz, 4);
-    if (std::memcmp(id, "RIFF", 4)) { std::fclose(f); throw std::runtime_error("wavio: not RIFF"); }
+    if (std::memcmp(id, "RIFF", 4)) throw std::runtime_error("wavio: not RIFF");
     rd(id, 4);
-    if (std::memcmp(id, "WAVE", 4)) { std::fclose(f); throw std::runtime_error("wavio: not WAVE"); }
+    if (std::memcmp(id, "WAVE", 4)) throw std::runtime_error("wavio: not WAVE");
     std::vector<float> out;
     bool have_fmt = false;
     for (;;) {
         if (std::fread(id, 1, 4, f) != 4) break;
         rd(&sz, 4);
         if (!std::memcmp(id, "fmt ", 4)) {
+            if (sz < 16 || sz > 4096) throw std::runtime_error("wavio: format chunk of " + std::to_string(sz) + " bytes");
             std::vector<uint8_t> b(sz);
             rd(b.data(), sz);
+            if (sz & 1) std::fseek(f, 1, SEEK_CUR); // chunks are word aligned
             std::memcpy(&info.format, &b[0], 2); std::memcpy(&info.channels, &b[2], 2);
             std::memcpy(&info.samplerate, &b[4], 4); std::memcpy(&info.bits, &b[14], 2);
             if (info.format == 0xFFFE && sz >= 26) std::memcpy(&info.format, &b[24], 2); // WAVE_FORMAT_EXTENSIBLE
+            if (info.channels == 0) throw std::runtime_error("wavio: no channels");
             have_fmt = true;
         } else if (!std::memcmp(id, "data", 4)) {
-            if (!have_fmt) { std::fclose(f); throw std::runtime_error("wavio: data before fmt"); }
-            const size_t bps = info.bits / 8;
-            const size_t items = sz / bps;
+            if (!have_fmt) throw std::runtime_error("wavio: data before fmt");
+            const bool f32 = info.format == 3 && info.bits == 32, pcm16 = info.format == 1 && info.bits == 16;
+            if (!f32 && !pcm16) throw std::runtime_error("wavio: only PCM16 and float32 are supported");
+            const size_t bps = f32 ? 4 : 2;
+            // no more than the file holds, whole frames only
+            const long here = std::ftell(f);
+            std::fseek(f, 0, SEEK_END);
+            const long fend = std::ftell(f);
+            std::fseek(f, here, SEEK_SET);
+            size_t bytes = sz;
+            if (here >= 0 && fend >= here && (size_t)(fend - here) < bytes) bytes = (size_t)(fend - here);
+            const size_t frame = bps * info.channels;
+            const size_t items = (bytes / frame) * info.channels;
             out.resize(items);
-            if (info.format == 3 && info.bits == 32) {
+            if (f32) {
                 rd(out.data(), items * 4);
-            } else if (info.format == 1 && info.bits == 16) {
+            } else {
                 std::vector<int16_t> t(items);
                 rd(t.data(), items * 2);
                 for (size_t i = 0; i < items; ++i) out[i] = (float)t[i] / 32768.0f;
-            } else {
-                std::fclose(f);
-                throw std::runtime_error("wavio: only PCM16 and float32 are supported");
             }
             info.frames = items / info.channels;
             break;
         } else {
-            std::fseek(f, (long)(sz + (sz & 1)), SEEK_CUR);
+            if (std::fseek(f, (long)sz + (long)(sz & 1), SEEK_CUR) != 0) break;
         }
     }
-    std::fclose(f);
     return out;
 }
 

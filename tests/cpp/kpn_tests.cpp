@@ -215,6 +215,62 @@ static int plumbing()
         auto iq = drain(dr);
         CHECK(iq.size() == 2048 && iq[1] == std::complex<float>(x[2], x[3]));
     }
+    { // malformed WAV files: a clean std::runtime_error or the frames that are there -- never a read or an allocation from an unchecked field
+        auto put = [](const std::string &name, const std::vector<uint8_t> &b) { FILE *f = std::fopen(name.c_str(), "wb"); if (!b.empty()) std::fwrite(b.data(), 1, b.size(), f); std::fclose(f); };
+        auto u32 = [](std::vector<uint8_t> &b, uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); };
+        auto u16 = [](std::vector<uint8_t> &b, uint16_t v) { b.push_back((uint8_t)v); b.push_back((uint8_t)(v >> 8)); };
+        auto tag = [](std::vector<uint8_t> &b, const char *t) { b.insert(b.end(), t, t + 4); };
+        auto header = [&](uint32_t fmt_sz, uint16_t format, uint16_t ch, uint16_t bits, uint32_t data_sz, size_t data_present) {
+            std::vector<uint8_t> b; tag(b, "RIFF"); u32(b, 36 + data_sz); tag(b, "WAVE"); tag(b, "fmt "); u32(b, fmt_sz);
+            std::vector<uint8_t> fm; u16(fm, format); u16(fm, ch); u32(fm, 48000); u32(fm, 48000u * ch * (bits / 8)); u16(fm, (uint16_t)(ch * (bits / 8))); u16(fm, bits);
+            fm.resize(fmt_sz < 64 ? fmt_sz : 64, 0);
+            b.insert(b.end(), fm.begin(), fm.end());
+            if (fmt_sz & 1) b.push_back(0);
+            tag(b, "data"); u32(b, data_sz);
+            for (size_t i = 0; i < data_present; ++i) b.push_back((uint8_t)(i * 37 + 1));
+            return b;
+        };
+        auto outcome = [&](const std::vector<uint8_t> &b, size_t *frames = nullptr) { // 0: read, 1: runtime_error
+            put("/tmp/kpn_bad.wav", b);
+            wavio::WavInfo info;
+            try { auto v = wavio::read_wav("/tmp/kpn_bad.wav", info); if (frames) *frames = info.frames; CHECK(v.size() == info.frames * info.channels); return 0; }
+            catch (const std::runtime_error &) { return 1; }
+        };
+        size_t fr = 0;
+        CHECK(outcome(header(16, 3, 1, 32, 400, 400), &fr) == 0 && fr == 100);          // well formed
+        CHECK(outcome(header(16, 1, 2, 16, 400, 400), &fr) == 0 && fr == 100);          // PCM16 stereo
+        CHECK(outcome(header(8, 3, 1, 32, 400, 400)) == 1);                             // format chunk shorter than its fixed part
+        CHECK(outcome(header(0xFFFFFFF0u, 3, 1, 32, 400, 400)) == 1);                   // ... or absurdly long
+        CHECK(outcome(header(16, 3, 0, 32, 400, 400)) == 1);                            // no channels
+        CHECK(outcome(header(16, 3, 1, 0, 400, 400)) == 1);                             // zero bits per sample
+        CHECK(outcome(header(16, 1, 1, 24, 400, 400)) == 1);                            // a width it does not convert
+        CHECK(outcome(header(16, 3, 2, 32, 0xFFFFFFFFu, 404), &fr) == 0 && fr == 50);   // streaming writer's size: the whole frames present (404 bytes = 50 frames + 4)
+        CHECK(outcome(header(16, 3, 1, 32, 400, 123), &fr) == 0 && fr == 30);           // truncated data
+        CHECK(outcome(header(17, 3, 1, 32, 40, 40), &fr) == 0 && fr == 10);             // odd-sized format chunk, pad byte skipped
+        CHECK(outcome({'R', 'I', 'F', 'F', 1, 0, 0, 0, 'W', 'A', 'V'}) == 1);           // cut inside the magic
+        CHECK(outcome({}) == 1);
+        { std::vector<uint8_t> b; tag(b, "RIFF"); u32(b, 4); tag(b, "WAVE"); tag(b, "data"); u32(b, 8); b.resize(b.size() + 8, 1); CHECK(outcome(b) == 1); } // data before fmt
+        // a seeded mutation run over a good file: every outcome is "read" or "runtime_error" (under ASan in tests/san_check.sh: no bad access)
+        uint32_t st = 12345; auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+        const auto good = header(18, 3, 2, 32, 800, 800);
+        int reads = 0, errors = 0;
+        for (int it = 0; it < 3000; ++it) {
+            auto b = good;
+            const int nmut = 1 + (int)(rnd() % 4);
+            for (int m = 0; m < nmut; ++m) {
+                const size_t pos = rnd() % 64; // the header region
+                switch (rnd() % 4) {
+                case 0: b[pos] = (uint8_t)rnd(); break;
+                case 1: b[pos] = 0; break;
+                case 2: b[pos] = 0xFF; break;
+                default: b.resize(rnd() % (b.size() + 1)); break;
+                }
+                if (b.size() <= pos) break;
+            }
+            (outcome(b) == 0 ? reads : errors)++;
+        }
+        CHECK(reads > 100 && errors > 100);
+    }
     { // a block that throws mid-stream is that task's panic only: the process lives and the hang-up cascades
         auto [a, ar] = channel<int>();
         auto [b, br] = channel<int>();
