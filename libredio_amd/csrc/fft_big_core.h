@@ -413,4 +413,17 @@ RD_HD constexpr long pw_first5_st(int L, int qq, int sp, int x, int n, int j)
     return 1024l * ((long)(2 * (qq & 1) + x) * (1l << (2 * (L - 6))) + (long)(qq >> 1) * (1l << (2 * (L - 7)))) + 256 * n + 16 * j + 2 * sp;
 }
 
+
+// ---- input of the four-wave kernels (16384 = 4 x 4096, 8192 = 4 x 2048 points; fft_kernels.hip f16k_deal_load / f8k_deal_load) ---------
+// Wave q transforms x[4 n + q].  The four waves read a round (half a block) in 512-byte runs -- wave w, load t: samples 256 t + 64 w + lane
+// of the round -- and DEAL them through LDS: sample e = 4 n + q goes to plane q, cell n; wave q then reads its positions lane-contiguous.
+// The plane stride PS is 8 mod 16 cells, so the four planes start 16 banks apart: the 16 lanes of a ds_write_b64 group (4 cells in each
+// plane) and the 32 lanes of a half-wave (8 in each) write different banks; the reads are consecutive cells.  Run lane by lane on the CPU
+// in tests/emu (tests/test_emu_lane_programs.py::test_four_wave_deal).
+constexpr int F16K_PS = 2056, F8K_PS = 1032;
+RD_HD int deal_write_cell(int PS, int w, int lane, int t) { return PS * (lane & 3) + 16 * w + (lane >> 2) + 64 * t; }
+RD_HD int deal_read_cell(int PS, int q, int lane, int pos) { return PS * q + pos + lane; } // pos: position in the round, a multiple of 64
+// position (in the wave's sub-sequence) of register a[i][j] of the 4096-point program, and of a[d2][j] of the 2048-point program
+RD_HD int f4k_reg_pos(int i, int j) { return 1024 * (j & 3) + 256 * (j >> 2) + 64 * i; }
+RD_HD int f2k_reg_pos(int d2, int j) { return 64 * (d2 + 4 * (j >> 1) + 16 * (j & 1)); }
 } // namespace redio

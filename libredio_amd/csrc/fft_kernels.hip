@@ -1282,15 +1282,14 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
 #ifndef REDIO_OV16K_LDS_DEAL
 #define REDIO_OV16K_LDS_DEAL 0
 #endif
-constexpr int F16K_PS = 2056, F8K_PS = 1032;
 __device__ __forceinline__ void f16k_deal_load(float2 (&a)[4][16], float2 (&b)[4][16], const float2 *blk, float2 *Ls, int w, int lane)
 {
     const float2 *row = blk + 64 * w;
 #pragma unroll
     for (int u = 0; u < 64; ++u) b[u >> 4][u & 15] = (row + 8192 * (u >> 5) + 256 * (u & 31))[(unsigned)lane];
     RD_SCHED_BARRIER();
-    float2 *cellw = Ls + F16K_PS * (lane & 3) + 16 * w + (lane >> 2);
-    const float2 *cellr = Ls + F16K_PS * w + lane;
+    float2 *cellw = Ls + deal_write_cell(F16K_PS, w, lane, 0);
+    const float2 *cellr = Ls + deal_read_cell(F16K_PS, w, lane, 0);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -1300,19 +1299,19 @@ __device__ __forceinline__ void f16k_deal_load(float2 (&a)[4][16], float2 (&b)[4
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                if (((j & 3) >> 1) == r) a[i][j] = cellr[1024 * (j & 1) + 256 * (j >> 2) + 64 * i]; // position 1024 (j & 3) + 256 (j >> 2) + 64 i + lane
+                if (f4k_reg_pos(i, j) / 2048 == r) a[i][j] = cellr[f4k_reg_pos(i, j) - 2048 * r];
         __syncthreads();
     }
 }
-// the same for 8192 points: a[d2][j] = position 64 (d2 + 4 (j >> 1) + 16 (j & 1)) + lane of the wave's sub-sequence; round = j & 1
+// the same for 8192 points: rounds of 4096 samples, 1024 positions per wave and round
 __device__ __forceinline__ void f8k_deal_load(float2 (&a)[4][8], float2 (&b)[2][16], const float2 *blk, float2 *Ls, int w, int lane)
 {
     const float2 *row = blk + 64 * w;
 #pragma unroll
     for (int u = 0; u < 32; ++u) b[u >> 4][u & 15] = (row + 4096 * (u >> 4) + 256 * (u & 15))[(unsigned)lane];
     RD_SCHED_BARRIER();
-    float2 *cellw = Ls + F8K_PS * (lane & 3) + 16 * w + (lane >> 2);
-    const float2 *cellr = Ls + F8K_PS * w + lane;
+    float2 *cellw = Ls + deal_write_cell(F8K_PS, w, lane, 0);
+    const float2 *cellr = Ls + deal_read_cell(F8K_PS, w, lane, 0);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -1322,7 +1321,7 @@ __device__ __forceinline__ void f8k_deal_load(float2 (&a)[4][8], float2 (&b)[2][
         for (int d2 = 0; d2 < 4; ++d2)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if ((j & 1) == r) a[d2][j] = cellr[64 * (d2 + 4 * (j >> 1))];
+                if (f2k_reg_pos(d2, j) / 1024 == r) a[d2][j] = cellr[f2k_reg_pos(d2, j) - 1024 * r];
         __syncthreads();
     }
 }

@@ -931,3 +931,52 @@ extern "C" int emu_pair_x5_bank_conflicts(void)
                 }
     return worst;
 }
+
+// ---- the four-wave kernels' input deal (fft_big_core.h deal_write_cell / deal_read_cell; fft_kernels.hip f16k_deal_load, f8k_deal_load) ----
+// Runs the two rounds for all four "wavefronts" on a block of n16k = 16384 or 8192 samples and checks that every register ends up with
+// sample 4 pos + q of the block; returns the number of wrong registers (0), or -1 when a cell is written twice in a round / lies outside the planes.
+extern "C" long emu_four_wave_deal(int nfft, const float2 *blk)
+{
+    const bool big = nfft == 16384;
+    const int PS = big ? F16K_PS : F8K_PS, round_samples = nfft / 2, loads = round_samples / 256, pos_per_round = round_samples / 4;
+    std::vector<float2> lds((size_t)4 * PS);
+    std::vector<char> seen((size_t)4 * PS);
+    long wrong = 0;
+    for (int r = 0; r < 2; ++r) {
+        for (auto &c : seen) c = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < loads; ++t) {
+                    const int cell = deal_write_cell(PS, w, lane, t);
+                    if (cell < 0 || cell >= 4 * PS || seen[(size_t)cell]) return -1;
+                    seen[(size_t)cell] = 1;
+                    lds[(size_t)cell] = blk[round_samples * r + 256 * t + 64 * w + lane];
+                }
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < (big ? 16 : 8); ++j) {
+                        const int pos = big ? f4k_reg_pos(i, j) : f2k_reg_pos(i, j);
+                        if (pos / pos_per_round != r) continue;
+                        const float2 got = lds[(size_t)deal_read_cell(PS, q, lane, pos - pos_per_round * r)], want = blk[4 * (pos + lane) + q];
+                        if (memcmp(&got, &want, sizeof got)) ++wrong;
+                    }
+    }
+    return wrong;
+}
+
+// worst number of 8-byte cells of one lane group that share a bank pair (1 = conflict free): ds_write_b64 groups of 16 consecutive lanes
+// and half-waves of 32 for the deal's writes, half-waves for its reads; 32 bank pairs
+extern "C" int emu_four_wave_deal_bank_conflicts(void)
+{
+    int worst = 1;
+    for (int PS : {F16K_PS, F8K_PS})
+        for (int w = 0; w < 4; ++w)
+            for (int grp : {16, 32})
+                for (int g0 = 0; g0 < 64; g0 += grp) {
+                    int wr[32] = {0}, rd[32] = {0};
+                    for (int l = g0; l < g0 + grp; ++l) { wr[deal_write_cell(PS, w, l, 3) % 32]++; rd[deal_read_cell(PS, w, l, 128) % 32]++; }
+                    for (int b = 0; b < 32; ++b) { worst = wr[b] > worst ? wr[b] : worst; worst = rd[b] > worst ? rd[b] : worst; }
+                }
+    return worst;
+}

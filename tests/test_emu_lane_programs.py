@@ -206,3 +206,15 @@ def test_pair_five_stage_passes(emu, oracle, lgn, inv):
 
 def test_pair_fifth_stage_image_is_bank_conflict_free(emu):
     assert emu.emu_pair_x5_bank_conflicts() == 1
+
+
+@pytest.mark.parametrize("nfft", [16384, 8192])
+def test_four_wave_deal(emu, oracle, nfft):
+    """fft16k_wave_kernel / fft8k_wave_kernel / ovsave8k_wave_kernel read their block in 512-byte runs and deal the samples to the four waves'
+    sub-sequences x[4 n + q] through LDS (fft_big_core.h deal_write_cell / deal_read_cell): every register gets its own sample, no cell is
+    written twice, and the writes (groups of 16 and of 32 lanes) and reads hit different bank pairs."""
+    import ctypes as C
+    x = oracle.synth_iq(0x16 + nfft, 0, nfft)
+    emu.emu_four_wave_deal.restype = C.c_long
+    assert emu.emu_four_wave_deal(C.c_int(nfft), x.ctypes.data_as(C.c_void_p)) == 0
+    assert emu.emu_four_wave_deal_bank_conflicts() == 1
