@@ -1279,6 +1279,9 @@ __global__ __launch_bounds__(256, 2) void ovsave4k_wave_kernel(const float2 *__r
 // start 16 banks apart and the 32 lanes of a half-wave (8 cells in each plane) write 64 different banks.  Round 4: 16384 points
 // 52.0 -> 55.5 %, 8192 points 57.8 -> 60.5 % (16384 fed contiguous rows of the wrong samples: 59.3 %); 8192-point overlap-save
 // 1.45 -> 1.43 ms, 16384-point overlap-save 1.63 -> 1.66 ms: kept on the strided reads (profiles/r04_four_wave_deal_loads.txt).
+#ifndef REDIO_F16K_TWO_IMAGES
+#define REDIO_F16K_TWO_IMAGES 1
+#endif
 #ifndef REDIO_OV16K_LDS_DEAL
 #define REDIO_OV16K_LDS_DEAL 0
 #endif
@@ -1343,10 +1346,13 @@ __global__ __launch_bounds__(256, 2) void fft16k_wave_kernel(const float2 *in, f
         RD_SCHED_BARRIER();
     }
     fft4k_wave_regs<INV>(a, b, TwProgram<4096, 1>{T}, Ls + w * F4W_REGION, lane);
-    float2 *X = Ls + 4 * F4W_REGION; // [q][1024]
+    // [q][1024]; two images alternate so that a round costs ONE barrier: the second one lies where the private images were (every wave is
+    // done with those before round 0's barrier), and a round's image is written again two rounds later, after the next round's barrier
+    static_assert(4 * F4W_REGION >= 4096, "the second image fits where the private ones were");
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (r) __syncthreads(); // the previous round has been read
+        float2 *X = REDIO_F16K_TWO_IMAGES && (r & 1) ? Ls : Ls + 4 * F4W_REGION;
+        if (!REDIO_F16K_TWO_IMAGES && r) __syncthreads(); // the previous round has been read
 #pragma unroll
         for (int j = 0; j < 16; ++j) X[1024 * w + 64 * j + lane] = a[r][j]; // j = d4 + 4 d5
         __syncthreads();
