@@ -1388,6 +1388,7 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
     float2 *X = Ls, *Y = Ls + 4096, *Lw = Ls + w * F4W_REGION;
     float2 a[4][16], b[4][16];
     static_assert(4 * F16K_PS <= 4096 + 4 * OV16W_YS, "the dealt planes fit");
+    static_assert(4 * OV16W_YS >= 4096, "the second image of the inverse last stage fits the product image");
     if (REDIO_OV16K_LDS_DEAL) f16k_deal_load(a, b, x + (long)blockIdx.x * hop, Ls, w, lane); // measured: 1.655 against 1.631 ms (127 taps): not adopted here
     else {
 #pragma unroll
@@ -1427,10 +1428,11 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
     fft4k_wave_regs<true>(b, a, TwProgram<4096, 1>{Ti}, Lw, lane_i);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { // d3 = r, as in fft16k_wave_kernel
-        if (r) __syncthreads();
+    for (int r = 0; r < 4; ++r) { // d3 = r, as in fft16k_wave_kernel: the rounds alternate between the two images, one barrier each
+        float2 *Xr = REDIO_F16K_TWO_IMAGES && (r & 1) ? Y : X;
+        if (!REDIO_F16K_TWO_IMAGES && r) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) X[1024 * w + 64 * j + lane_i] = b[r][j];
+        for (int j = 0; j < 16; ++j) Xr[1024 * w + 64 * j + lane_i] = b[r][j];
         __syncthreads();
 #pragma unroll
         for (int d4 = 0; d4 < 4; ++d4) {
@@ -1438,7 +1440,7 @@ __global__ __launch_bounds__(256, 2) void ovsave16k_wave_kernel(const float2 *__
             const unsigned k = 1024u * w + 256u * d4 + 64u * r + lane_i;
             float2 f[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) f[q] = X[1024 * q + 64 * jj + lane_i];
+            for (int q = 0; q < 4; ++q) f[q] = Xr[1024 * q + 64 * jj + lane_i];
             const TwOrdered lsti = tw_ordered_stage(Ti, 1u, 6);
             bfly4<true>(f[0], f[1], f[2], f[3], lsti.get(1, k), lsti.get(2, k), lsti.get(3, k));
 #pragma unroll
