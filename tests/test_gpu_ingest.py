@@ -178,3 +178,21 @@ def test_chain_from_u8_bytes_full_size(gpu, redio):
     del x
     assert got.shape == want.shape == (plan.nblocks(n), 1024)
     assert gpu.equal(gpu.view_as_real(got).view(gpu.int32), gpu.view_as_real(want).view(gpu.int32))
+
+
+def test_trigger_buffer_reset_past_25_6_million_samples(gpu, redio, oracle):
+    """bitfount.rs:52-54: a buffer that has grown past 1000 * 50 * 512 samples is dropped and restarts as vec!(0.0).  One quiet block, then
+    50 010 loud ones (every one re-arms the 50-block counter), then silence until the counter runs out: the emitted buffer is what was
+    collected AFTER the reset -- same length, same bits as the reference walk; fed in three calls that cut inside the run."""
+    nb, bl = 50010 + 70, 512
+    blocks = np.full((nb, bl), 1e-4, np.float32)
+    blocks[1:50011] = (0.5 + 0.25 * np.sin(np.arange(bl, dtype=np.float32)))[None, :]
+    blocks[1:50011, 0] += (np.arange(50010) % 7).astype(np.float32) * 0.125      # the blocks differ: a misplaced one shows
+    dev, ref = redio.bitfount.Trigger(), oracle.Trigger()
+    got, want = [], []
+    for lo, hi in ((0, 20000), (20000, 50005), (50005, nb)):
+        got += [g.cpu().numpy() for g in dev.feed(gpu.from_numpy(blocks[lo:hi]).cuda())]
+        want += ref.feed(blocks[lo:hi])
+    assert len(want) == 1 and len(got) == 1
+    assert 1 < len(want[0]) < 1000 * 50 * 512 and want[0][0] == 0.0              # restarted once, then collected to the end of the burst
+    assert len(got[0]) == len(want[0]) and np.array_equal(bits(got[0]), bits(want[0]))
