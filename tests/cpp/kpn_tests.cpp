@@ -5,6 +5,8 @@
 //   kpn_tests resample in.bin out.bin ratio msg_len   samplerate::resample block over raw f32 messages
 #include "../../include/kpn.hpp"
 #include "../../include/wavio.hpp"
+#include <sstream>
+#include <iostream>
 #include "../../include/kpn_dev.hpp"
 #include <atomic>
 #include <chrono>
@@ -163,6 +165,46 @@ static int plumbing()
         feed<std::optional<int>>(std::move(m), {1, std::nullopt, 2});
         t6.join();
         CHECK((drain(nr) == std::vector<int>{1, 2}));
+    }
+    { // the remaining map / plumbing blocks: applicator_vecs, cross_applicator_vecs, delay_vecs, looper, soft_source, print_sink
+        auto [a, ar] = channel<std::vector<int>>(); auto [b, br] = channel<std::vector<int>>();
+        auto t = spawn([&, r = std::move(ar), s = std::move(b)]() mutable { applicator_vecs<int>(std::move(r), std::move(s), [](const int &x) { return x * x; }); });
+        feed<std::vector<int>>(std::move(a), {{1, 2, 3}, {}, {4}});
+        t.join();
+        auto o = drain(br);
+        CHECK(o.size() == 3 && o[0] == (std::vector<int>{1, 4, 9}) && o[1].empty() && o[2] == (std::vector<int>{16}));   // kpn.rs:134-138
+        auto [c, cr] = channel<std::vector<int>>(); auto [d, dr] = channel<std::vector<double>>();
+        auto t2 = spawn([&, r = std::move(cr), s = std::move(d)]() mutable { cross_applicator_vecs<int, double>(std::move(r), std::move(s), [](const int &x) { return 0.5 * x; }); });
+        feed<std::vector<int>>(std::move(c), {{1, 2}, {3}});
+        t2.join();
+        auto o2 = drain(dr);
+        CHECK(o2.size() == 2 && o2[0] == (std::vector<double>{0.5, 1.0}) && o2[1] == (std::vector<double>{1.5}));          // kpn.rs:170-174
+        auto [e, er] = channel<std::vector<int>>(); auto [g, gr] = channel<std::vector<int>>();
+        auto t3 = spawn([&, r = std::move(er), s = std::move(g)]() mutable { delay_vecs<std::vector<int>>(std::move(r), std::move(s), std::vector<int>{7, 7}); });
+        feed<std::vector<int>>(std::move(e), {{1}, {2, 3}});
+        t3.join();
+        auto o3 = drain(gr);
+        CHECK(o3.size() == 3 && o3[0] == (std::vector<int>{7, 7}) && o3[2] == (std::vector<int>{2, 3}));                 // kpn.rs:261-263: the constant first
+        auto [h, hr] = channel<int>(); auto [k, kr] = channel<long>();
+        auto t4 = spawn([&, r = std::move(hr), s = std::move(k)]() mutable {
+            looper<int, long>(std::move(r), std::move(s), [](Receiver<int> &in, Sender<long> &out) { long acc = 0; for (;;) { acc += in.recv(); out.send_unwrap(acc); } });
+        });
+        feed<int>(std::move(h), {1, 2, 3, 4});
+        t4.join();
+        CHECK((drain(kr) == std::vector<long>{1, 3, 6, 10}));                                                             // kpn.rs:148-150: the closure owns the stream
+        auto [m, mr] = channel<int>();
+        // kpn.rs:141-145: the closure runs, then the block parks FOREVER so that its sender never hangs up -- the thread is detached, not joined
+        std::thread([s = std::move(m)]() mutable { soft_source<int>(std::move(s), [](Sender<int> &v) { for (int i = 0; i < 3; ++i) v.send(i); }); }).detach();
+        CHECK(mr.recv() == 0 && mr.recv() == 1 && mr.recv() == 2);
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        CHECK(!mr.try_recv());   // nothing more, and no hang-up either: a recv() here would block, as downstream of the reference's source
+        auto [p, pr] = channel<int>();
+        std::ostringstream cap; auto *old = std::cout.rdbuf(cap.rdbuf());
+        auto t6 = spawn([&, r = std::move(pr)]() mutable { print_sink<int>(std::move(r)); });
+        feed<int>(std::move(p), {5, 6});
+        t6.join();
+        std::cout.rdbuf(old);
+        CHECK(cap.str() == "5\n6\n");                                                                                    // kpn.rs:104-108: println per item
     }
     { // sum_across / mul_across / sum_across_vecs
         auto [a, ar] = channel<float>(); auto [b, br] = channel<float>(); auto [o, orx] = channel<float>();
