@@ -38,7 +38,7 @@ def read_wav_f32(path):
 
 
 def test_plumbing_blocks_cpu(exe):
-    out = subprocess.run([exe, "plumbing"], capture_output=True, text=True)
+    out = subprocess.run([exe, "plumbing"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stderr
 
 
@@ -47,7 +47,7 @@ def test_hot_blocks_fail_loudly_without_gpu(exe, tmp_path):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     write_wav_f32(tmp_path / "in.wav", np.zeros(2048, np.float32), 48000)
-    out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True)
+    out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True, timeout=900)
     # convolve has no CPU path: the block dies with the library's error, nothing is computed on the host
     assert not os.path.exists(tmp_path / "out.wav") or len(read_wav_f32(tmp_path / "out.wav")) == 0
 
@@ -59,7 +59,7 @@ def test_config1_wav_fir_wav(exe, gpu, oracle, tmp_path):
     n = 1 << 16
     x = oracle.synth_f32(0x5EED0001, 0, n + 300)  # 300 trailing samples do not fill a block: dropped by shaper
     write_wav_f32(tmp_path / "in.wav", x, 48000)
-    out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True)
+    out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     y = read_wav_f32(tmp_path / "out.wav")
     taps = oracle.lpf_corrected(63, 0.1)
@@ -74,7 +74,7 @@ def test_config1_wav_fir_wav(exe, gpu, oracle, tmp_path):
 def test_kissfft_block_in_cpp_graph(exe, gpu, oracle, tmp_path, n, inv):
     x = oracle.synth_iq(3, 0, n * 6 + 5)
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "fft", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(n), str(inv)], capture_output=True, text=True)
+    out = subprocess.run([exe, "fft", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(n), str(inv)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     y = np.fromfile(tmp_path / "out.bin", dtype=np.complex64)
     assert np.array_equal(bits(y), bits(oracle.fft(x[: n * 6], n, bool(inv))))
@@ -84,7 +84,7 @@ def test_kissfft_block_in_cpp_graph(exe, gpu, oracle, tmp_path, n, inv):
 def test_resample_block_in_cpp_graph(exe, gpu, oracle, tmp_path):
     x = oracle.synth_f32(5, 0, 30000)
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "resample", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0.5", "7000"], capture_output=True, text=True)
+    out = subprocess.run([exe, "resample", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0.5", "7000"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     ref = oracle.Resampler(1)
@@ -99,7 +99,7 @@ def test_device_resident_graph_fork_chain_and_fir(exe, gpu, oracle, tmp_path):
     x = oracle.synth_iq(0x5EED0002, 0, 3 * msg)
     x.tofile(tmp_path / "in.bin")
     out = subprocess.run([exe, "devchain", str(tmp_path / "in.bin"), str(tmp_path / "spec.bin"), str(tmp_path / "fir.bin"), str(msg)],
-                         capture_output=True, text=True)
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     taps = oracle.lpf_corrected(127, 0.08)
     spec = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
@@ -118,7 +118,7 @@ def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tm
     x = oracle.synth_iq(0x5EED0002, 0, n)
     x.tofile(tmp_path / "in.bin")
     out = subprocess.run([exe, "devstream", str(tmp_path / "in.bin"), str(tmp_path / "spec.bin"), str(tmp_path / "fir.bin"),
-                          str(tmp_path / "ovs.bin"), str(seed)], capture_output=True, text=True)
+                          str(tmp_path / "ovs.bin"), str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     taps = oracle.lpf_corrected(127, 0.08)
     spec = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
@@ -137,7 +137,7 @@ def test_byte_messages_through_the_one_kernel_chain_block(exe, gpu, oracle, tmp_
     msg = 2 * (5 * 1024 * 6 + 122 + 777)           # six blocks and a ragged tail per message
     raw = np.random.default_rng(3).integers(0, 256, 3 * msg + 2 * (5 * 1024 + 122), dtype=np.uint8)
     raw.tofile(tmp_path / "raw.bin")
-    out = subprocess.run([exe, "devbytes", str(tmp_path / "raw.bin"), str(tmp_path / "spec.bin"), str(msg)], capture_output=True, text=True)
+    out = subprocess.run([exe, "devbytes", str(tmp_path / "raw.bin"), str(tmp_path / "spec.bin"), str(msg)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     taps = oracle.lpf_corrected(127, 0.08)
     want = np.concatenate([oracle.chain_fir_fft(oracle.data_to_samples(raw[o:o + msg]), taps, 5, 1024, True).reshape(-1)
@@ -154,7 +154,7 @@ def test_sharded_channelizer_from_one_cpp_process(exe, gpu, oracle, tmp_path):
     M, P, rows = 64, 16, 3001
     x = oracle.synth_iq(0x5EED0004, 0, M * rows)
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "devc4", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0"], capture_output=True, text=True)
+    out = subprocess.run([exe, "devc4", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "0"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     ndev = int(out.stdout.split("devices")[1].split()[0])
     want = oracle.pfb_channelizer(x, oracle.lpf_corrected(M * P, 0.45 / M), M, P, True)
@@ -168,7 +168,7 @@ def test_sharded_channelizer_from_one_cpp_process(exe, gpu, oracle, tmp_path):
 def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
     x = oracle.synth_f32(3, 0, 10000)
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "devshaper", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "3000", "1024"], capture_output=True, text=True)
+    out = subprocess.run([exe, "devshaper", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "3000", "1024"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     assert np.array_equal(bits(y), bits(x[: (10000 // 1024) * 1024]))   # the trailing partial chunk is dropped (kpn.rs:278-282)
@@ -180,7 +180,7 @@ def test_device_vector_maps_and_resampler_blocks(exe, gpu, oracle, tmp_path):
     msg, ratio = 4000, 0.5
     x = oracle.synth_f32(21, 0, 5 * msg + 123)          # the last message is short: zip truncates to it
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "devmix", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(msg), str(ratio)], capture_output=True, text=True)
+    out = subprocess.run([exe, "devmix", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(msg), str(ratio)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     i = np.arange(msg)
     c = ((i % 7).astype(np.float32) * np.float32(0.25) - np.float32(0.5)).astype(np.float32)
@@ -199,7 +199,7 @@ def test_device_channelizer_and_overlap_save_blocks(exe, gpu, oracle, tmp_path):
     x = oracle.synth_iq(22, 0, 2 * msg)
     x.tofile(tmp_path / "in.bin")
     out = subprocess.run([exe, "devbank", str(tmp_path / "in.bin"), str(tmp_path / "pfb.bin"), str(tmp_path / "ovs.bin"), str(msg)],
-                         capture_output=True, text=True)
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     proto, taps = oracle.lpf_corrected(64 * 16, 0.45 / 64), oracle.lpf_corrected(127, 0.08)
     want_pfb = np.concatenate([oracle.pfb_channelizer(x[i * msg:(i + 1) * msg], proto, 64, 16, True).reshape(-1) for i in range(2)])
