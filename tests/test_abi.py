@@ -121,3 +121,46 @@ def test_oracle_is_test_infrastructure_only():
     bench = open(os.path.join(root, "bench.py")).read()
     body = bench[bench.index("def cpu_baseline"): bench.index("def main")]
     assert bench.count("import oracle") == 1 and "import oracle" in body      # bench.py: the cpu_baseline leg only
+
+
+def test_public_headers_are_plain_c_and_a_c_program_links(redio, tmp_path):
+    """The boundary is a C ABI (plain pointers and sizes): the three public headers compile as C99 and as C++17 under -pedantic, and a C
+    program that includes all of them links against the three libraries and runs the calls that need no GPU."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for h in ("redio.h", "kiss_fft.h", "samplerate.h"):
+        for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++17", "c++")):
+            r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", lang, os.path.join(inc, h)],
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, (h, cc, r.stderr)
+    src = tmp_path / "link.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "redio.h"
+#include "kiss_fft.h"
+#include "samplerate.h"
+int main(void)
+{
+    float w[5], out[3];
+    size_t n = 0;
+    const float u[4] = {1.f, 2.f, 3.f, 4.f}, v[2] = {0.5f, 0.25f};
+    if (!redio_version() || !redio_strerror(-1)) return 1;
+    if (redio_window(4, w) != 0) return 2;                       /* host-side generators need no device */
+    if (redio_fir_create(NULL, v, 2, 1, 0) >= 0) return 3;       /* argument errors come back as codes */
+    if (src_is_valid_ratio(0.02) != 1 || src_is_valid_ratio(1e6) != 0) return 4;
+    if (!src_strerror(6) || !src_get_name(1) || src_get_name(9)) return 5;
+    if (kiss_fft_next_fast_size(17) != 18) return 6;
+    if (sizeof(SRC_DATA) != 64) return 7;                        /* samplerate.rs:15-24 on LP64 */
+    (void)u; (void)out; (void)n;
+    puts("c link ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "link"
+    bdir = os.path.dirname(redio.LIBREDIO)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe), "-L", bdir, "-lredio", "-lkissfft", "-lsamplerate",
+                        f"-Wl,-rpath,{bdir}"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c link ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
