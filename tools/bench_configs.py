@@ -5,9 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, libredio_amd as R
 
 
-def timeit(f, n=50, warm=10):
+def timeit(f, n=50, warm=10, warm_ms=100.0):
+    """mean of n launches after `warm` launches AND at least warm_ms of back-to-back work: the chip raises its clock over the first
+    50-100 ms of a burst (profiles/r02_clock_probe.txt; bench.py pre-conditions its line the same way, disclosed there), and a line
+    timed inside that ramp reads 3-15 % low"""
+    import time
     for _ in range(warm): f()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < warm_ms:
+        for _ in range(4): f()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): f()
