@@ -2346,7 +2346,10 @@ static bool fftbig_plan_b(int lgN, BigPlanB &p)
     case 18: p = {4, 1, {5, 0}, 0}; return true;
     case 19: p = {2, 1, {5, 0}, 2}; return true;
     case 20: p = {5, 1, {5, 0}, 0}; return true;
-    // (2^22 as 5 + 5 + 1 was the faster plan until the four-stage pass got its interleaved twiddle copy: 4 + 4 + 3 now wins, 84 against 80 GS/s)
+    // (2^22 as 5 + 5 + 1 was the faster plan until the four-stage pass got its interleaved twiddle copy; re-measured in round 4 with the pair-form
+    // five-stage passes: 0.720 against 0.705 ms per 2^26 points, and 2^24 as 5 + 5 + 2 0.879 against 0.690 -- profiles/r04_plan_b_large_sizes_null.txt)
+    case 22: if (measure_env("REDIO_FFT_PLAN_B_22")) { p = {5, 1, {5, 0}, 1}; return true; } return false; // measurement: 5 + 5 + 1 against 4 + 4 + 3
+    case 24: if (measure_env("REDIO_FFT_PLAN_B_24")) { p = {5, 1, {5, 0}, 2}; return true; } return false; // measurement: 5 + 5 + 2 against 4 + 4 + 4
     case 23: p = {2, 2, {5, 4}, 0}; return true;
     default: return false;
     }
