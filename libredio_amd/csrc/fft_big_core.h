@@ -414,6 +414,41 @@ RD_HD constexpr long pw_first5_st(int L, int qq, int sp, int x, int n, int j)
 }
 
 
+// =============================================================================================================================
+// G512 (lane program and CPU emulation this round; the device kernel is next): the gather pass of N = 2 * 4^L' points with FIVE stages --
+// G128's four and the radix-4 stage of sub-length 128 -- on tiles of 512 rows x 32 source columns, one workgroup of four wavefronts per
+// tile.  Leaf position P = 512 h + (b0 + 2 d1 + 8 d2 + 32 d3 + 128 d4) holds input n = column + S5 (d4 + 4 d3 + 16 d2 + 64 d1 + 256 b0),
+// S5 = N / 512, h = digit reversal of the column: wavefront n = d4 runs the G128 program on the columns shifted by S5 n (its row stride
+// N / 128 is 4 S5), then the fifth stage combines position p of the four wavefronts with the twiddles n k N / 512, k = p.  With this pass
+// 2^19 points are TWO passes (this one and a five-stage in-place pass on rows 512 apart) instead of three.
+// The regrouping reuses the five-stage passes' workgroup image and unit map (pw_unit_x5, conflict-free both ways): round (r, xh) moves
+// b[r][2 xh + xl][.][d3] as unit jj = 4 xl + d3 of lane (cp = kp, q = cg); wavefront w reads jj = 2 w, 2 w + 1 of the four wavefronts.
+// After phase B of G128 the two images can both lie where the four wave-private G128 images were (4 x 16 KiB >= 2 x 32 KiB).
+// =============================================================================================================================
+constexpr int PW_G5_TABLE = PW_G_TABLE + 3 * 128; // G128's 128 entries, then the ordered copy of sub-length 128: [128 + (n - 1) 128 + k] = tw[n k N / 512]
+RD_HD void pw_g5_table_entry(const float2 *tw, unsigned N, int i, float2 &out)
+{
+    if (i < PW_G_TABLE) { pw_g_table_entry(tw, N, i, out); return; }
+    const int r = i - PW_G_TABLE, n = r / 128 + 1, k = r % 128;
+    out = tw[(size_t)n * k * (N / 512u)];
+}
+template <int R, int XH>
+RD_HD void pw_g5_write(const float2 (&b)[2][4][2][4], float4 *Xi, int lane, int n)
+{
+    const int kp = lane & 7, cg = lane >> 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jj = 0; jj < 8; ++jj) {
+        const float2 v0 = b[R][2 * XH + (jj >> 2)][0][jj & 3], v1 = b[R][2 * XH + (jj >> 2)][1][jj & 3];
+        Xi[pw_unit_x5(n, cg, jj, kp)] = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+}
+// what wavefront w holds after pw_x5_read in round (r, xh): v[jp][n][e] = position 16 r + 2 kp + e + 32 d3 of column cg + 8 x, quarter n
+RD_HD constexpr int pw_g5_x(int xh, int w) { return 2 * xh + (w >> 1); }
+RD_HD constexpr int pw_g5_d3(int w, int jp) { return 2 * (w & 1) + jp; }
+RD_HD constexpr unsigned pw_g5_k0(int r, int kp, int w) { return (unsigned)(16 * r + 2 * kp + 32 * pw_g5_d3(w, 0)); } // twiddle index of jp = 0, e = 0; jp adds 32
+
 // ---- input of the four-wave kernels (16384 = 4 x 4096, 8192 = 4 x 2048 points; fft_kernels.hip f16k_deal_load / f8k_deal_load) ---------
 // Wave q transforms x[4 n + q].  The four waves read a round (half a block) in 512-byte runs -- wave w, load t: samples 256 t + 64 w + lane
 // of the round -- and DEAL them through LDS: sample e = 4 n + q goes to plane q, cell n; wave q then reads its positions lane-contiguous.

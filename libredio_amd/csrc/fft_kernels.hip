@@ -1716,6 +1716,18 @@ __global__ __launch_bounds__(256, 2) void fftbig_g128_kernel(const float2 *in, f
     const unsigned ctile = (unsigned)(tile & ((1u << (lgN - 12)) - 1)); // source columns 32 ctile .. + 31
     pw_g128_tile<INV, MULH>(in + xf * in_stride, out + xf * (long)(1u << lgN), lgN, ctile, lane, Lg + w * PW_G_UNITS, mulH, Tg);
 }
+// G512 gather pass (round 4; fft_pair.h pw_g512_tile): one workgroup of four wavefronts per tile of 512 source rows x 32 source columns
+template <bool INV>
+__global__ __launch_bounds__(256, 2) void fftbig_g512_kernel(const float2 *in, float2 *out, long in_stride, long ngroups, int lgN, const float2 *__restrict__ Tg5)
+{
+    __shared__ float4 Lg[4 * PW_G_UNITS];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long group = f64w_first_tile() >> 2;
+    if (group >= ngroups) return; // whole workgroup
+    const long xf = group >> (lgN - 14);
+    const unsigned ctile = (unsigned)(group & ((1u << (lgN - 14)) - 1));
+    pw_g512_tile<INV>(in + xf * in_stride, out + xf * (long)(1u << lgN), lgN, ctile, lane, w, Lg, Tg5);
+}
 // overlap-save with 32768-point blocks, middle pass (fft_pair.h): eight tiles of 256 rows x 16 columns per block
 __global__ __launch_bounds__(256, 2) void ovsave32k_mid_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ b_out, const float2 *__restrict__ Tf,
                                                             const float2 *__restrict__ Tgi, const float2 *__restrict__ Hc, long ntiles)
@@ -2381,6 +2393,11 @@ static bool fftbig_plan_g(int lgN)
 }
 // after G128 (rows 128 apart): `left` radix-4 stages to go = 4 (2^15: one four-stage pass), 5 (2^17: one five-stage pass), 6 (2^19: four-stage
 // pass + two register-only stages), 7 (2^21: four + three), 8 (2^23: two four-stage passes)
+// Plan G5 (round 4): 2^19 points as TWO passes -- the five-stage gather pass G512 and ONE five-stage in-place pass on rows 512 apart -- for the
+// stand-alone transform (the overlap-save entry, with its spectrum product and masked store, keeps plan G).  Its tables (G128's copy extended by
+// the sub-length-128 stage, then the in-place pass's ordered copy) follow plan G's at the very end.
+static bool fftbig_plan_g5(int lgN) { return REDIO_TILE_PAIR && lgN == 19 && !measure_env("REDIO_FFT_NO_PLAN_G5"); }
+static size_t fftbig_g5_elems(int lgN) { return fftbig_plan_g5(lgN) ? (size_t)PW_G5_TABLE + ((size_t)1023 << 9) : 0; }
 static size_t fftbig_g_elems(int lgN)
 {
     if (!fftbig_plan_g(lgN)) return 0;
@@ -2388,7 +2405,7 @@ static size_t fftbig_g_elems(int lgN)
     size_t n = (size_t)PW_G_TABLE + ((size_t)(left == 5 ? 1023 : FFTBIG_MID4_ELEMS) << 7);
     if (left == 7) n += (size_t)15 << (lgN - 6);
     if (left == 8) n += (size_t)FFTBIG_MID4_ELEMS << 15;
-    return n;
+    return n + fftbig_g5_elems(lgN);
 }
 static void fftbig_after_first(int lgN, int &lm, int &left)
 {
@@ -2415,6 +2432,12 @@ __global__ __launch_bounds__(128) void fftbig_g_table_kernel(const float2 *__res
 {
     float2 v;
     pw_g_table_entry(tw, N, (int)threadIdx.x, v);
+    T[threadIdx.x] = v;
+}
+__global__ __launch_bounds__(512) void fftbig_g5_table_kernel(const float2 *__restrict__ tw, float2 *__restrict__ T, unsigned N)
+{
+    float2 v;
+    pw_g5_table_entry(tw, N, (int)threadIdx.x, v);
     T[threadIdx.x] = v;
 }
 hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipStream_t s)
@@ -2463,8 +2486,14 @@ hipError_t fftbig_tables_build(const float2 *tw, float2 *tables, int nfft, hipSt
         T += PW_G_TABLE;
         hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << 7, left == 5 ? 5 : 4, (unsigned)nfft);
         T += (size_t)(left == 5 ? 1023 : FFTBIG_MID4_ELEMS) << 7;
-        if (left == 7) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft);
-        if (left == 8) hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << 15, 4, (unsigned)nfft);
+        if (left == 7) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << (lgN - 6), 2, (unsigned)nfft); T += (size_t)15 << (lgN - 6); }
+        if (left == 8) { hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << 15, 4, (unsigned)nfft); T += (size_t)FFTBIG_MID4_ELEMS << 15; }
+        if (fftbig_plan_g5(lgN)) {
+            static_assert(PW_G5_TABLE == 512, "one thread per entry");
+            hipLaunchKernelGGL(fftbig_g5_table_kernel, dim3(1), dim3(512), 0, s, tw, T, (unsigned)nfft);
+            T += PW_G5_TABLE;
+            hipLaunchKernelGGL(fftbig_tables_kernel, dim3(2048), dim3(256), 0, s, tw, T, 1u << 9, 5, (unsigned)nfft);
+        }
     }
     return hipGetLastError();
 }
@@ -2484,6 +2513,13 @@ static hipError_t launch_fftbig(const float2 *in, float2 *out, const float2 *tw,
     int rev = 0; // direction of the pass before (the gather pass walks forward)
     const unsigned grid = (unsigned)((ntiles + 3) / 4);
     const float2 *T1 = fftbig_first_elems(lgN) ? tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN) - fftbig_first_elems(lgN)) : nullptr;
+    if (fftbig_plan_g5(lgN) && !mulH && !vout) { // G512, then ONE five-stage in-place pass on rows 512 apart
+        const float2 *Tg5 = tables + (fftbig_tables_elems(1 << lgN) - fftbig_g5_elems(lgN)), *Tm5 = Tg5 + PW_G5_TABLE;
+        const long ngroups = nbatch << (lgN - 14);
+        hipLaunchKernelGGL(fftbig_g512_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, in, out, in_stride, ngroups, lgN, Tg5);
+        hipLaunchKernelGGL(fftbig_mid5_kernel<INV>, dim3((unsigned)ngroups), dim3(256), 0, s, out, Tm5, ngroups, lgN, 9, (float2 *)nullptr, 0l, 1.0f, 1);
+        return hipGetLastError();
+    }
     if (fftbig_plan_g(lgN)) { // G128, then in-place passes on rows 128 (and 32768) apart
         const float2 *Tg = tables + (fftbig_tables_elems(1 << lgN) - fftbig_g_elems(lgN)), *Tm = Tg + PW_G_TABLE;
         const int left = (lgN - 7) / 2;

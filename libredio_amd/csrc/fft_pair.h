@@ -411,6 +411,53 @@ __device__ __forceinline__ void pw_g128_tile(const float2 *in_blk, float2 *out_b
             for (int d3 = 0; d3 < 4; ++d3) pw_st((dst + pw_g_st(nd, 0, 0, x, r, d3)) + lo_dst, b[r][x][0][d3], b[r][x][1][d3]);
 }
 
+// ---- G512: G128 on the four wavefronts of a workgroup (source columns N / 512 apart), then the radix-4 stage of sub-length 128 across them --
+// (fft_big_core.h; run lane by lane on the CPU in tests/emu: test_pair_g512_gather_pass).  Lg: the four wave-private G128 images; once every
+// wavefront is through phase B the fifth stage's two alternating images lie in the same 64 KiB.
+template <bool INV>
+__device__ __forceinline__ void pw_g512_tile(const float2 *in_blk, float2 *out_blk, int lgN, unsigned ctile, int lane, int w, float4 *Lg,
+                                             const float2 *__restrict__ Tg5)
+{
+    static_assert(4 * PW_G_UNITS >= 2 * PW_X5_UNITS, "the fifth stage's images fit where the G128 images were");
+    const long S5 = 1l << (lgN - 9), S = 4 * S5;
+    const int nd = (lgN - 9) / 2; // base-4 digits of a source column (N / 512 of them)
+    const int cp = lane & 15, q = lane >> 4;
+    const float2 *src = in_blk + 32 * ctile + S5 * w;
+    float2 a[2][4][8], b[2][4][2][4];
+    const unsigned lo_src = (unsigned)pw_g_ld(S, q, cp, 0, 0);
+#pragma unroll
+    for (int d2 = 0; d2 < 4; ++d2)
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            const float4 v = pw_ld_once((src + pw_g_ld(S, 0, 0, d2, jb)) + lo_src);
+            a[0][d2][jb] = make_float2(v.x, v.y); a[1][d2][jb] = make_float2(v.z, v.w);
+        }
+    RD_SCHED_BARRIER();
+    pw_g128_stages<INV>(a, b, Tg5, Lg + w * PW_G_UNITS, lane);
+    __syncthreads(); // every wavefront is done with its private image
+    const int kp = lane & 7, cg = lane >> 3;
+    unsigned hc = 0; // digits of ctile >> 1 reversed (nd - 3 of them)
+    for (int d = 0, cc = (int)(ctile >> 1); d < nd - 3; ++d, cc >>= 2) hc = (hc << 2) | (cc & 3);
+    // column 32 ctile + cg + 8 x has the base-4 digits cg & 3 | (cg >> 2) + 2 (x & 1) | (x >> 1) + 2 (ctile & 1) | ctile >> 1: reversed, times 512
+    float2 *dst0 = out_blk + 512l * (((long)(cg & 3) << (2 * (nd - 1))) + ((long)(cg >> 2) << (2 * (nd - 2))) + ((long)(2 * (ctile & 1)) << (2 * (nd - 3))) + hc) + 2 * kp;
+    const TwPairOrderedT<false> t5{Tg5 + PW_G_TABLE, 128u};
+#define REDIO_G5_ROUND(RR, XH)                                                                                                          \
+    {                                                                                                                                   \
+        float4 *Xi = Lg + ((((2 * RR + XH) & 1) != 0) ? PW_X5_UNITS : 0);                                                               \
+        pw_g5_write<RR, XH>(b, Xi, lane, w);                                                                                            \
+        __syncthreads();                                                                                                                \
+        float2 v[2][4][2];                                                                                                              \
+        pw_x5_read(v, Xi, lane, w);                                                                                                     \
+        pw_x5_stage<INV>(v, t5, pw_g5_k0(RR, kp, w), 32u);                                                                              \
+        const int x = pw_g5_x(XH, w);                                                                                                   \
+        float2 *dst = dst0 + 512l * (((long)(2 * (x & 1)) << (2 * (nd - 2))) + ((long)(x >> 1) << (2 * (nd - 3)))) + 16 * RR;           \
+        _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                                \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) pw_st(dst + 32 * pw_g5_d3(w, jp) + 128 * u, v[jp][u][0], v[jp][u][1]);        \
+    }
+    REDIO_G5_ROUND(0, 0) REDIO_G5_ROUND(0, 1) REDIO_G5_ROUND(1, 0) REDIO_G5_ROUND(1, 1)
+#undef REDIO_G5_ROUND
+}
+
 // ---- overlap-save, 32768-point blocks: the 65536-point scheme with this gather pass ------------------------------------------------------
 // middle pass: the forward in-place pass (rows 128 apart), x conj H, and the INVERSE transform's G128 pass on the same tile.  After
 // the forward stages lane (cp, q) holds rows s + 16 j, s = q + 8 x, of tile columns 2 cp + e, i.e. spectrum positions

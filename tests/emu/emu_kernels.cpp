@@ -980,3 +980,70 @@ extern "C" int emu_four_wave_deal_bank_conflicts(void)
                 }
     return worst;
 }
+
+// ---- G512: G128 on four "wavefronts" + the radix-4 stage of sub-length 128 across them (fft_big_core.h; lane program only this round) ----
+namespace {
+template <bool INV> void g512_tile(const float2 *in_blk, float2 *out_blk, int lgN, unsigned ctile, const float2 *Tg5, std::vector<float4> &img, std::vector<float4> &X)
+{
+    const long S5 = 1l << (lgN - 9), S = 4 * S5;
+    const int nd = (lgN - 9) / 2; // base-4 digits of the N / 512 source columns
+    std::vector<GLane> L[4];
+    for (int n = 0; n < 4; ++n) {
+        L[n].resize(64);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int cp = lane & 15, q = lane >> 4;
+            for (int d2 = 0; d2 < 4; ++d2)
+                for (int jb = 0; jb < 8; ++jb) {
+                    const float2 *p = in_blk + S5 * n + 32 * ctile + pw_g_ld(S, 0, 0, d2, jb) + pw_g_ld(S, q, cp, 0, 0);
+                    L[n][lane].a[0][d2][jb] = p[0]; L[n][lane].a[1][d2][jb] = p[1];
+                }
+        }
+        g128_stages<INV>(L[n], Tg5, img);
+    }
+    auto rev = [&](unsigned col) { unsigned h = 0; for (int d = 0; d < nd; ++d, col >>= 2) h = (h << 2) | (col & 3); return h; };
+    const TwPairOrderedT<false> t5{Tg5 + PW_G_TABLE, 128u};
+    auto round = [&](auto wr, int r, int xh) {
+        for (int n = 0; n < 4; ++n)
+            for (int lane = 0; lane < 64; ++lane) wr(L[n][lane].b, X.data(), lane, n);
+        for (int w = 0; w < 4; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                float2 v[2][4][2];
+                pw_x5_read(v, X.data(), lane, w);
+                const int kp = lane & 7, cg = lane >> 3, x = pw_g5_x(xh, w);
+                pw_x5_stage<INV>(v, t5, pw_g5_k0(r, kp, w), 32u);
+                const unsigned col = 32u * ctile + (unsigned)(cg + 8 * x);
+                for (int jp = 0; jp < 2; ++jp)
+                    for (int u = 0; u < 4; ++u)
+                        for (int e = 0; e < 2; ++e)
+                            out_blk[512l * rev(col) + 16 * r + 2 * kp + e + 32 * pw_g5_d3(w, jp) + 128 * u] = v[jp][u][e];
+            }
+    };
+    round([](auto &b, float4 *Xi, int lane, int n) { pw_g5_write<0, 0>(b, Xi, lane, n); }, 0, 0);
+    round([](auto &b, float4 *Xi, int lane, int n) { pw_g5_write<0, 1>(b, Xi, lane, n); }, 0, 1);
+    round([](auto &b, float4 *Xi, int lane, int n) { pw_g5_write<1, 0>(b, Xi, lane, n); }, 1, 0);
+    round([](auto &b, float4 *Xi, int lane, int n) { pw_g5_write<1, 1>(b, Xi, lane, n); }, 1, 1);
+}
+} // namespace
+
+// N = 2^lgN (odd lgN >= 17): the five-stage gather pass G512 through the lane programs, then the remaining radix-4 stages with the generic
+// in-place stage.  Returns the number of stages, -1 if the size does not fit.
+extern "C" int emu_pair_g512_fft(int lgN, const float2 *in, float2 *out, int inverse)
+{
+    const unsigned N = 1u << lgN;
+    FftStage st[32];
+    const int ns = fft_plan_stages((int)N, st, 32);
+    if (ns < 6 || st[ns - 1].p != 2 || lgN < 17) return -1;
+    std::vector<float2> tw = make_tw((int)N, inverse), Tg5(PW_G5_TABLE);
+    for (int i = 0; i < PW_G5_TABLE; ++i) pw_g5_table_entry(tw.data(), N, i, Tg5[i]);
+    std::vector<float4> img(PW_G_UNITS), X(PW_X5_UNITS);
+    for (unsigned ct = 0; ct < (N >> 14); ++ct) {
+        if (inverse) g512_tile<true>(in, out, lgN, ct, Tg5.data(), img, X);
+        else g512_tile<false>(in, out, lgN, ct, Tg5.data(), img, X);
+    }
+    for (int s = ns - 6; s >= 0; --s)
+        for (unsigned b = 0; b < N / 4; ++b) {
+            if (inverse) fft_stage_butterfly<true>(out, tw.data(), st[s], (int)b);
+            else fft_stage_butterfly<false>(out, tw.data(), st[s], (int)b);
+        }
+    return ns;
+}

@@ -218,3 +218,16 @@ def test_four_wave_deal(emu, oracle, nfft):
     emu.emu_four_wave_deal.restype = C.c_long
     assert emu.emu_four_wave_deal(C.c_int(nfft), x.ctypes.data_as(C.c_void_p)) == 0
     assert emu.emu_four_wave_deal_bank_conflicts() == 1
+
+
+@pytest.mark.parametrize("lgn,inv", [(17, 0), (19, 0), (19, 1)])
+def test_pair_g512_gather_pass(emu, oracle, lgn, inv):
+    """G512 (fft_big_core.h; the device kernel is the next step): G128 on four wavefronts whose columns are N / 512 apart, then kissfft's
+    radix-4 stage of sub-length 128 across them through the five-stage passes' workgroup image -- 2^19 points in TWO passes.  Every lane
+    map, the extended twiddle copy and the store positions, one lane at a time: the oracle's kiss_fft, bit for bit."""
+    n = 1 << lgn
+    emu.emu_pair_g512_fft.argtypes = [C.c_int, c64, c64, C.c_int]
+    x = oracle.synth_iq(0x512 + lgn + inv, 0, n)
+    y = np.empty_like(x)
+    assert emu.emu_pair_g512_fft(lgn, x, y, inv) > 0
+    assert np.array_equal(bits(y), bits(oracle.fft(x, n, inverse=bool(inv))))

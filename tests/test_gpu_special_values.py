@@ -66,7 +66,7 @@ def test_fir_special_values(gpu, redio, oracle, k, d, cplx, fused):
         assert same_special(got, want), (k, d, cplx, fused, seed, where_differs(got, want))
 
 
-@pytest.mark.parametrize("nfft", [4, 16, 64, 256, 1024, 4096, 16384, 65536, 2, 8, 32, 128, 512, 2048, 8192, 32768, 131072, 1 << 18, 1 << 20,
+@pytest.mark.parametrize("nfft", [4, 16, 64, 256, 1024, 4096, 16384, 65536, 2, 8, 32, 128, 512, 2048, 8192, 32768, 131072, 1 << 18, 1 << 19, 1 << 20,
                                   3, 5, 15, 100, 1000, 1536, 6144, 7, 49, 20000])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_special_values(gpu, redio, oracle, nfft, inverse):
