@@ -111,3 +111,15 @@ def test_overlap_save_65536_step_launch_edges(gpu, redio, oracle, nblk):
         cut = nblk // 3 + 1
         y2 = gpu.cat([plan(x[: nfft + hop * (cut - 1)]), plan(x[hop * cut:])])
         assert gpu.equal(y, y2)
+
+
+def test_overlap_save_2_19_point_blocks_mix_the_two_plans(gpu, redio, oracle):
+    """2^19-point blocks: the forward transform takes the two-pass plan (G512 + five-stage pass), the inverse -- spectrum product on the way in,
+    masked store on the way out -- the three-pass plan of the same size; both read their tables from one plan allocation."""
+    nfft, k = 1 << 19, 127
+    h = oracle.lpf_corrected(k, 0.08)
+    hop = nfft - k + 1
+    x = oracle.synth_iq(19, 0, nfft + 2 * hop + 5)
+    got = redio.OverlapSave(h, nfft)(gpu.from_numpy(x).cuda()).cpu().numpy()
+    want = oracle.overlap_save(x, h, nfft)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
