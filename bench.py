@@ -27,6 +27,12 @@ the rocprofv3 PMC passes of a separate run (`traffic_source`); `roofline.valu` p
 world size and every rank's device as torch.distributed saw them.  `cpu_baseline` is the CPU oracle (oracle/, a port of
 the reference's algorithm) timed on this host on a bounded sample: all cores as independent replicas (`value`), one
 core, and the reference's own structure -- a thread per block with a heap Vec per message (`kpn_pipeline`).
+
+`value_cold` is the figure rounds 1-3 reported under the same flags (launches W .. W+K-1 of the cold burst of this same run, from the
+pre-conditioning's own per-launch HIP events), so that the line stays comparable round over round.  `other_configs` (rank 0, after
+the timed region, `--no-other-configs` skips it, about 1 s): BASELINE.json configs[2] (256 channels x 2^22 frames, exact and the opt-in
+f32 mode), configs[3] on one GPU (cf32 and u8 input), configs[4] on one GPU (65536-point blocks, 8193 taps) and the 65536-point
+transform alone, each {workload, alg_bytes, kernel_ms by HIP events after >= 100 ms of warm-up, frac of 8 TB/s, binding, kernel}.
 """
 import argparse
 import ctypes as C
@@ -55,6 +61,8 @@ def parse():
     ap.add_argument("--unfused", action="store_true", help="run FIR and FFT as two kernels (12.8 B/sample)")
     ap.add_argument("--exact", action="store_true", help="reference rounding (mul+add) instead of fmaf in the FIR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs leg (BASELINE.json configs[2..4] and the 65536-point "
+                                                                    "transform, each timed with HIP events after the timed region; rank 0 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=23, help="slice per CPU thread")
@@ -124,6 +132,129 @@ def cpu_baseline(log2n, min_seconds=12.0):
                                        f"5th] -> [kiss_fft 1024] -> sink, one OS thread per block, one heap Vec per message, mutex/condvar "
                                        f"queues (oracle/kpn_baseline.cpp; the structure of src/kissfft/src/kissfft.rs:18-31 and "
                                        f"src/ratpak.rs:60-185), CPU restatement of the reference"}}
+
+
+def other_configs(R, lib, stream, x, n):
+    """Outside the timed region, rank 0 only, never `value`: the other BASELINE.json configs at SURVEY.md 8d's sizes, each timed with HIP
+    events on the launch stream after >= 100 ms of back-to-back warm-up launches (the chip raises its clock over the first ~100 ms of a
+    burst; tools/bench_configs.py times its lines the same way).  Every entry: workload, alg_bytes per call (SURVEY.md 8d's per-sample
+    figure x the samples of the call), kernel_ms (mean per call), frac of 8 TB/s, which roofline binds, the kernels the call launches.
+    x: the resident 2^28-sample cf32 stream of the headline (reused as the input of C4 / C5 / the 65536-point transform)."""
+    import torch
+
+    def timed(f, reps, warm_ms=100.0, warm_min=3):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        R.check(lib.redio_event_create(C.byref(e0)))
+        R.check(lib.redio_event_create(C.byref(e1)))
+        for _ in range(warm_min):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < warm_ms:
+            for _ in range(4):
+                f()
+            torch.cuda.synchronize()
+        R.check(lib.redio_event_record(e0, stream))
+        for _ in range(reps):
+            f()
+        R.check(lib.redio_event_record(e1, stream))
+        torch.cuda.synchronize()
+        ms = C.c_float()
+        R.check(lib.redio_event_elapsed_ms(e0, e1, C.byref(ms)))
+        lib.redio_event_destroy(e0)
+        lib.redio_event_destroy(e1)
+        return ms.value / reps
+
+    def entry(workload, alg_bytes, ms, kernel, units, unit_name, binding="hbm", **more):
+        e = {"workload": workload, "alg_bytes": alg_bytes, "kernel_ms": ms, "achieved": alg_bytes / (ms * 1e-3) / 1e9, "unit": "GB/s",
+             "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "binding": binding, "kernel": kernel,
+             "value": units / ms / 1e3, "value_unit": unit_name}
+        e.update(more)
+        return e
+
+    res = {}
+    t_leg = time.perf_counter()
+
+    # --- configs[3] on one GPU: 64-channel polyphase filterbank, 16 taps per branch, the whole 2^28-sample slice (16 B per sample) ---
+    h = R.dsputils.lpf_corrected(1024, 0.45 / 64)
+    pfb = R.Channelizer(h)
+    rows = pfb.nrows(n)
+    o4 = torch.empty((rows, 64), dtype=torch.complex64, device="cuda")
+    ms = timed(lambda: pfb(x, out=o4), 50)
+    res["c4_channelizer_cf32"] = entry("BASELINE.json configs[3] on one GPU: 64-channel critically sampled polyphase filterbank, prototype 64 x 16 taps, "
+                                       "2^%d cf32 samples per call, natural [row][channel] output" % (n.bit_length() - 1),
+                                       16.0 * n, ms, "pfb64_kernel<16>", n, "MSamples/s")
+    g = torch.Generator(device="cuda"); g.manual_seed(0x5EED0004)
+    raw = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    ms = timed(lambda: pfb.from_bytes(raw, out=o4), 50)
+    res["c4_channelizer_u8"] = entry("the same filterbank fed with the receiver's u8 I/Q bytes (rtlsdr::data_to_samples folded into the window loads): "
+                                     "2 B in + 8 B out per sample", 10.0 * n, ms, "pfb64_kernel<16, u8>", n, "MSamples/s",
+                                     binding="valu (37+ vector instructions per sample; see DESIGN.md 5.6)")
+    del raw, o4, pfb
+
+    # --- configs[4] on one GPU: overlap-save, 65536-point blocks, 8193 taps (17.14 B per output sample), >= 2 work-buffer chunks ---
+    K5, N5 = 8193, 65536
+    ovs = R.OverlapSave(R.dsputils.lpf_corrected(K5, 0.08), N5)
+    o5 = torch.empty(ovs.nout(n), dtype=torch.complex64, device="cuda")
+    hop = N5 - K5 + 1
+    b5 = 8.0 * N5 / hop + 8.0
+    ms = timed(lambda: ovs(x, out=o5), 20)
+    res["c5_overlap_save_65536"] = entry("BASELINE.json configs[4] on one GPU: overlap-save FFT convolution, 65536-point blocks, 8193 taps (hop 57344), "
+                                         "%d blocks = %d output samples per call (64 MiB work-buffer chunks: %d chunk steps)"
+                                         % (o5.numel() // hop, o5.numel(), (o5.numel() // hop * N5 * 8 + (64 << 20) - 1) // (64 << 20)),
+                                         b5 * o5.numel(), ms, "ovsave64k_step_kernel (gather / middle / last tiles interleaved per chunk step)",
+                                         o5.numel(), "MSamples/s (output)",
+                                         moved_bytes_over_alg=3.07, note="three passes at the L2 boundary move 3.07 x the algorithmic bytes: the scheme's ceiling is 25 % at this pool's copy rate")
+    del o5, ovs
+
+    # --- the 65536-point transform alone (kissfft::fft at configs[4]'s block size), 2^26 points per call, 16 B per point ---
+    m = min(n, 1 << 26)
+    fft = R.Fft(65536)
+    xs = x[:m]
+    of = torch.empty(m, dtype=torch.complex64, device="cuda")
+    ms = timed(lambda: fft(xs, out=of), 50)
+    res["fft_65536"] = entry("kissfft::fft, 65536-point forward transforms, %d blocks (2^%d points) per call" % (m // 65536, m.bit_length() - 1),
+                             16.0 * m, ms, "fftbig_first_kernel + fftbig_mid_kernel (two passes, 32 B moved per point)", m, "MSamples/s",
+                             moved_bytes_over_alg=2.0)
+    del of, fft
+
+    # --- configs[2]: 256 channels x 2^22 frames, ratio 48000 / 2400000 = 0.02, medium-quality sinc converter (4.08 B per input frame) ---
+    nch, frames, ratio = 256, 1 << 22, 0.02
+    x3 = torch.empty((nch, frames), dtype=torch.float32, device="cuda")
+    for c in range(nch):
+        x3[c] = R.synth_f32(100 + c, 0, frames)
+    b3 = nch * frames * 4.0 * (1.0 + ratio)
+    tab_half, tab_inc = 22438 - 2, 491                      # the medium converter's half table and increment (src_core.h)
+    taps_per_out = 2 * int(tab_half / (tab_inc * ratio)) + 1
+    nout3 = nch * frames * ratio
+    for key, mode, kern, what in (("c3_resample_exact", R.Src.EXACT, "src_window_rb_kernel",
+                                   "bit-identical to the oracle's libsamplerate-0.1.8 arithmetic: f32 -> f64 convert, separately rounded v_mul_f64 + v_add_f64 per tap"),
+                                  ("c3_resample_fast", R.Src.FAST, "src_window_fastp_kernel",
+                                   "opt-in REDIO_SRC_FAST mode: the same filter as an f32 polyphase bank (v_pk_fma_f32), tolerance-tested, NOT bit-identical")):
+        plan = R.Src(nch, 1, mode=mode)
+        plan.process(x3, ratio)                             # first call: history of zeros, same work
+        ms = timed(lambda: plan.process(x3, ratio), 10 if mode == R.Src.EXACT else 20)
+        flops = 2.0 * taps_per_out * nout3
+        if mode == R.Src.EXACT:
+            # 78.6 TFLOP/s = the f64 vector peak (FMA counted as 2); unfused mul + add can reach half of it; the modelled issue bound is the
+            # measured back-to-back cost of this kernel's three instructions per tap (tools/bench_configs.py c3: 6.2 / 2 + 5.0 + 4.6 cycles)
+            t_issue = nout3 * taps_per_out / 64 * 12.7 / 1024 / 2.4e9
+            more = {"valu": {"tflops": flops / (ms * 1e-3) / 1e12, "peak_tflops_f64": 78.6, "frac_of_f64_peak": flops / (ms * 1e-3) / 1e12 / 78.6,
+                             "frac_of_modelled_issue_bound": t_issue / (ms * 1e-3), "modelled_issue_bound_ms": t_issue * 1e3}}
+            bind = "valu_f64"
+        else:
+            more = {"valu": {"tflops": flops / (ms * 1e-3) / 1e12, "peak_tflops_f32": 157.3, "frac_of_f32_peak": flops / (ms * 1e-3) / 1e12 / 157.3}}
+            bind = "valu_f32"
+        res[key] = entry("BASELINE.json configs[2]: samplerate polyphase resample 2.4 MS/s -> 48 kS/s (ratio 0.02), %d channels x 2^%d frames per call, "
+                         "%d taps per output; %s" % (nch, frames.bit_length() - 1, taps_per_out, what),
+                         b3, ms, kern, nch * frames, "MSamples/s (input)", binding=bind, **more)
+        del plan
+    del x3
+    torch.cuda.empty_cache()
+    res["leg_seconds"] = time.perf_counter() - t_leg
+    res["note"] = ("each entry: HIP events on the launch stream around `reps` back-to-back calls after >= 100 ms of warm-up calls; inputs resident in HBM; "
+                   "outside the timed region, beside value, never value; every config has a full-shape bit-exactness test under tests/ (-m gpu)")
+    return res
 
 
 def main():
@@ -230,6 +361,14 @@ def main():
                         "criterion": f"medians of the last three windows of {WIN} launches within {TOL * 100:.0f} % of each other, at most {a.precondition_max} launches",
                         "converged": len(meds) >= 3 and max(meds[-3:]) <= (1.0 + TOL) * min(meds[-3:]),
                         "first_ms": series[0], "last_ms": series[-1], "window_medians_ms": [round(m, 4) for m in meds]}
+        # the cold-burst figure of rounds 1-3 from the same run: launches W .. W+K-1 of the burst, i.e. what `--warmup W --steps K` timed
+        # before the pre-conditioning existed (per-launch HIP events; the slowest rank's sum)
+        cold_s = sum(series[a.warmup:a.warmup + a.steps]) * 1e-3 if len(series) >= a.warmup + a.steps else None
+        if cold_s is not None and dist is not None:
+            tc = torch.tensor([cold_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            cold_s = float(tc.item())
+        precondition["cold_seconds_for_steps"] = cold_s
 
     for _ in range(a.warmup):
         chain(x, out)
@@ -364,6 +503,13 @@ def main():
                           "transform of its %d decimated blocks); as separate kernels the chain moves 12.8 B per input sample, fused 9.6" % (a.log2_samples, nblk)}
         del y
 
+    # outside the timed region, rank 0 only: the other BASELINE configs (docstring of other_configs)
+    others = None
+    if rank == 0 and not a.no_other_configs and not a.exact and not a.unfused and a.log2_samples >= 26:
+        del out
+        torch.cuda.empty_cache()
+        others = other_configs(R, lib, stream, x, n)
+
     if rank == 0:
         kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
@@ -387,6 +533,9 @@ def main():
             "unit": "MSamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
+            # comparable with rounds 1-3 (no pre-conditioning then): launches W .. W+K-1 of the cold burst of this same run
+            "value_cold": (world * used * a.steps / precondition["cold_seconds_for_steps"] / 1e6
+                           if precondition and precondition.get("cold_seconds_for_steps") else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single f32 IQ stream, 1024-pt kissfft + 127-tap FIR decimate-by-5, 1 MI355X "
@@ -430,6 +579,8 @@ def main():
                                             "format from BASELINE.json configs[1] (f32 IQ), so beside value, never as value"}
         if stages is not None:
             rec["stages"] = stages
+        if others is not None:
+            rec["other_configs"] = others
         if ranks_seen is not None:
             rec["ranks_seen"] = ranks_seen
         # rank 0 only, also at N > 1 (the other ranks have nothing left to do; they wait in destroy_process_group)
