@@ -16,6 +16,7 @@
 // 1/50); the window and table reads are served by L1/L2.
 #include "redio_internal.h"
 #include "src_core.h"
+#include <type_traits>
 
 namespace redio {
 
@@ -959,6 +960,8 @@ __global__ __launch_bounds__(64 * SrcFastP<NPAIR>::W) void src_window_fastp_kern
     }
 }
 
+#include "src_fastp2.h" // round 5: the same kernel with the loader inside the multiply-add stream (two image halves by phase)
+
 // tap pairs per phase the f32 polyphase phase-split kernel is built for (>= the shape's); 0: the kernel does not serve the shape
 #define REDIO_FASTP_SHAPES(X) X(16) X(20) X(24) X(32) X(40) X(46) X(48)
 int src_fastp_pairs(int S, int KH)
@@ -999,8 +1002,27 @@ hipError_t launch_src_window(const float *old_img, long old_stride, const float 
     if (nout > 0) {
         if (fast && Hp && fastp_nc > 0) {
             const int KH = ncl + ncr;
-            // tiles per (persistent) workgroup: a channel's tiles in equal runs, about two workgroups per CU in all (one is resident)
             const long ntiles = (nout + 511) / 512;
+            bool done = false;
+            // round 5: the same arithmetic with the loader inside the multiply-add stream (src_fastp2.h) for the tap counts of the medium and
+            // fastest converters at S >= 25; persistent workgroups, about one per CU in all (its prologue loads a tile with nothing to overlap)
+#define LAUNCH_FP2(N)                                                                                                             \
+    if (!done && fastp_nc == N && SrcFastP2<N, 32>::fits(S) && !measure_env("REDIO_SRC_FASTP_R3")) {                              \
+        auto kern = src_window_fastp2_kernel<N, 32, 0>;                                                                           \
+        const size_t lds = SrcFastP2<N, 32>::lds_bytes(S);                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                            \
+        long splits = 256 / nchan;                                                                                                \
+        splits = splits < 1 ? 1 : (splits > ntiles ? ntiles : splits);                                                            \
+        const long tpw = (ntiles + splits - 1) / splits;                                                                          \
+        dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), (unsigned)nchan);                                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, w, Hp, KH, cl, a0, S, out, out_stride, nout, (int)tpw);                 \
+        done = true;                                                                                                              \
+    }
+            LAUNCH_FP2(20) LAUNCH_FP2(24) LAUNCH_FP2(46) LAUNCH_FP2(48)
+#undef LAUNCH_FP2
+            if (!done) {
+            // tiles per (persistent) workgroup: a channel's tiles in equal runs, about two workgroups per CU in all (one is resident)
             long splits = 512 / nchan;
             splits = splits < 1 ? 1 : (splits > ntiles ? ntiles : splits);
             const long tpw = (ntiles + splits - 1) / splits;
@@ -1015,6 +1037,7 @@ hipError_t launch_src_window(const float *old_img, long old_stride, const float 
     }
             REDIO_FASTP_SHAPES(LAUNCH_FP)
 #undef LAUNCH_FP
+            }
         } else if (fast) {
             const int KH = ncl + ncr;
             const bool padded = (S % 2) == 0;

@@ -216,7 +216,7 @@ def test_fast_mode_error_bound_and_state(gpu, redio, oracle):
     assert np.array_equal(bits(a.cpu().numpy()), bits(b.cpu().numpy()))
 
 
-@pytest.mark.parametrize("S", [2, 3, 4, 5, 7, 8, 10, 16, 25, 32, 50, 53, 64])
+@pytest.mark.parametrize("S", [2, 3, 4, 5, 7, 8, 10, 16, 25, 26, 31, 32, 33, 40, 41, 47, 48, 49, 50, 53, 64])
 @pytest.mark.parametrize("conv,nch", [(1, 1), (1, 3), (2, 2)])
 def test_fast_mode_phase_split_kernel_over_decimations(gpu, redio, oracle, S, conv, nch):
     """REDIO_SRC_FAST at ratio 1/S through the phase-split polyphase kernel (src_window_fastp_kernel: persistent tiles of 512
