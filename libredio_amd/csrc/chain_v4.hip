@@ -152,10 +152,9 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     }
 }
 
-// blocks per wavefront of a launch over nblocks blocks (every instantiation: WPS = 2)
-long chain_v4_blocks_per_wave(long nblocks)
+// blocks per wavefront of a launch over nblocks blocks at WPS wavefronts per SIMD (the chain: 2; the FIR alone: 3)
+long chain_v4_blocks_per_wave(long nblocks, int WPS)
 {
-    constexpr int WPS = 2;
     // Short runs in dispatch order, not one long run per residency slot: the wavefronts resident at any moment then read one
     // compact window of the stream (2048 x 4 blocks = 335 MB apart at most, instead of 2048 places spread over all of it).
     // Measured with non-temporal accesses 0.533 -> 0.517 ms per 2^28 samples (profiles/r03_chain_variants.txt); a run
@@ -176,7 +175,7 @@ template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg, long dbg_cap = 0)
 {
-    static_assert(WPS == 2 || WPS == 3, "chain_v4_blocks_per_wave assumes two wavefronts per SIMD (three: measurement builds only)");
+    static_assert(WPS == 2 || WPS == 3, "two wavefronts per SIMD (the chain: its transform needs 197 registers) or three (the FIR alone: 94-145)");
     using G = FirGeomV<K, D, 4>;
     constexpr int ELEMS = G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS;
     constexpr size_t LDS_NEED = (size_t)ELEMS * sizeof(float2);
@@ -187,7 +186,7 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     // half empty, and the launch ends when the most crowded CU does (measured: wave lifetimes 320-570 us).
     constexpr size_t LDS = (160 * 1024 / (4 * WPS)) - 480 > LDS_NEED ? (160 * 1024 / (4 * WPS)) - 480 : LDS_NEED;
     static_assert((4 * WPS + 1) * LDS > 160 * 1024, "one more wave must not fit");
-    const long bpw = chain_v4_blocks_per_wave(nblocks);
+    const long bpw = chain_v4_blocks_per_wave(nblocks, WPS);
     const long grid = (nblocks + bpw - 1) / bpw;
     if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
     else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
@@ -238,9 +237,20 @@ hipError_t launch_chain_v4_shape(int K, int D, const float2 *x, const float *tap
 // decimated samples instead of transforming them.  hipErrorNotSupported: no such instantiation (the tiled kernels run).
 hipError_t launch_fir_v4(int K, int D, const float2 *x, const float *taps, float2 *y, long nblocks, bool fused, hipStream_t s)
 {
+    // Three wavefronts per SIMD (round 5): without the transform these instantiations need 94-145 registers, and the third wavefront
+    // hides more of the window reads' and the stream's latency -- 2^26 samples: 127 / 5 0.1189 -> 0.1109 ms (67.7 -> 72.6 % of 8 TB/s),
+    // 63 / 5 0.1007 -> 0.0983, 63 / 1 0.2561 -> 0.2441; 2^28: 0.4901 -> 0.4818, 0.4655 -> 0.4664, 0.9973 -> 0.9688; the reference-rounding
+    // builds 4-6 % (profiles/r05_fir_three_waves.txt; interleaved A/B in one process, bit-identical).  REDIO_FIR_WPS2: measurement builds.
+    if (!measure_env("REDIO_FIR_WPS2")) {
+        if (K == 127 && D == 5) return launch_v4_t<127, 5, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
+        if (K == 63 && D == 5) return launch_v4_t<63, 5, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
+        if (K == 63 && D == 1) return launch_v4_t<63, 1, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
+    }
+#ifdef REDIO_MEASURE
     if (K == 127 && D == 5) return launch_v4_t<127, 5, 2, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
     if (K == 63 && D == 5) return launch_v4_t<63, 5, 2, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
     if (K == 63 && D == 1) return launch_v4_t<63, 1, 2, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
+#endif
     // (127 taps, no decimation: VALU-bound, and the 256-thread tiled kernel with 8 outputs per lane is faster -- 0.44 against 0.56 ms per 2^26 samples;
     //  127 taps / 3: the chunked tiled kernel since its window reads are immediate-offset ds_read_b64 -- 0.180 against 0.197 ms, 0.290 against 0.340
     //  with the reference's rounding)

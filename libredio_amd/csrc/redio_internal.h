@@ -65,7 +65,7 @@ hipError_t launch_chain_u8(const FftPlanDev &p, const void *bytes, const float *
                            hipStream_t s);
 hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const float *taps, int K, long D,
                         float2 *out, long nblocks, bool fused, hipStream_t s, unsigned long long *dbg = nullptr, long dbg_cap = 0);
-long chain_v4_blocks_per_wave(long nblocks); // chain_v4.hip: consecutive blocks one wavefront of the fused kernel owns
+long chain_v4_blocks_per_wave(long nblocks, int WPS = 2); // chain_v4.hip: consecutive blocks one wavefront of the fused kernel owns (WPS wavefronts per SIMD: the chain 2, the FIR alone 3)
 // the fused kernel's name as rocprofv3 prints it (spaces removed), so that a counter file can be tied to the kernel a plan launches
 const char *chain_kernel_name(int K, long D, bool fused_math, char *buf, size_t cap);
 
