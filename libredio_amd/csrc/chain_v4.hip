@@ -245,6 +245,7 @@ hipError_t launch_fir_v4(int K, int D, const float2 *x, const float *taps, float
         if (K == 127 && D == 5) return launch_v4_t<127, 5, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
         if (K == 63 && D == 5) return launch_v4_t<63, 5, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
         if (K == 63 && D == 1) return launch_v4_t<63, 1, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
+        if (K == 127 && D == 3) return launch_v4_t<127, 3, 3, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
     }
 #ifdef REDIO_MEASURE
     if (K == 127 && D == 5) return launch_v4_t<127, 5, 2, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
