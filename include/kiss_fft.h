@@ -23,13 +23,16 @@ typedef struct { float r, i; } kiss_fft_cpx; /* = num::complex::Complex<f32>, in
 typedef struct kiss_fft_state *kiss_fft_cfg;
 
 /* mem/lenmem placement protocol of the published API: lenmem == NULL -> heap; otherwise *lenmem is
- * set to the bytes needed and mem is used when it is non-NULL and large enough (else NULL). */
+ * set to the bytes needed and mem is used when it is non-NULL, large enough and aligned for pointers (else NULL). */
 kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, size_t *lenmem);
 void kiss_fft(kiss_fft_cfg cfg, const kiss_fft_cpx *fin, kiss_fft_cpx *fout);
 void kiss_fft_stride(kiss_fft_cfg cfg, const kiss_fft_cpx *fin, kiss_fft_cpx *fout, int fin_stride);
 void kiss_fft_cleanup(void);             /* no global state: no-op (kissfft.rs:30 is unreachable) */
 int kiss_fft_next_fast_size(int n);      /* next n whose only prime factors are 2, 3, 5 */
 void kiss_fft_free(kiss_fft_cfg cfg);    /* releases the device plan (the published macro is free()) */
+/* Not in the published interface: the wall-time bound (nanoseconds, default 100 000) of the completion poll a call makes before it falls
+ * back to an ordinary stream wait; 0 takes the fall-back on every call (a test hook). */
+void kiss_fft_set_spin_ns(long ns);
 
 #ifdef __cplusplus
 }

@@ -238,7 +238,11 @@ int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, void *d_out, 
  * 26 bytes per sample through HBM), other shapes convert into a plan-owned buffer first (grown on first use). */
 int redio_pfb_enqueue_u8(redio_pfb *h, const void *d_bytes, size_t nbytes, void *d_out, int ngroups, void *stream);
 int redio_pfb_reserve_u8(redio_pfb *h, size_t nbytes, int ngroups); /* as redio_pfb_reserve, for messages of up to nbytes bytes */
-/* scratch of the two-pass shapes for inputs of up to n_in samples (the fused 64-channel kernel needs none) */
+/* scratch of the two-pass shapes for inputs of up to n_in samples.  The fused 64-channel kernel needs none; the one-kernel shapes (32 ...
+ * 1024 channels x 4 / 8 / 16 taps per branch) need it only for an output that is not 16-byte aligned and reserve NOTHING unless
+ * REDIO_PFB_RESERVE_TWO_PASS is or-ed into ngroups (un-reserved, that fall-back sizes its scratch at first use and returns
+ * REDIO_ERR_NOT_RESERVED inside a capture). */
+#define REDIO_PFB_RESERVE_TWO_PASS 0x40000000
 int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups);
 
 /* ---- the channelizer's one exchange step over RCCL / xGMI (the only collective on the path) ----

@@ -186,6 +186,7 @@ def kisslib():
     _sig(K.kiss_fft_cleanup, None)
     _sig(K.kiss_fft_next_fast_size, C.c_int, C.c_int)
     _sig(K.kiss_fft_free, None, C.c_void_p)
+    _sig(K.kiss_fft_set_spin_ns, None, C.c_long)
     _kiss = K
     return K
 

@@ -14,7 +14,9 @@ typedef float pw_v4 __attribute__((ext_vector_type(4)));
 // the caller's buffers (block b of the stream starts at x + b hop: 8-byte aligned only when hop is odd)
 typedef float pw_v4u __attribute__((ext_vector_type(4), aligned(8)));
 
-__device__ __forceinline__ float4 pw_ld(const float2 *p) { return *reinterpret_cast<const float4 *>(p); }
+// pw_ld / pw_ld_mid / pw_st also reach the CALLER's `out` (a stand-alone transform of 32768 points or more works in place in it): declared
+// 8-byte aligned like every caller-owned address -- the same global_load / store_dwordx4, and no 16-byte promise the caller never made
+__device__ __forceinline__ float4 pw_ld(const float2 *p) { const pw_v4u v = *reinterpret_cast<const pw_v4u *>(p); return make_float4(v.x, v.y, v.z, v.w); }
 // an intermediate that a pass reads exactly once (the work buffers of the multi-pass schemes): -DREDIO_EXP_PW_NT_MID=1 reads it non-temporally
 #ifndef REDIO_EXP_PW_NT_MID
 #define REDIO_EXP_PW_NT_MID 0
@@ -22,13 +24,13 @@ __device__ __forceinline__ float4 pw_ld(const float2 *p) { return *reinterpret_c
 __device__ __forceinline__ float4 pw_ld_mid(const float2 *p)
 {
 #if REDIO_EXP_PW_NT_MID
-    const pw_v4 v = __builtin_nontemporal_load(reinterpret_cast<const pw_v4 *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
+    const pw_v4u v = __builtin_nontemporal_load(reinterpret_cast<const pw_v4u *>(p));
 #else
-    return *reinterpret_cast<const float4 *>(p);
+    const pw_v4u v = *reinterpret_cast<const pw_v4u *>(p);
 #endif
+    return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void pw_st(float2 *p, float2 lo, float2 hi) { *reinterpret_cast<float4 *>(p) = make_float4(lo.x, lo.y, hi.x, hi.y); }
+__device__ __forceinline__ void pw_st(float2 *p, float2 lo, float2 hi) { const pw_v4u v = {lo.x, lo.y, hi.x, hi.y}; *reinterpret_cast<pw_v4u *>(p) = v; }
 // data touched ONCE by a multi-pass transform (the caller's input / output): non-temporal, like big_ld_once / big_st_once
 __device__ __forceinline__ float4 pw_ld_once(const float2 *p)
 {

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <stdint.h>
 
 struct kiss_fft_state {
@@ -24,6 +25,11 @@ struct kiss_fft_state {
     uint32_t seq;
 };
 enum { KISS_ZERO_COPY_MAX = 8192 };
+// wall-time bound of the completion poll (nanoseconds): 100 us by default; kiss_fft_set_spin_ns is a test hook (0 forces the fall-back
+// to redio_stream_sync on every call, tests/test_gpu_parity.py) and not part of the published kiss_fft interface
+static long g_kiss_spin_ns = 100000;
+static long kiss_spin_ns(void) { return __atomic_load_n(&g_kiss_spin_ns, __ATOMIC_RELAXED); }
+extern "C" void kiss_fft_set_spin_ns(long ns) { __atomic_store_n(&g_kiss_spin_ns, ns < 0 ? 0 : ns, __ATOMIC_RELAXED); }
 
 extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, size_t *lenmem)
 {
@@ -33,7 +39,8 @@ extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, siz
         st = (kiss_fft_state *)malloc(need);
         if (st) st->on_heap = 1;
     } else {
-        if (mem != NULL && *lenmem >= need) { st = (kiss_fft_state *)mem; st->on_heap = 0; }
+        // the state holds pointers: a caller's buffer that is not aligned for them is refused like one that is too small (NULL, *lenmem = need)
+        if (mem != NULL && *lenmem >= need && ((uintptr_t)mem % alignof(kiss_fft_state)) == 0) { st = (kiss_fft_state *)mem; st->on_heap = 0; }
         *lenmem = need;
     }
     if (!st) return NULL;
@@ -70,6 +77,11 @@ extern "C" void kiss_fft_stride(kiss_fft_cfg st, const kiss_fft_cpx *fin, kiss_f
     const kiss_fft_cpx *src = fin;
     if (in_stride != 1) {
         if (!st->gather) st->gather = (kiss_fft_cpx *)malloc(bytes);
+        if (!st->gather) { // no error return in this interface (kissfft.rs:14): a poisoned block, as for a device failure
+            fprintf(stderr, "kiss_fft_stride: out of memory (%zu bytes)\n", bytes);
+            for (int i = 0; i < st->nfft; ++i) fout[i].r = fout[i].i = NAN;
+            return;
+        }
         for (int i = 0; i < st->nfft; ++i) st->gather[i] = fin[(size_t)i * in_stride];
         src = st->gather;
     }
@@ -80,8 +92,18 @@ extern "C" void kiss_fft_stride(kiss_fft_cfg st, const kiss_fft_cpx *fin, kiss_f
             const uint32_t seq = ++st->seq;
             volatile uint32_t *word = (volatile uint32_t *)st->flag;
             if (word && redio_stream_signal(st->stream, st->flag_dev, seq) == REDIO_OK) {
-                long spins = 0; // the word lands a few microseconds after the kernel; bounded, then the ordinary wait
-                while (*word != seq && ++spins < 4000000) __builtin_ia32_pause();
+                // The word lands a few microseconds after the kernel.  Poll for at most KISS_SPIN_NS of wall time, then the ordinary wait.
+                // Ordering: the stream writes the word behind the kernel (hipStreamWriteValue32 is ordered after all prior work of the
+                // stream), the message buffers and the word are host-coherent pinned memory (redio_host_alloc: hipHostMallocMapped), so a
+                // host that sees the word sees the kernel's stores to pin_out; the acquire fence keeps the memcpy below behind the poll.
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                for (;;) {
+                    for (int i = 0; i < 64 && *word != seq; ++i) __builtin_ia32_pause();
+                    if (*word == seq) break;
+                    clock_gettime(CLOCK_MONOTONIC, &t1);
+                    if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > kiss_spin_ns()) break;
+                }
                 if (*word != seq) rc0 = redio_stream_sync(st->stream);
                 else __atomic_thread_fence(__ATOMIC_ACQUIRE);
             } else rc0 = redio_stream_sync(st->stream);

@@ -148,6 +148,12 @@ extern "C" int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups)
 {
     if (!h) return REDIO_ERR_ARG;
     if (h->fused_kernel) return REDIO_OK;
+    // the one-kernel shapes (32 ... 1024 channels x 4 / 8 / 16 taps) touch the scratch only for an output that is not 16-byte aligned:
+    // 2-4 GiB per 2^28-sample message held for nothing otherwise.  REDIO_PFB_RESERVE_TWO_PASS in `ngroups` asks for it all the same
+    // (the two-pass form then never allocates, e.g. inside a capture with such an output).
+    const bool want_two_pass = (ngroups & REDIO_PFB_RESERVE_TWO_PASS) != 0;
+    ngroups &= ~REDIO_PFB_RESERVE_TWO_PASS;
+    if (pfb_p2_supported(h->nchan, h->taps_per_branch) && !want_two_pass) return REDIO_OK;
     const size_t total = redio_pfb_nrows(h, n_in) * (size_t)h->nchan;
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_rc(e);
@@ -190,7 +196,7 @@ extern "C" int redio_pfb_enqueue(redio_pfb *h, const void *d_in, size_t n_in, vo
         if (total > h->v_elems || (ngroups > 1 && total > h->w_elems)) { // un-reserved: grow on first use, never inside a capture
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return REDIO_ERR_NOT_RESERVED;
-            const int rc = redio_pfb_reserve(h, n_in, ngroups);
+            const int rc = redio_pfb_reserve(h, n_in, ngroups | REDIO_PFB_RESERVE_TWO_PASS);
             if (rc != REDIO_OK) return rc;
         }
         long blocks = (long)((total + 255) / 256);

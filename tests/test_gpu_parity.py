@@ -310,6 +310,50 @@ def test_kiss_fft_placement_stride_and_helpers(gpu, redio, oracle):
         assert L.kiss_fft_next_fast_size(n) == want, n
 
 
+def test_kiss_fft_misaligned_mem_and_completion_fallback(gpu, redio, oracle):
+    """kiss_fft_alloc refuses a caller's buffer that is not aligned for the state's pointers (NULL, the size comes back); a call whose
+    completion poll is cut to zero takes the ordinary stream wait and returns the same bits (kissfft_shim.cpp: the poll is bounded by
+    wall time, kiss_fft_set_spin_ns is the hook)."""
+    L = redio.kisslib()
+    need = C.c_size_t(0)
+    L.kiss_fft_alloc(1024, 0, None, C.byref(need))
+    mem = C.create_string_buffer(need.value + 16)
+    base = C.addressof(mem)
+    odd = base + 1 if base % 2 == 0 else base + 2                                    # 1 (mod 2): never aligned for a pointer
+    got = C.c_size_t(need.value)
+    assert L.kiss_fft_alloc(1024, 0, C.c_void_p(odd), C.byref(got)) is None and got.value == need.value
+    from libredio_amd import kissfft
+    cfg = kissfft.Cfg(1024, 0)
+    x = oracle.synth_iq(77, 0, 1024)
+    want = oracle.fft(x, 1024, False)
+    try:
+        L.kiss_fft_set_spin_ns(0)                                                       # every call: the fall-back branch
+        for _ in range(3):
+            assert same_bits(cfg(x), want)
+    finally:
+        L.kiss_fft_set_spin_ns(100000)
+    assert same_bits(cfg(x), want)
+    cfg.close()
+
+
+def test_big_fft_into_an_odd_sample_view(gpu, redio, oracle):
+    """Stand-alone transforms of 32768 points and more work in place in the caller's `out` with 16-byte accesses; `out` is only promised
+    8-byte (one cf32 sample) alignment: a view that starts on an odd sample must give the oracle's bits (the pair tile
+    program's accesses to caller-owned memory are declared 8-byte aligned)."""
+    import torch
+    for n, nb in ((32768, 3), (65536, 2), (1 << 17, 1), (1 << 19, 1)):
+        xh = oracle.synth_iq(0x0DD + n, 0, n * nb)
+        x = gpu.from_numpy(np.concatenate([np.zeros(1, np.complex64), xh])).cuda()[1:]   # input on an odd sample too
+        buf = torch.zeros(n * nb + 3, dtype=torch.complex64, device="cuda")
+        out = buf[1:1 + n * nb]
+        assert out.data_ptr() % 16 == 8
+        redio.Fft(n)(x, out=out)
+        got = out.cpu().numpy()
+        for b in range(nb):
+            assert same_bits(got[b * n:(b + 1) * n], oracle.fft(xh[b * n:(b + 1) * n], n, False)), (n, b)
+        assert buf[0].item() == 0 and buf[-1].item() == 0 and buf[-2].item() == 0
+
+
 def test_kissfft_block_function(gpu, redio, oracle):
     import queue
     import threading
