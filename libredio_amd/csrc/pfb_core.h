@@ -36,6 +36,17 @@ RD_HD void pfb_fft64_passAB(float2 (&v)[16], TwPtr tw)
         bfly4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3], tw[4 * k2], tw[8 * k2], tw[12 * k2]);
 }
 
+// the same two stages with the twiddles already in registers (wave-uniform: a1[k2] = tw[4 k2], a2[k2] = tw[8 k2], a3[k2] = tw[12 k2]): the
+// kernel loads them ONCE per wavefront -- fetched inside the tile loop they are scalar loads whose wait (lgkmcnt(0)) also waits for LDS traffic
+template <bool INV>
+RD_HD void pfb_fft64_passAB_pre(float2 (&v)[16], float2 one, const float2 (&a1)[4], const float2 (&a2)[4], const float2 (&a3)[4])
+{
+#pragma unroll
+    for (int d1 = 0; d1 < 4; ++d1) bfly4<INV>(v[d1], v[d1 + 4], v[d1 + 8], v[d1 + 12], one, one, one);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) bfly4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3], a1[k2], a2[k2], a3[k2]);
+}
+
 // exchange 2: lane (tt, d0) stores value (k1, k2); lane (tt, k1) loads element f = d0 + 4 k2
 RD_HD int pfb_x2_store(int lane, int k1, int k2) { return (lane >> 2) * PFB_ROW + 16 * k1 + 4 * k2 + (lane & 3); }
 RD_HD int pfb_x2_load(int lane, int f) { return (lane >> 2) * PFB_ROW + 16 * (lane & 3) + f; }
@@ -50,6 +61,15 @@ RD_HD void pfb_fft64_passC(float2 (&w)[16], int lane, TwPtr tw)
         const int k = k2 + 4 * k1;
         bfly4<INV>(w[4 * k2], w[4 * k2 + 1], w[4 * k2 + 2], w[4 * k2 + 3], tw[k], tw[2 * k], tw[3 * k]);
     }
+}
+// the same stage with the lane's twiddles already in registers (w1[k2] = tw[k], w2[k2] = tw[2 k], w3[k2] = tw[3 k], k = k2 + 4 (lane & 3)):
+// fetched inside the tile loop they are ten vector loads per tile whose wait (vmcnt(0): loads return in order) also waits for the NEXT tile's
+// rows requested at the top of the loop -- the prefetch then has to land within the tile that issued it (round 5)
+template <bool INV>
+RD_HD void pfb_fft64_passC_pre(float2 (&w)[16], const float2 (&w1)[4], const float2 (&w2)[4], const float2 (&w3)[4])
+{
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) bfly4<INV>(w[4 * k2], w[4 * k2 + 1], w[4 * k2 + 2], w[4 * k2 + 3], w1[k2], w2[k2], w3[k2]);
 }
 // channel index of element (k0, k2) held by lane after pass C
 RD_HD int pfb_out_channel(int lane, int k0, int k2) { return k2 + 4 * (lane & 3) + 16 * k0; }

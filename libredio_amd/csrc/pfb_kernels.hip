@@ -47,27 +47,41 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
         if constexpr (IN_U8) return make_float2(i2f(w & 255u), i2f((unsigned)w >> 8));
         else return w;
     };
+    // ONE straight-line path: a row past the end of the stream (only the last tiles of the last wave ever ask for one) is clamped with
+    // scalar arithmetic, and a tile's request is never skipped (the last tile of a wave requests rows it will not use).  With a fast and a
+    // clamped path, or a request under a condition, the compiler cannot count the loads in flight at a use and waits for ALL of them
+    // (vmcnt(0)) in the middle of the branch filters -- i.e. for the request it issued a few instructions earlier.
     auto load_rows = [&](raw_t(&dst)[PFB_TILE], long first) {
-        if (first + PFB_TILE - 1 <= last_in_row) {
-            const raw_t *xr = xraw + PFB_M * first;
 #pragma unroll
-            for (int ti = 0; ti < PFB_TILE; ++ti) dst[ti] = (xr + PFB_M * ti)[(unsigned)lane];
-        } else {
-#pragma unroll
-            for (int ti = 0; ti < PFB_TILE; ++ti) {
-                long r = first + ti;
-                r = r < last_in_row ? r : last_in_row;
-                dst[ti] = (xraw + PFB_M * r)[(unsigned)lane];
-            }
+        for (int ti = 0; ti < PFB_TILE; ++ti) {
+            long r = first + ti;
+            r = r < last_in_row ? r : last_in_row;
+            dst[ti] = (xraw + PFB_M * r)[(unsigned)lane];
         }
     };
+    // the transform's twiddles, once per wavefront (pfb_core.h: why not inside the tile loop): 20 scalar and 24 vector registers
+    float2 twone = tw[0], twa1[4], twa2[4], twa3[4], twc1[4], twc2[4], twc3[4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        twa1[k2] = tw[4 * k2]; twa2[k2] = tw[8 * k2]; twa3[k2] = tw[12 * k2];
+        const int k = k2 + 4 * (lane & 3);
+        twc1[k2] = tw[k]; twc2[k2] = tw[2 * k]; twc3[k2] = tw[3 * k];
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) { // kept where they are: no reload, no rematerialisation inside the loop
+        asm volatile("" : "+v"(twc1[k2].x), "+v"(twc1[k2].y), "+v"(twc2[k2].x), "+v"(twc2[k2].y), "+v"(twc3[k2].x), "+v"(twc3[k2].y));
+        asm volatile("" : "+s"(twa1[k2].x), "+s"(twa1[k2].y), "+s"(twa2[k2].x), "+s"(twa2[k2].y), "+s"(twa3[k2].x), "+s"(twa3[k2].y));
+    }
+    asm volatile("" : "+s"(twone.x), "+s"(twone.y));
     float2 win[P];
 #pragma unroll
     for (int p = 0; p < P - 1; ++p) win[p] = sample((xraw + PFB_M * (t0 + p))[(unsigned)lane]);
-    raw_t cur[PFB_TILE], nx[PFB_TILE];
-    load_rows(cur, t0 + P - 1);
-    for (long tb = t0; tb < t1; tb += PFB_TILE) {
-        if (!REDIO_PFB_LATE_PREFETCH && tb + PFB_TILE < t1) load_rows(nx, tb + PFB_TILE + P - 1);
+    // One tile: rows tb .. tb + 15 from `cur`, the next tile's rows requested into `nx`.  The tile loop below is unrolled by two with the
+    // roles of the two register sets swapped instead of copying nx -> cur: the copies of a loop-carried array land on the loop's back
+    // edge, BEHIND the tile's eight stores, where their wait (vmcnt(0): stores count too on gfx950) made every tile pay the write
+    // acknowledgement of the tile before it (round 5; and the transform's twiddles come from registers: pfb_core.h).
+    auto tile = [&](long tb, raw_t(&cur)[PFB_TILE], raw_t(&nx)[PFB_TILE]) {
+        if (!REDIO_PFB_LATE_PREFETCH) load_rows(nx, tb + PFB_TILE + P - 1);
         // branch FIRs: lane = branch, strict fold over p (dsputils.rs:31)
 #pragma unroll
         for (int ti = 0; ti < PFB_TILE; ++ti) {
@@ -77,13 +91,13 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
             for (int p = 0; p < P; ++p) acc = mac<FUSED>(win[(ti + p) % P], g[p], acc);
             lds[pfb_x1_store(ti, lane)] = acc;
         }
-        if (REDIO_PFB_LATE_PREFETCH && tb + PFB_TILE < t1) load_rows(cur, tb + PFB_TILE + P - 1); // into the registers the branch filters have just emptied
+        if (REDIO_PFB_LATE_PREFETCH) load_rows(cur, tb + PFB_TILE + P - 1); // into the registers the branch filters have just emptied
         wave_lds_fence();
         float2 v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = lds[pfb_x1_load(lane, e)];
         wave_lds_fence();
-        pfb_fft64_passAB<false>(v, tw);
+        pfb_fft64_passAB_pre<false>(v, twone, twa1, twa2, twa3);
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2)
 #pragma unroll
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
 #pragma unroll
         for (int f = 0; f < 16; ++f) v[f] = lds[pfb_x2_load(lane, f)];
         wave_lds_fence();
-        pfb_fft64_passC<false>(v, lane, tw);
+        pfb_fft64_passC_pre<false>(v, twc1, twc2, twc3);
         const long row = tb + (lane >> 2);
         if (row < t1) {
             if (ROWMAJOR) { // channels 16 k0 + 4 (lane & 3) + k2 of row tb + (lane >> 2): 32 bytes per lane, 128 per row and k0
@@ -116,9 +130,16 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
                 }
             }
         }
-        if (!REDIO_PFB_LATE_PREFETCH) {
-#pragma unroll
-            for (int ti = 0; ti < PFB_TILE; ++ti) cur[ti] = nx[ti];
+    };
+    raw_t ra[PFB_TILE], rb[PFB_TILE];
+    load_rows(ra, t0 + P - 1);
+    for (long tb = t0; tb < t1; tb += 2 * PFB_TILE) {
+        if constexpr (REDIO_PFB_LATE_PREFETCH) { // one register set: the request goes into the registers the branch filters have emptied
+            tile(tb, ra, ra);
+            if (tb + PFB_TILE < t1) tile(tb + PFB_TILE, ra, ra);
+        } else {
+            tile(tb, ra, rb);
+            if (tb + PFB_TILE < t1) tile(tb + PFB_TILE, rb, ra);
         }
     }
 }
