@@ -64,7 +64,7 @@ while time.time() < t_end and not (STATE and ncases):
     if TRACE:
         with open(TRACE, "w") as fh:
             json.dump(rng.bit_generator.state, fh); fh.flush(); os.fsync(fh.fileno())
-    which = rng.integers(0, 13) if not ONLY else int(rng.choice(ONLY))
+    which = rng.integers(0, 14) if not ONLY else int(rng.choice(ONLY))
     if which == 0:      # FIR, any K / D / length / alignment
         k = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 255, 500, int(rng.integers(1, 2000)), int(rng.integers(2000, 20000))]))
         d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 13]))
@@ -286,6 +286,30 @@ while time.time() < t_end and not (STATE and ncases):
                 want += ref.feed(blocks[lo:hi])
         ok = len(got) == len(want) and all(len(g) == len(w) and np.array_equal(bits(g), bits(w)) for g, w in zip(got, want))
         check("trigger", ok, (bl, nb, amp, cuts, len(got), len(want)))
+    elif which == 13:   # REDIO_SRC_FAST (opt-in f32 mode) against EXACT on the device: integer decimations 2 ... 64 (25 ... 53: the round-5 kernel with its two
+                        # image halves, straddling tiles and patch path), any channel count, any cut into messages: same frame counts, values inside the f32 bound
+        S = int(rng.choice([50, 50, 25, 26, 32, 33, 40, 41, 48, 49, 53, int(rng.integers(2, 65)), int(rng.integers(25, 54))]))
+        conv = int(rng.choice([1, 1, 2])); nch = int(rng.choice([1, 2, 3, 7, int(rng.integers(1, 40))]))
+        ratio = 1.0 / S
+        n = int(rng.integers(S * 40, S * 40 + 60000))
+        x = np.stack([O.synth_f32(int(rng.integers(1, 1 << 30)), 0, n) for _ in range(nch)])
+        tab, half, inc = O.src_table(conv)
+        pos = np.arange(0.0, half, inc * ratio)
+        sum_h = 2 * ratio * np.abs(np.interp(pos, np.arange(half + 2), tab.astype(np.float64))).sum()
+        bound = (2 * len(pos) + 1) * 2.0 ** -24 * max(sum_h, 1.0) * float(np.abs(x).max())
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 5)))]))
+        exact, fast = R.Src(nch, conv), R.Src(nch, conv, mode=R.Src.FAST)
+        dx = torch.from_numpy(x).cuda()
+        ok, worst = True, 0.0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            if hi == lo: continue
+            a, ua = exact.process(dx[:, lo:hi].contiguous(), ratio)
+            b, ub = fast.process(dx[:, lo:hi].contiguous(), ratio)
+            ok = ok and ua == ub and a.shape == b.shape
+            if ok and a.numel():
+                worst = max(worst, float((a - b).abs().max().item()))
+                ok = ok and worst <= bound
+        check("srcfast", ok, (S, conv, nch, n, cuts, worst, bound))
     else:               # resampler, batched, random ratio and message cuts
         nch = int(rng.choice([1, 3, 40, int(rng.integers(1, 100))])); conv = int(rng.integers(0, 5))
         ratio = float(rng.choice([0.02, 0.5, 1.0, 0.25, 0.1, 2.0, 0.0213, 1.0884, 48000 / 44100, 1.5, 0.3, 4 / 3, 0.75, 1 / 7, float(rng.uniform(0.01, 3.0)), 1 / 256, 256.0, 100.0, 0.004]))
