@@ -165,9 +165,9 @@ __global__ __launch_bounds__(512) void src_window_fastp2_kernel(SrcWindow w, con
     const Map mapA = mapping(0, PA), mapB = mapping(PA, S - PA); // four registers kept across the kernel
     // The window of a tile: round u of a request reads the tile samples (g0 + GI*u)*S + pl, i.e. one running byte offset per lane and ONE
     // buffer descriptor whose range check returns +0.0f at or behind `need` (samples of no valid output, which may not exist).  The one
-    // tile of a call that straddles [old image | new input] cannot be read through one descriptor (`straddles`): it is requested outside
-    // the steps, from both sources, and pays the wait.
-    struct Tile { const float *src_old, *src_new; int need, nsplit; bool straddles; };
+    // tile of a call that straddles [old image | new input] cannot be read through one descriptor: it is requested in the prologue, from both
+    // sources (request_now), and pays the wait.
+    struct Tile { const float *src_old, *src_new; int need, nsplit; };
     auto tile_window = [&](long tile) {
         Tile t;
         const long k0 = tile * NO, tile_base = a0 + (long)S * k0 - cl;
@@ -177,35 +177,21 @@ __global__ __launch_bounds__(512) void src_window_fastp2_kernel(SrcWindow w, con
         t.nsplit = ns < 0 ? 0 : (ns < t.need ? (int)ns : t.need); // [0, nsplit): old image, [nsplit, need): new input
         t.src_old = w.old_img + (long)ch * w.old_stride + tile_base;
         t.src_new = w.input + (long)ch * w.in_stride + (tile_base - w.a_in0); // tile sample 0 (valid from nsplit on)
-        t.straddles = t.nsplit > 0 && t.nsplit < t.need;
         return t;
     };
-    // The descriptor a step requests a tile through.  A tile in one source: that source, the whole range.  The straddling tile: the NEW
-    // input from sample nsplit on, every lane's offset lowered by 4*nsplit (`bias`: an old-image sample wraps far out of range, +0.0f);
-    // its old-image samples are written into the image by patch_old() when the tile is parked.  No branch: the request registers have
-    // ONE definition per step (with the straddling tile requested in a branch of its own the compiler copied both register sets at the
-    // loop's back edge, and the copies waited for every request in flight).
-    auto descriptor = [&](const Tile &t, unsigned *bias) {
+    // The descriptor a step requests a tile through: the NEW input, the whole range.  The launcher guarantees that every tile requested inside the steps
+    // (B of the workgroup's second tile, everything of its later tiles) lies in the new input: the old buffer image reaches two filter half-lengths into a
+    // call's window, a tile is 512 x S samples, so only the call's FIRST tile straddles [old image | new input] -- and a workgroup's first tile (and the A
+    // half of its second) is requested in the prologue, from both sources.  (A call whose second tile would straddle runs round 3's kernel:
+    // src_kernels.hip.)  No branch around a request: with the straddling tile requested in a branch of its own the compiler copied both register sets
+    // at the loop's back edge, and the copies waited for every request in flight.
+    auto descriptor = [&](const Tile &t) {
         SrcFastReq rq;
-        const bool from_old = t.nsplit >= t.need && t.nsplit > 0;
-        const int first = from_old ? 0 : t.nsplit;
-        rq.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(from_old ? t.src_old : t.src_new + first), 0, 4 * (t.need - first), 0x00020000);
+        rq.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(t.src_new), 0, 4 * t.need, 0x00020000);
         rq.doff = 4u * (unsigned)(GI * S);
-        *bias = 4u * (unsigned)first;
         return rq;
     };
     auto offset0 = [&](const Map &mp) { return 4u * (mp.g0 * (unsigned)S + mp.pl); };
-    // the straddling tile's old-image samples of one half -> their image cells (once per call and channel; behind the step that parked
-    // the half, before the barrier that publishes it)
-    auto patch_old = [&](const Tile &t, const Map &mp) {
-        const auto r_old = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(t.src_old), 0, t.nsplit * 4, 0x00020000);
-        const unsigned rowbytes = 8u * (unsigned)(S * NCOL), base = 8u * mp.pl * (unsigned)NCOL;
-        for (int u = 0; u < PFH; ++u) {
-            const unsigned g = mp.g0 + (unsigned)(GI * u), n = g * (unsigned)S + mp.pl;
-            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_old, 4u * n, 0, 0));
-            if (n < (unsigned)t.nsplit) *reinterpret_cast<float *>(smem + (__umul24((g >> 1) & 3u, rowbytes) + base + ((g >> 3) << 3) + ((g & 1u) << 2))) = v;
-        }
-    };
     auto request_now = [&](long tile, const Map &mp, float(&pf)[PFH]) { // outside the steps: the prologue, the straddling tile
         const Tile t = tile_window(tile);
         unsigned off = offset0(mp);
@@ -288,26 +274,14 @@ __global__ __launch_bounds__(512) void src_window_fastp2_kernel(SrcWindow w, con
         for (int c = 0; c <= R / 2; ++c) accB[c] = src_v2f{0.f, 0.f};
         // a0: parks B(t) and requests B(t+1) into the same registers, one chunk behind; then the sums of tile t-1 leave
         addresses(a8, mapB);
-        {
-            unsigned bias;
-            const SrcFastReq rq = descriptor(tile_window((ABL & 16) ? t0 : t0 + ti + 1), &bias);
-            run_step(0, ParkRequest{}, pfB, rq, offset0(mapB) - bias);
-            const Tile cur = tile_window(t0 + ti);
-            if (cur.straddles && ti > 0) patch_old(cur, mapB); // (the workgroup's first tile was requested from both sources in the prologue)
-        }
+        run_step(0, ParkRequest{}, pfB, descriptor(tile_window((ABL & 16) ? t0 : t0 + ti + 1)), offset0(mapB));
         if (ti > 0) reduce_store(t0 + ti - 1);
         if (!(ABL & 2)) src_lds_barrier(); // B(t) complete
         for (int k = 1; k < nA; ++k) run_step(k, Plain{}, pfA, none, 0u);
         if (!(ABL & 2)) src_lds_barrier(); // A rows free
         // b0: parks A(t+1) and requests A(t+2)
         addresses(a8, mapA);
-        {
-            unsigned bias;
-            const SrcFastReq rq = descriptor(tile_window((ABL & 16) ? t0 : t0 + ti + 2), &bias);
-            run_step(nA, ParkRequest{}, pfA, rq, offset0(mapA) - bias);
-            const Tile nxt = tile_window(t0 + ti + 1);
-            if (nxt.straddles && ti > 0) patch_old(nxt, mapA); // (the workgroup's second tile: A requested from both sources in the prologue)
-        }
+        run_step(nA, ParkRequest{}, pfA, descriptor(tile_window((ABL & 16) ? t0 : t0 + ti + 2)), offset0(mapA));
         if (!(ABL & 2)) src_lds_barrier(); // A(t+1) complete
         if (wave + W * (nA + 1) >= S) fill_window(wave); // a wavefront whose last step is b0
         for (int k = nA + 1; k < nsteps; ++k)

@@ -1004,10 +1004,14 @@ hipError_t launch_src_window(const float *old_img, long old_stride, const float 
             const int KH = ncl + ncr;
             const long ntiles = (nout + 511) / 512;
             bool done = false;
+            // the round-5 kernel requests everything behind a workgroup's first tile from the NEW input only (src_fastp2.h): the call's second tile must
+            // not reach into the old image.  The image holds about two filter half-lengths of a call's window, a tile is 512 x S samples: true for every
+            // state the converter can be in at these S -- checked, not assumed; a call that fails the check runs round 3's kernel.
+            const bool later_tiles_in_new_input = w.a_in0 <= a0 - cl + 512L * S;
             // round 5: the same arithmetic with the loader inside the multiply-add stream (src_fastp2.h) for the tap counts of the medium and
             // fastest converters at S >= 25; persistent workgroups, about one per CU in all (its prologue loads a tile with nothing to overlap)
 #define LAUNCH_FP2(N)                                                                                                             \
-    if (!done && fastp_nc == N && SrcFastP2<N, 32>::fits(S) && !measure_env("REDIO_SRC_FASTP_R3")) {                              \
+    if (!done && fastp_nc == N && SrcFastP2<N, 32>::fits(S) && later_tiles_in_new_input && !measure_env("REDIO_SRC_FASTP_R3")) {                              \
         auto kern = src_window_fastp2_kernel<N, 32, 0>;                                                                           \
         const size_t lds = SrcFastP2<N, 32>::lds_bytes(S);                                                                        \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -310,9 +310,13 @@ class Trigger:
         self._t = lib().orc_trigger_new()
         self._fed = 0
 
-    def __del__(self):
+    def __del__(self, _lib=lib):  # bound at definition: module globals may be gone at interpreter shutdown
         if getattr(self, "_t", None):
-            lib().orc_trigger_free(self._t); self._t = None
+            try:
+                _lib().orc_trigger_free(self._t)
+            except Exception:
+                pass
+            self._t = None
 
     def feed(self, blocks):
         blocks = _f32(blocks)
