@@ -10,7 +10,7 @@
 # leak checking off: the interpreter never frees its own arenas).  usage: bash tests/san_check.sh [logfile]
 set -e -o pipefail   # a sanitizer abort or a failing test ends the script non-zero (tail / tee no longer hide the status)
 R=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$R/profiles/r04_sanitizers.txt}
+LOG=${1:-$R/profiles/r05_sanitizers.txt}
 cd $R
 make -C oracle -s SAN=1
 make -C tests/emu -s SAN=1
