@@ -226,7 +226,15 @@ struct FftP2 {
     }
 };
 
-template <int LOG2N, bool INV, int M, typename TwPtr>
+// LB: the workgroup barriers between the stages order LDS traffic only and the caller keeps global requests in flight across them
+// (pfb_p2_kernel): `s_waitcnt lgkmcnt(0); s_barrier` instead of __syncthreads(), whose fence also waits for those requests (vmcnt(0))
+template <bool LB>
+__device__ __forceinline__ void fftp2_barrier()
+{
+    if constexpr (LB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
+template <int LOG2N, bool INV, int M, typename TwPtr, bool LB = false>
 __device__ __forceinline__ void fftp2_rest(float2 *Ls, TwPtr tw, int tid)
 {
     using F = FftP2<LOG2N>;
@@ -252,8 +260,8 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, TwPtr tw, int tid)
 #pragma unroll
             for (int j = 0; j < 16; ++j) Ls[F::phys(base + j * M)] = a[j];
         }
-        __syncthreads();
-        fftp2_rest<LOG2N, INV, 16 * M>(Ls, tw, tid);
+        fftp2_barrier<LB>();
+        fftp2_rest<LOG2N, INV, 16 * M, TwPtr, LB>(Ls, tw, tid);
     } else if constexpr (M <= N / 4) { // one stage left
         constexpr int FS = N / (4 * M);
 #pragma unroll 1
@@ -265,25 +273,25 @@ __device__ __forceinline__ void fftp2_rest(float2 *Ls, TwPtr tw, int tid)
             bfly4<INV>(a0, a1, a2, a3, tw_get(tw, (unsigned)kk, (unsigned)FS, 1), tw_get(tw, (unsigned)kk, (unsigned)FS, 2), tw_get(tw, (unsigned)kk, (unsigned)FS, 3));
             Ls[F::phys(base)] = a0; Ls[F::phys(base + M)] = a1; Ls[F::phys(base + 2 * M)] = a2; Ls[F::phys(base + 3 * M)] = a3;
         }
-        __syncthreads();
+        fftp2_barrier<LB>();
     }
 }
 
 // every stage of the transforms of one workgroup image in LDS (leaf order in, natural order out); ends with a workgroup barrier
-template <int LOG2N, bool INV>
+template <int LOG2N, bool INV, bool LB = false>
 __device__ __forceinline__ void fftp2_lds_stages(float2 *Ls, const float2 *__restrict__ tw, const float2 *__restrict__ Tord, int tid)
 {
     using F = FftP2<LOG2N>;
     constexpr int N = F::N, E = F::E;
     if constexpr (!F::ODD) {
-        fftp2_rest<LOG2N, INV, 1>(Ls, tw, tid); // powers of four: stages m = 1, 4, ... straight away
+        fftp2_rest<LOG2N, INV, 1, const float2 *, LB>(Ls, tw, tid); // powers of four: stages m = 1, 4, ... straight away
     } else if constexpr (N == 2) {
         for (int g = tid; g < E / 2; g += 256) {
             float2 a0 = Ls[F::phys(2 * g)], a1 = Ls[F::phys(2 * g + 1)];
             bfly2(a0, a1, tw[0]);
             Ls[F::phys(2 * g)] = a0; Ls[F::phys(2 * g + 1)] = a1;
         }
-        __syncthreads();
+        fftp2_barrier<LB>();
     } else {
         // first pass: radix-2 (m = 1) then radix-4 (m = 2) on 8 consecutive positions
         constexpr int FS = N / 8;
@@ -300,9 +308,9 @@ __device__ __forceinline__ void fftp2_lds_stages(float2 *Ls, const float2 *__res
 #pragma unroll
             for (int j = 0; j < 8; ++j) Ls[F::phys(8 * g + j)] = a[j];
         }
-        __syncthreads();
-        if constexpr (LOG2N == 9) fftp2_rest<LOG2N, INV, 8>(Ls, TwProgram<512, 2>{Tord}, tid); // 512: the stage-ordered copy (+6 %; nothing below)
-        else fftp2_rest<LOG2N, INV, 8>(Ls, tw, tid);
+        fftp2_barrier<LB>();
+        if constexpr (LOG2N == 9) fftp2_rest<LOG2N, INV, 8, TwProgram<512, 2>, LB>(Ls, TwProgram<512, 2>{Tord}, tid); // 512: the stage-ordered copy (+6 %; nothing below)
+        else fftp2_rest<LOG2N, INV, 8, const float2 *, LB>(Ls, tw, tid);
     }
 }
 
@@ -382,8 +390,16 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
     for (int c = 0; c < CPT; ++c)
 #pragma unroll
         for (int p = 0; p < P; ++p) gt[c][p] = h[M * p + chan(c)];
-    float2 hist[CPT][P - 1], cur[CPT][TR], nx[CPT][TR];
-    // rows past the stream's end are clamped (their outputs are never stored)
+    float2 hist[CPT][P - 1], ra[CPT][TR], rb[CPT][TR];
+    // The transform's twiddles live in LDS for the life of the workgroup (round 5): read from global memory inside the stages they are vector
+    // loads whose wait (vmcnt: loads return in order) also waits for the NEXT iteration's rows requested at the top of this one -- and every
+    // barrier below is an LDS-only barrier for the same reason (__syncthreads() waits for all requests in flight).  M <= 1024 entries.
+    float2 *Ltw = Ls + F::LDS_ELEMS, *Ltord = Ltw + 512; // the M-entry table; for 512 channels also the stage-ordered copy (510 entries) behind it
+    for (int i = tid; i < M; i += 256) Ltw[i] = tw[i];
+    if constexpr (LOG2M == 9)
+        for (int i = tid; i < 510; i += 256) Ltord[i] = Tord[i];
+    // rows past the stream's end are clamped (their outputs are never stored); ONE path, never skipped: the compiler can then count the
+    // requests in flight at every use instead of waiting for all of them
     auto ld_row = [&](long r, float2 *dst /* [CPT], stride given by `step` */, int step) {
         const float2 *rowp = x + (long)M * (r < last_in_row ? r : last_in_row);
 #pragma unroll
@@ -397,14 +413,15 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
 #pragma unroll
     for (int p = 0; p < P - 1; ++p) ld_row(t0 + p, &hist[0][p], P - 1);
 #pragma unroll
-    for (int ti = 0; ti < TR; ++ti) ld_row(t0 + P - 1 + ti, &cur[0][ti], TR);
+    for (int ti = 0; ti < TR; ++ti) ld_row(t0 + P - 1 + ti, &ra[0][ti], TR);
     const int cpg = M / ngroups;
-    for (int it = 0; it < iters; ++it) {
+    fftp2_barrier<true>(); // the twiddle copy is complete
+    // one iteration: rows tb .. tb + TR - 1 from `cur`, the next iteration's rows requested into `nx` (the loop below is unrolled by two with
+    // the two register sets swapping roles: a copy nx -> cur of a loop-carried array lands behind the iteration's stores and waits for them)
+    auto iteration = [&](int it, float2(&cur)[CPT][TR], float2(&nx)[CPT][TR]) {
         const long tb = t0 + (long)TR * it;
-        if (it + 1 < iters) {
 #pragma unroll
-            for (int ti = 0; ti < TR; ++ti) ld_row(tb + TR + P - 1 + ti, &nx[0][ti], TR);
-        }
+        for (int ti = 0; ti < TR; ++ti) ld_row(tb + TR + P - 1 + ti, &nx[0][ti], TR);
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             const int lp = (TR * g) * M + F::leaf_pos(chan(c));
@@ -421,8 +438,8 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
 #pragma unroll
             for (int p = 0; p < P - 1; ++p) hist[c][p] = hn[p];
         }
-        __syncthreads();
-        fftp2_lds_stages<LOG2M, false>(Ls, tw, Tord, tid);
+        fftp2_barrier<true>();
+        fftp2_lds_stages<LOG2M, false, true>(Ls, Ltw, Ltord, tid);
 #pragma unroll 2
         for (int e = 2 * tid; e < 4096; e += 512) { // two neighbouring channels per thread: one 16-byte store
             const int xf = e / M, n = e % M, gg = xf / TR, ti = xf % TR;
@@ -434,11 +451,11 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
                 else { out[(long)n * rows + row] = v0; out[(long)(n + 1) * rows + row] = v1; }
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CPT; ++c)
-#pragma unroll
-            for (int ti = 0; ti < TR; ++ti) cur[c][ti] = nx[c][ti];
+        fftp2_barrier<true>();
+    };
+    for (int it = 0; it < iters; it += 2) {
+        iteration(it, ra, rb);
+        if (it + 1 < iters) iteration(it + 1, rb, ra); // workgroup-uniform
     }
 }
 
@@ -460,7 +477,7 @@ static hipError_t launch_pfb_p2_t(const float2 *x, const float *h, const float2 
     if (rps < 64) rps = 64;
     const long nstreams = (rows + rps - 1) / rps;
     const unsigned grid = (unsigned)((nstreams + G - 1) / G);
-    const size_t lds = (size_t)F::LDS_ELEMS * sizeof(float2);
+    const size_t lds = (size_t)(F::LDS_ELEMS + 1024) * sizeof(float2); // the image + the twiddles
     if (fused) hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, true, PAIR>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
     else hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, false, PAIR>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
     return hipGetLastError();
