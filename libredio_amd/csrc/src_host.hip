@@ -644,11 +644,15 @@ static int try_uniform_window(redio_src *f, const SrcInput &in, long in_count, f
     if (rc) return rc;
     const bool fast = f->mode == REDIO_SRC_FAST;
     if (fast) { rc = prepare_fast_taps(f, S, scale); if (rc) return rc; }
-    // rebuild the final image into the other buffer: [b_current - reach, b_end) with `reach` the WIDEST filter's (ratio 1 / 256), not this
+    // the final image.  A call without a move (A0 == 0: the library only appended) appends the new samples to the LIVE image in place, like
+    // prepare_data above -- the launch reads the image below a_in0 only and the append writes from a_in0 on, so the image keeps everything
+    // since its last move and a small message costs its own samples, not the widest filter's reach (round 5; advisor, round 4).
+    // A call with a move rebuilds the other buffer: [b_current - reach, b_end) with `reach` the WIDEST filter's (ratio 1 / 256), not this
     // call's -- a later call with a lower ratio reads that far back, and the library's buffer holds the true history there
     // (round 4: rebuilding only this call's half left stale cells a falling ratio then read; tests/fuzz_parity.py seed 60407)
-    const int other = f->cur ^ 1;
-    long j0 = (long)b_current - f->front, j1 = b_end;
+    const bool in_place = A0 == 0;
+    const int other = in_place ? f->cur : f->cur ^ 1;
+    long j0 = in_place ? a_in0 : (long)b_current - f->front, j1 = b_end;
     if (j0 < 0) j0 = 0;
     hipError_t e = launch_src_window(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, f->d_cl, f->ncl, f->d_cr, f->ncr,
                                      f->d_T2, f->nm, f->d_Hp, f->fastp_nc, fast, a_first < 0 ? 0 : a_first, S, scale, d_out, out_stride, out_gen, f->nchan,
@@ -864,9 +868,11 @@ static int try_general_window(redio_src *f, const SrcInput &in, long in_count, f
         if (r != 1) return give_back(r);
         launched = out_gen;
     }
-    // rebuild [b_current - widest filter's reach, b_end) of the final image into the other buffer (see try_uniform_window)
-    const int other = f->cur ^ 1;
-    long j0 = (long)b_current - f->front, j1 = b_end;
+    // the final image: appended in place when the call moved nothing, else [b_current - widest filter's reach, b_end) rebuilt into the other
+    // buffer (see try_uniform_window)
+    const bool in_place = A0 == 0;
+    const int other = in_place ? f->cur : f->cur ^ 1;
+    long j0 = in_place ? a_in0 : (long)b_current - f->front, j1 = b_end;
     if (j0 < 0) j0 = 0;
     SRC_TRY(launch_src_window_image(f->d_buf[f->cur], f->buf_stride, in.dev, in.in_stride, a_in0, A0, j0, j1, f->d_buf[other], f->nchan, st));
     f->cur = other;

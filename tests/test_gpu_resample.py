@@ -488,6 +488,30 @@ def test_ratio_decrease_reaches_in_front_of_the_buffer(gpu, redio, oracle, conv,
             assert total > 40                           # the widened best-quality filter did produce outputs in the calls that reach back
 
 
+# round 5: a call that moves nothing appends to the live image in place (src_host.hip, try_uniform_window / the tile form); a long run of small
+# messages -- several buffer moves apart, the ratio falling and rising between them -- must read the same history the library's buffer holds
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv,nch", [(0, 1), (1, 3), (2, 2)])
+def test_many_small_messages_with_falling_and_rising_ratios(gpu, redio, oracle, conv, nch):
+    rng = np.random.default_rng(500 + conv)
+    for mode in (redio.Src.EXACT, redio.Src.EPOCHS):
+        plan = redio.Src(nch, conv, mode=mode)
+        refs = [oracle.Resampler(conv) for _ in range(nch)]
+        ratio = 0.02
+        rs = np.random.default_rng(77)
+        for i in range(70):
+            m = int(rs.integers(200, 5000)) if i % 9 else int(rs.integers(1, 40))
+            if i and i % 7 == 0: ratio = float(rs.choice([0.02, 0.01, 0.005, 0.04, 1 / 64, 0.02, 0.0213]))
+            x = np.stack([oracle.synth_f32(int(rng.integers(1, 1 << 30)), 0, m) for _ in range(nch)])
+            cap = int(ratio * m + 1.0)
+            got, used = plan.process(gpu.from_numpy(x).cuda(), ratio, output_frames=cap, end_of_input=False)
+            got = got.cpu().numpy()
+            for c in range(nch):
+                e2, want, u2 = refs[c].process(x[c], ratio, cap, False)
+                assert (0, used, got.shape[1]) == (e2, u2, len(want)), (conv, mode, i, m, ratio)
+                assert np.array_equal(bits(got[c]), bits(want)), (conv, mode, i, m, ratio, c)
+
+
 # found by the randomised run with ratios over the library's whole range (round 4): end_of_input at a ratio of 1 / 256 makes prepare_data's
 # last move longer than the buffer (libsamplerate 0.1.8 overruns its allocation); defined as SRC_ERR_SINC_PREPARE_DATA_BAD_LEN (include/samplerate.h (iv))
 EOI_SMALLEST = [(342, 474237719, '0x1.0000000000000p+0', 343, 0), (4, 835049986, '0x1.a074d40eaf3ffp-3', 1, 0),
