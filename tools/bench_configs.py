@@ -235,6 +235,23 @@ if "srcgen" in which:
             per, gen = plan.path_counts()
             print(f"resample ratio {ratio:.5f} x{nch} ch, {frames} frames ({name}; epochs periodic/general {per}/{gen}): {best*1e3:.2f} ms  "
                   f"{nch*used/best/1e9:.3f} GS/s in, {best*1e9/(nch*used):.3f} ns per input frame, {out.shape[1]} out per channel")
+if "srcsmall" in which:
+    # the reference's calling pattern (samplerate.rs:59-87: one message per src_process call): small messages x 256 channels at 1/50, per-call time on
+    # the stream and on the host clock -- catches a per-call cost that does not scale with the message (round 4's image rebuild; advisor, round 4)
+    import time
+    nch = 256
+    for frames in (1024, 4096, 16384, 65536):
+        x = torch.stack([R.synth_f32(100 + c, 0, frames) for c in range(nch)])
+        for name, mode in (("exact", R.Src.EXACT), ("fast", R.Src.FAST)):
+            plan = R.Src(nch, 1, mode=mode)
+            for _ in range(20): plan.process(x, 0.02)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter(); e0.record()
+            for _ in range(200): plan.process(x, 0.02)
+            e1.record(); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 200
+            print(f"resample 1/50 x{nch} ch, {frames} frames per message ({name}): {e0.elapsed_time(e1) / 200 * 1e3:.1f} us per call on the stream, "
+                  f"{wall * 1e6:.1f} us wall, {nch * frames / wall / 1e9:.2f} GS/s")
 if "c4gen" in which:
     for M, P in ((64, 16), (32, 16), (128, 16), (256, 16), (256, 8), (128, 8), (32, 4), (512, 8), (1024, 4), (64, 12)):
         h = R.dsputils.lpf_corrected(M * P, 0.45 / M)

@@ -9,4 +9,4 @@ python3 tests/fuzz_parity.py 480 50501 > $O/${TAG}_fuzz_all.txt 2>&1; grep -E "^
 FUZZ_ONLY=13 python3 tests/fuzz_parity.py 150 50502 > $O/${TAG}_fuzz_fast.txt 2>&1; grep -E "^runs|^FAIL" $O/${TAG}_fuzz_fast.txt | tail -2
 FUZZ_SRC_HARD=1 FUZZ_ONLY=5,9 python3 tests/fuzz_parity.py 150 50503 > $O/${TAG}_fuzz_srchard.txt 2>&1; grep -E "^runs|^FAIL" $O/${TAG}_fuzz_srchard.txt | tail -2
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_flags.json 2> $O/${TAG}_bench_driver_flags.err; cut -c1-300 $O/${TAG}_bench_driver_flags.json
-python3 tools/bench_configs.py c3 c3big c4 firshapes > $O/${TAG}_lines.txt 2>&1; grep -v amdgpu $O/${TAG}_lines.txt | cut -c1-170
+python3 tools/bench_configs.py c3 c3big c4 firshapes srcsmall > $O/${TAG}_lines.txt 2>&1; grep -v amdgpu $O/${TAG}_lines.txt | cut -c1-170

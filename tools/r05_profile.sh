@@ -13,7 +13,7 @@ if [ "$2" != "notests" ]; then
 fi
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_flags.json 2> $O/${TAG}_bench_driver_flags.err
 python3 bench.py --no-cpu-baseline > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
-python3 tools/bench_configs.py c3 c4 c5 fir fft firshapes srcgen ingest u8chain > $O/${TAG}_other_configs_bench_lines.txt 2>&1
+python3 tools/bench_configs.py c3 c4 c5 fir fft firshapes srcgen srcsmall ingest u8chain > $O/${TAG}_other_configs_bench_lines.txt 2>&1
 python3 tools/bench_bigfft.py > $O/${TAG}_bigfft_bench_lines.txt 2>&1
 python3 tools/bench_configs.py c3big > $O/${TAG}_c3big_lines.txt 2>&1
 python3 tools/bench_configs.py hipfft > $O/${TAG}_vendor_fft_yardstick.txt 2>&1   # same-hardware yardstick, never the engine
