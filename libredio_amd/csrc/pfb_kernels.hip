@@ -19,10 +19,17 @@ namespace redio {
 // Prefetch of the next tile's rows: cf32 rows are requested BEFORE the current tile's arithmetic into a second set of registers; u8 rows
 // AFTER the branch filters, into the registers those have just emptied (164 instead of 180+ registers: 0.765 -> 0.726 ms from bytes; the
 // cf32 kernel measured 0.810 -> 0.825 ms that way and keeps the early request; profiles/r04_channelizer_64_experiments.txt)
+// IN_U8 == 2 (round 5; 4-byte aligned streams, the grouped output layouts): a wave instruction loads TWO rows of bytes, one dword (two samples)
+// per lane -- lanes 0-31 the even row of the pair, lanes 32-63 the odd one -- through a buffer descriptor over the wave's own byte range
+// (requests past the stream's end return zeros: no clamp arithmetic), and lane l takes its sample out of the dword of lane l / 2 (+ 32) with a
+// ds_bpermute and a shift when the row enters the window.  A 16-row set is 8 registers instead of 16, so the next tile's rows are requested
+// EARLY into a second set at the register count of the late form.  Measured on one box (profiles/r05_channelizer_u8_two_row_loads.txt): the
+// grouped x8 layout (two wavefronts per SIMD either way) 0.820 -> 0.757 ms; the row-major layout (three wavefronts per SIMD in the 2-byte form)
+// 0.675 -> 0.703 ms, also with the stores through a range-checked descriptor and the loop's waits counted past them -- it keeps IN_U8 == 1.
 #ifndef REDIO_PFB_LATE_PREFETCH
-#define REDIO_PFB_LATE_PREFETCH IN_U8
+#define REDIO_PFB_LATE_PREFETCH (IN_U8 == 1)
 #endif
-template <int P, bool FUSED, bool ROWMAJOR, bool IN_U8 = false>
+template <int P, bool FUSED, bool ROWMAJOR, int IN_U8 = 0>
 __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x, const float *__restrict__ h,
                                                     const float2 *__restrict__ tw, float2 *__restrict__ out, long rows,
                                                     long rows_per_wave, int ngroups)
@@ -41,22 +48,50 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     for (int p = 0; p < P; ++p) g[p] = h[PFB_M * p + lane];
     // row r of the input = (x + 64 r)[lane]: wave-uniform row pointer + one 32-bit lane offset per load; rows past the
     // end of the stream (only the last tiles of the last wave ever ask for them) are clamped on a separate path
-    using raw_t = typename std::conditional<IN_U8, unsigned short, float2>::type; // one sample as it lies in memory
+    constexpr bool PAIRS = IN_U8 == 2;
+    using raw_t = typename std::conditional<IN_U8 != 0, unsigned short, float2>::type; // one sample as it lies in memory
+    using set_t = typename std::conditional<PAIRS, unsigned, raw_t>::type;              // one register of a row set
+    constexpr int NSET = PAIRS ? PFB_TILE / 2 : PFB_TILE;
     const raw_t *xraw = reinterpret_cast<const raw_t *>(x);
     auto sample = [](raw_t w) -> float2 {
-        if constexpr (IN_U8) return make_float2(i2f(w & 255u), i2f((unsigned)w >> 8));
+        if constexpr (IN_U8 != 0) return make_float2(i2f(w & 255u), i2f((unsigned)w >> 8));
         else return w;
+    };
+    // PAIRS: the wave's byte range [row t0, the last row any of its tiles can ask for) and the lane constants of the extraction
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned bp_addr = 0, bp_shift = 0;
+    if constexpr (PAIRS) {
+        long nrows_here = rows + P - 1 - t0, cap = rows_per_wave + 2 * PFB_TILE + P;
+        nrows_here = nrows_here < cap ? nrows_here : cap;
+        nrows_here = nrows_here < (1l << 23) ? nrows_here : (1l << 23);
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<raw_t *>(xraw + PFB_M * t0), 0, (int)(nrows_here * (2 * PFB_M)), 0x00020000);
+        bp_addr = 4u * ((unsigned)lane >> 1);
+        bp_shift = 16u * ((unsigned)lane & 1u);
+    }
+    // row `ti` of a set, as this lane's sample
+    auto row_of = [&](const set_t(&set)[NSET], int ti) -> float2 {
+        if constexpr (PAIRS) {
+            const unsigned d = (unsigned)__builtin_amdgcn_ds_bpermute((int)(bp_addr + ((ti & 1) ? 128u : 0u)), (int)set[ti >> 1]);
+            const unsigned w = d >> bp_shift;
+            return make_float2(i2f(w & 255u), i2f((w >> 8) & 255u));
+        } else return sample(set[ti]);
     };
     // ONE straight-line path: a row past the end of the stream (only the last tiles of the last wave ever ask for one) is clamped with
     // scalar arithmetic, and a tile's request is never skipped (the last tile of a wave requests rows it will not use).  With a fast and a
     // clamped path, or a request under a condition, the compiler cannot count the loads in flight at a use and waits for ALL of them
     // (vmcnt(0)) in the middle of the branch filters -- i.e. for the request it issued a few instructions earlier.
-    auto load_rows = [&](raw_t(&dst)[PFB_TILE], long first) {
+    auto load_rows = [&](set_t(&dst)[NSET], long first) {
+        if constexpr (PAIRS) {
+            const unsigned soff = (unsigned)((first - t0) * (2 * PFB_M));
 #pragma unroll
-        for (int ti = 0; ti < PFB_TILE; ++ti) {
-            long r = first + ti;
-            r = r < last_in_row ? r : last_in_row;
-            dst[ti] = (xraw + PFB_M * r)[(unsigned)lane];
+            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4u * (unsigned)lane, soff + 4u * PFB_M * k, 0);
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < PFB_TILE; ++ti) {
+                long r = first + ti;
+                r = r < last_in_row ? r : last_in_row;
+                dst[ti] = (xraw + PFB_M * r)[(unsigned)lane];
+            }
         }
     };
     // the transform's twiddles, once per wavefront (pfb_core.h: why not inside the tile loop): 20 scalar and 24 vector registers
@@ -80,12 +115,12 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     // roles of the two register sets swapped instead of copying nx -> cur: the copies of a loop-carried array land on the loop's back
     // edge, BEHIND the tile's eight stores, where their wait (vmcnt(0): stores count too on gfx950) made every tile pay the write
     // acknowledgement of the tile before it (round 5; and the transform's twiddles come from registers: pfb_core.h).
-    auto tile = [&](long tb, raw_t(&cur)[PFB_TILE], raw_t(&nx)[PFB_TILE]) {
+    auto tile = [&](long tb, set_t(&cur)[NSET], set_t(&nx)[NSET]) {
         if (!REDIO_PFB_LATE_PREFETCH) load_rows(nx, tb + PFB_TILE + P - 1);
         // branch FIRs: lane = branch, strict fold over p (dsputils.rs:31)
 #pragma unroll
         for (int ti = 0; ti < PFB_TILE; ++ti) {
-            win[(ti + P - 1) % P] = sample(cur[ti]);
+            win[(ti + P - 1) % P] = row_of(cur, ti);
             float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
             for (int p = 0; p < P; ++p) acc = mac<FUSED>(win[(ti + p) % P], g[p], acc);
@@ -131,7 +166,7 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
             }
         }
     };
-    raw_t ra[PFB_TILE], rb[PFB_TILE];
+    set_t ra[NSET], rb[NSET];
     load_rows(ra, t0 + P - 1);
     for (long tb = t0; tb < t1; tb += 2 * PFB_TILE) {
         if constexpr (REDIO_PFB_LATE_PREFETCH) { // one register set: the request goes into the registers the branch filters have emptied
@@ -149,7 +184,7 @@ bool pfb_supported(int nchan, int taps_per_branch)
     return nchan == PFB_M && (taps_per_branch == 4 || taps_per_branch == 8 || taps_per_branch == 16);
 }
 
-template <int P, bool IN_U8 = false>
+template <int P, int IN_U8 = 0>
 static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw, float2 *out, long rows, int ngroups,
                                bool fused, hipStream_t s)
 {
@@ -190,7 +225,10 @@ hipError_t launch_pfb_u8(const void *bytes, const float *h, const float2 *tw64, 
 {
     if (rows <= 0) return hipSuccess;
     if (taps_per_branch != 16 || (reinterpret_cast<uintptr_t>(bytes) & 1)) return hipErrorNotSupported;
-    return launch_pfb_t<16, true>((const float2 *)bytes, h, tw64, out, rows, ngroups, fused, s);
+    // round 5: two rows per wave instruction (a dword per lane) for the grouped layouts when the bytes are 4-byte aligned
+    if (ngroups != 1 && !(reinterpret_cast<uintptr_t>(bytes) & 3) && !measure_env("REDIO_PFB_U8_SHORTS"))
+        return launch_pfb_t<16, 2>((const float2 *)bytes, h, tw64, out, rows, ngroups, fused, s);
+    return launch_pfb_t<16, 1>((const float2 *)bytes, h, tw64, out, rows, ngroups, fused, s);
 }
 
 } // namespace redio

@@ -133,6 +133,9 @@ while time.time() < t_end and not (STATE and ncases):
         got = R.Channelizer(h, M, P, fused=fused).from_bytes(torch.from_numpy(raw).cuda()[off:]).cpu().numpy()
         want = O.pfb_channelizer(O.data_to_samples(raw[off:]), h, M, P, fused)
         check("pfb_u8", got.shape == want.shape and np.array_equal(bits(got), bits(want)), (M, P, fused, rows, off))
+        if g > 1 and M % g == 0 and rows > 0:  # ... and into the grouped layout (64 x 16, 4-byte aligned: two rows per load instruction)
+            grp = R.Channelizer(h, M, P, fused=fused).from_bytes(torch.from_numpy(raw).cuda()[off:], ngroups=g).cpu().numpy()
+            check("pfb_u8_grouped", np.array_equal(bits(np.ascontiguousarray(grp.transpose(1, 0, 2)).reshape(want.shape)), bits(want)), (M, P, fused, rows, g, off))
     elif which == 6:    # ingest: bytes -> samples -> |x| -> block sums -> slicer, any length / offset
         from libredio_amd import bitfount as B
         n = int(rng.integers(1, 60000)); off = 8 * int(rng.integers(0, 3))

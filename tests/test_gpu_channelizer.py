@@ -236,21 +236,21 @@ def test_channelizer_from_u8_bytes(gpu, redio, oracle, M, P, fused):
     rng = np.random.default_rng(M + P)
     for rows, extra in ((0, 5), (1, 0), (17, 3), (400, M - 1), (5000, 1)):
         nsamp = M * (rows + P - 1) + extra if rows else M * (P - 1) + extra
-        raw = rng.integers(0, 256, 2 * nsamp + 2, dtype=np.uint8)
+        raw = rng.integers(0, 256, 2 * nsamp + 4, dtype=np.uint8)
         if len(raw) >= 256:
             raw[:256] = np.arange(256, dtype=np.uint8)
-        for off in (0, 2, 1):
+        for off in (0, 2, 1, 4):   # 0 / 4: two rows per load instruction (round 5); 2: one 2-byte load per sample; 1: converted first
             view = raw[off: off + 2 * nsamp]
             dv = gpu.from_numpy(raw).cuda()[off: off + 2 * nsamp]
             want = oracle.pfb_channelizer(oracle.data_to_samples(view), h, M, P, fused)
             got = plan.from_bytes(dv).cpu().numpy().reshape(-1, M)
             assert got.shape == np.asarray(want).reshape(-1, M).shape
             assert np.array_equal(bits(got), bits(np.asarray(want).reshape(-1, M))), (M, P, fused, rows, extra, off)
-        if rows and M % 4 == 0:
-            g = plan.from_bytes(gpu.from_numpy(raw).cuda()[: 2 * nsamp], ngroups=4).cpu().numpy().reshape(4, -1, M // 4)
-            want = np.asarray(oracle.pfb_channelizer(oracle.data_to_samples(raw[: 2 * nsamp]), h, M, P, fused)).reshape(-1, M)
+        for off in (0, 4, 2) if rows and M % 4 == 0 else ():   # grouped layouts; 0 / 4: two rows per load instruction, early request (round 5)
+            g = plan.from_bytes(gpu.from_numpy(raw).cuda()[off: off + 2 * nsamp], ngroups=4).cpu().numpy().reshape(4, -1, M // 4)
+            want = np.asarray(oracle.pfb_channelizer(oracle.data_to_samples(raw[off: off + 2 * nsamp]), h, M, P, fused)).reshape(-1, M)
             for q in range(4):
-                assert np.array_equal(bits(g[q]), bits(np.ascontiguousarray(want[:, q * (M // 4):(q + 1) * (M // 4)])))
+                assert np.array_equal(bits(g[q]), bits(np.ascontiguousarray(want[:, q * (M // 4):(q + 1) * (M // 4)]))), (M, P, fused, rows, off, q)
 
 
 @pytest.mark.gpu
@@ -265,6 +265,11 @@ def test_channelizer_from_u8_bytes_full_size(gpu, redio):
     got = plan.from_bytes(raw)
     x = B.data_to_samples(raw)
     want = plan(x)
+    assert got.shape == want.shape
+    assert gpu.equal(gpu.view_as_real(got).view(gpu.int32), gpu.view_as_real(want).view(gpu.int32))
+    del got, want
+    got = plan.from_bytes(raw, ngroups=8)       # the exchange's layout: two rows per load instruction, early request (round 5)
+    want = plan(x, ngroups=8)
     del x
     assert got.shape == want.shape
     assert gpu.equal(gpu.view_as_real(got).view(gpu.int32), gpu.view_as_real(want).view(gpu.int32))
