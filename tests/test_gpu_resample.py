@@ -310,6 +310,31 @@ def test_rational_ratios_take_the_periodic_phase_kernel_bit_exactly(gpu, redio, 
     assert lit.path_counts()[0] == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ratio,conv", [(48000 / 44100, 2), (1.5, 1), (2.0, 2), (0.3, 1), (4 / 3, 2)])
+def test_periodic_ratios_long_messages(gpu, redio, oracle, ratio, conv):
+    """Messages of several hundred thousand frames at periodic ratios -- dozens of buffer moves of the library's control flow inside one
+    call, two channels, carried state: the oracle's bits and counts, and the literal per-refill schedule's.  (Round 5 ran these calls
+    through a window form of the periodic-phase kernel, one launch per 65536 outputs with one set of tables per call: bit-identical and
+    8 x fewer launches, but no faster -- such calls are bound by the host's per-output recurrence; profiles/r05_src_periodic_window_null.txt.)"""
+    n = 420000
+    x = np.stack([oracle.synth_f32(900 + c, 0, n) for c in range(2)])
+    d = gpu.from_numpy(x).cuda()
+    new, lit = redio.Src(2, conv), redio.Src(2, conv, mode=redio.Src.EPOCHS)
+    refs = [oracle.Resampler(conv) for _ in range(2)]
+    for lo, hi in ((0, 260000), (260000, 260300), (260300, n)):
+        cap = int(ratio * (hi - lo) + 1.0)
+        a, ua = new.process(d[:, lo:hi].contiguous(), ratio, output_frames=cap)
+        b, ub = lit.process(d[:, lo:hi].contiguous(), ratio, output_frames=cap)
+        assert ua == ub and a.shape == b.shape
+        an = a.cpu().numpy()
+        assert np.array_equal(bits(an), bits(b.cpu().numpy())), (ratio, lo, hi)
+        for c in range(2):
+            err, want, wused = refs[c].process(x[c, lo:hi], ratio, cap)
+            assert err == 0 and wused == ua and np.array_equal(bits(an[c]), bits(want)), (ratio, c, lo, hi)
+    assert new.path_counts()[0] > 0
+
+
 def test_periodic_path_then_ratio_change_and_flush(gpu, redio, oracle):
     # a periodic message, then a varying-ratio one (general kernel), then end_of_input on a periodic ratio again
     n = 120000
