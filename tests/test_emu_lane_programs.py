@@ -231,3 +231,24 @@ def test_pair_g512_gather_pass(emu, oracle, lgn, inv):
     y = np.empty_like(x)
     assert emu.emu_pair_g512_fft(lgn, x, y, inv) > 0
     assert np.array_equal(bits(y), bits(oracle.fft(x, n, inverse=bool(inv))))
+
+
+def test_channelizer_two_row_byte_loads_lane_map():
+    """pfb_kernels.hip, IN_U8 == 2 (round 5): one wave instruction loads two 64-sample rows of u8 I/Q bytes, a dword per lane (lanes 0-31 the even
+    row of the pair, 32-63 the odd one); lane l then takes ITS sample -- bytes (2l, 2l + 1) of the row -- from the dword of lane l / 2 (+ 32) with a
+    ds_bpermute and a right shift by 16 (l & 1).  The map restated in numpy on random bytes, plus what the range-checked descriptor returns for a
+    pair whose second row lies past the end of the stream (zeros: the lanes of that row only)."""
+    rng = np.random.default_rng(12)
+    rows = rng.integers(0, 256, (2, 128), dtype=np.uint8)                # two rows of 64 samples x (I, Q)
+    dwords = rows.reshape(-1).view("<u4")                                # lane j holds bytes 4j .. 4j + 3 of the 256-byte pair
+    assert dwords.shape == (64,)
+    lane = np.arange(64)
+    for ti in (0, 1):
+        src_lane = (lane >> 1) + 32 * ti                                 # ds_bpermute address / 4
+        w = dwords[src_lane] >> (16 * (lane & 1)).astype(np.uint32)
+        i_byte, q_byte = w & 255, (w >> 8) & 255
+        assert np.array_equal(i_byte, rows[ti, 0::2]) and np.array_equal(q_byte, rows[ti, 1::2])
+    nbytes = 128                                                         # the stream ends after the first row of the pair
+    off = 4 * lane
+    got = np.where(off + 4 <= nbytes, dwords, 0)                         # raw buffer load: a lane out of range reads zero
+    assert np.array_equal(got[:32], dwords[:32]) and not got[32:].any()
