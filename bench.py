@@ -32,7 +32,12 @@ core, and the reference's own structure -- a thread per block with a heap Vec pe
 pre-conditioning's own per-launch HIP events), so that the line stays comparable round over round.  `other_configs` (rank 0, after
 the timed region, `--no-other-configs` skips it, about 1 s): BASELINE.json configs[2] (256 channels x 2^22 frames, exact and the opt-in
 f32 mode), configs[3] on one GPU (cf32 and u8 input), configs[4] on one GPU (65536-point blocks, 8193 taps) and the 65536-point
-transform alone, each {workload, alg_bytes, kernel_ms by HIP events after >= 100 ms of warm-up, frac of 8 TB/s, binding, kernel}.
+transform alone, each {workload, alg_bytes, kernel_ms by HIP events after >= 100 ms of warm-up, frac of 8 TB/s, binding, kernel,
+cpu_baseline = the oracle's restatement of that config on this host, one core and all cores on a stated prefix}; `kpn_graph_c2` = the
+chain behind the operator API (include/kpn_dev.hpp: one thread per block, messages through channels, bounded rings) against the bare
+plan launches, messages of 2^13 ... 2^28 samples, with the round-5 host path beside it (`tests/_build/kpn_tests bench_c2_list`, a child
+process); `dropin_calls` = microseconds per call of the host-buffer drop-ins (kiss_fft, src_process, redio_convolve_f32) with the
+oracle's CPU microseconds for the same call beside them.  `--no-graph-leg` skips those two (about 25 s).
 """
 import argparse
 import ctypes as C
@@ -63,6 +68,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs leg (BASELINE.json configs[2..4] and the 65536-point "
                                                                     "transform, each timed with HIP events after the timed region; rank 0 only)")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip other_configs.kpn_graph_c2 and other_configs.dropin_calls")
+    ap.add_argument("--moved-json", default=os.path.join(ROOT, "profiles", "r06_moved_bytes.json"), help="file with the PMC-measured HBM bytes per call of the "
+                                                                                                       "multi-pass configs (C5, 65536-point transform), keyed by kernel name")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=23, help="slice per CPU thread")
@@ -134,7 +142,185 @@ def cpu_baseline(log2n, min_seconds=12.0):
                                        f"src/ratpak.rs:60-185), CPU restatement of the reference"}}
 
 
-def other_configs(R, lib, stream, x, n):
+def _cpu_rate(make_call, units_per_call, seconds):
+    """(one-core units/s, all-core units/s, cores): `make_call()` returns a closure that runs the oracle once on private data (the C calls
+    release the GIL); one thread for ~seconds / 2, then one thread per host core for ~seconds / 2."""
+    import threading
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    f = make_call()
+    f()
+    t0, n1 = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds / 2:
+        f(); n1 += 1
+    one = n1 * units_per_call / (time.perf_counter() - t0)
+    if cores == 1:
+        return one, one, 1
+    calls = [f] + [make_call() for _ in range(cores - 1)]
+    done = [0] * cores
+    start = threading.Barrier(cores + 1)
+    deadline = [0.0]
+
+    def work(t):
+        start.wait()
+        while time.perf_counter() < deadline[0]:
+            calls[t](); done[t] += 1
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for t in th:
+        t.start()
+    deadline[0] = time.perf_counter() + seconds / 2
+    t0 = time.perf_counter()
+    start.wait()
+    for t in th:
+        t.join()
+    return one, sum(done) * units_per_call / (time.perf_counter() - t0), cores
+
+
+def cpu_baseline_configs(seconds_each=3.0):
+    """The oracle's restatement of BASELINE.json configs[2..4] on this host's cores (north_star: "the reference Rust+kissfft+libsamplerate path
+    timed on the same host cores ... in the same run"): one core, and one thread per core as independent replicas, each on a stated prefix
+    of the config's workload.  Reported beside the GPU figure, never a target."""
+    import oracle as O
+    out = {}
+
+    def rec(one, allc, cores, unit, sample):
+        return {"value": allc / 1e6, "unit": unit, "cores": cores, "kind": "port", "single_core": {"value": one / 1e6, "unit": unit, "cores": 1}, "sample": sample}
+
+    # configs[2]: libsamplerate's medium sinc converter at ratio 0.02, one mono channel per state (samplerate.rs:59-87), messages of 2^16 frames
+    def c3():
+        st, x = O.Resampler(1), O.synth_f32(100, 0, 1 << 16)
+        st.block(x, 0.02)
+        return lambda: st.block(x, 0.02)
+    one, allc, cores = _cpu_rate(c3, 1 << 16, seconds_each)
+    out["c3"] = rec(one, allc, cores, "MSamples/s (input)", "oracle/oracle_src.c (orc_src_process: libsamplerate 0.1.8's sinc converter restated, medium quality, ratio 0.02), "
+                    "one converter state per thread fed 2^16-frame messages of one channel again and again; the config has 256 such channels")
+
+    # configs[3]: 64 channels x 16 taps per branch, 2^18 samples per call
+    h4 = O.lpf_corrected(1024, 0.45 / 64)
+    def c4():
+        x = O.synth_iq(0x5EED0004, 0, 1 << 18)
+        return lambda: O.pfb_channelizer(x, h4, 64, 16, True)
+    one, allc, cores = _cpu_rate(c4, 1 << 18, seconds_each)
+    out["c4"] = rec(one, allc, cores, "MSamples/s", "oracle/oracle_dsp.c (orc_pfb_channelizer: branch folds of dsputils.rs:31 + the kissfft restatement across 64 branches), "
+                    "2^18-sample slices of the hash-generated stream per call")
+
+    # configs[4]: overlap-save, 65536-point blocks, 8193 taps; 4 blocks per call
+    h5 = O.lpf_corrected(8193, 0.08)
+    hop = 65536 - 8193 + 1
+    def c5():
+        x = O.synth_iq(0x5EED0005, 0, 65536 + 3 * hop)
+        return lambda: O.overlap_save(x, h5, 65536)
+    one, allc, cores = _cpu_rate(c5, 4 * hop, seconds_each)
+    out["c5"] = rec(one, allc, cores, "MSamples/s (output)", "oracle/oracle_dsp.c (orc_overlap_save over the kissfft restatement: 65536-point blocks, 8193 taps), 4 blocks per call")
+
+    # the 65536-point transform alone
+    def f64k():
+        x = O.synth_iq(2, 0, 4 * 65536)
+        return lambda: O.fft(x, 65536)
+    one, allc, cores = _cpu_rate(f64k, 4 * 65536, seconds_each / 2)
+    out["fft_65536"] = rec(one, allc, cores, "MSamples/s", "oracle/oracle_kiss.c (kissfft 1.3.0 restated, 4^8 butterflies), 4 transforms per call")
+    return out
+
+
+def kpn_graph_leg(cpu_kpn_msps, timeout=90):
+    """other_configs.kpn_graph_c2: the chain behind the operator API.  Runs tests/_build/kpn_tests bench_c2_list in a child process (this
+    process only holds memory meanwhile): source (4 resident messages, cycled) -> dev::fir_fft_chain -> sink, one OS thread per block, against
+    the same launches made bare from one thread; see the header of bench_c2 in tests/cpp/kpn_tests.cpp."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "_build", "kpn_tests")
+    if not os.path.exists(exe):
+        return {"error": f"{os.path.relpath(exe, ROOT)} is missing (built by __graft_entry__.build())"}
+    shipped = [(13, 12000), (16, 12000), (20, 10000), (22, 5000), (24, 2000), (26, 1000), (28, 340)]
+    specs = [f"{k}:{n}:4:0:0:resident:checksum" for k, n in shipped]
+    specs += [f"{k}:{n}:4:0:0:resident:drop" for k, n in ((24, 4000), (28, 340))]
+    specs += [f"{k}:{n}:0:1:1:resident:checksum" for k, n in ((16, 4000), (24, 200), (28, 28))]          # the round-5 host path
+    specs += ["28:200:4:0:0:synth:drop"]                                                                     # input generated per message
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run([exe, "bench_c2_list"] + specs, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"kpn_tests bench_c2_list did not finish in {timeout} s"}
+    pts = []
+    for line in p.stdout.splitlines():
+        if line.startswith("{"):
+            pts.append(json.loads(line))
+    if p.returncode != 0 or not pts:
+        return {"error": f"kpn_tests bench_c2_list rc={p.returncode}: {p.stderr[-400:]}"}
+
+    def slim(r):
+        return {"log2_msg": r["log2_msg"], "messages": r["messages"], "graph_gsps": r["graph_gsps"], "bare_gsps": r["bare_gsps"], "frac_of_bare": r["frac_of_bare"],
+                "frac_of_bare_chain_only": r["frac_of_bare_chain_only"], "graph_us_per_msg": r["graph_us_per_msg"], "bare_us_per_msg": r["bare_us_per_msg"],
+                "mallocs_in_timed_region": r["mallocs_in_timed_region"]}
+
+    sel = lambda **kw: [slim(r) for r in pts if all(r[k] == v for k, v in kw.items())]
+    ship = sel(ring=4, host_sync=0, source="resident", sink="checksum")
+    over = [r["log2_msg"] for r in ship if r["graph_gsps"] * 1e3 > cpu_kpn_msps] if cpu_kpn_msps else []
+    return {"workload": "BASELINE.json configs[1] behind the operator API (include/kpn_dev.hpp; kpn.rs:278-291, kissfft.rs:18-31, ratpak.rs:60-185): source -> "
+                        "dev::fir_fft_chain (127 taps / 5 -> 1024-point transform) -> sink, one OS thread per block, messages through channels, bounded rings of 4 "
+                        "buffers per block, compute blocks on the shared graph stream; GS/s of input samples that reach a spectrum; bare = the same launches "
+                        "(redio_chain_enqueue [+ redio_checksum_u32]) back to back from one thread on one stream, same buffers, same process",
+            "checksum_sink": ship, "drop_sink": sel(ring=4, host_sync=0, source="resident", sink="drop"),
+            "round5_host_path": sel(ring=0, host_sync=1),
+            "synth_source_drop_sink": sel(source="synth"),
+            "overtakes_cpu_kpn_pipeline_from_log2_msg": min(over) if over else None,
+            "cpu_kpn_pipeline_msps": cpu_kpn_msps,
+            "note": "frac_of_bare: graph rate / bare rate for the same work (chain + sink kernel); frac_of_bare_chain_only: against the chain launches alone "
+                    "(the checksum sink reads every spectrum word once more: 1.6 of 11.2 B per sample).  round5_host_path = no pool (hipMalloc + hipFree per message), "
+                    "hipStreamSynchronize before every send, a stream per block.  synth_source: every message generated afresh in the source block "
+                    "(8 more bytes per sample through HBM).  A message of 2^13 samples holds one 1024-point spectrum.",
+            "leg_seconds": time.perf_counter() - t0}
+
+
+def dropin_calls_leg(R):
+    """other_configs.dropin_calls: the reference's own call pattern, unmodified (kissfft.rs:26, samplerate.rs:76, dsputils.rs:30): host buffers in
+    and out, synchronous, one message per call.  Microseconds per call on this box (PCIe + launch bound) and the oracle's CPU restatement of
+    the same call on one core beside it."""
+    import numpy as np
+    import oracle as O
+    from libredio_amd import dsputils, samplerate
+    res = {}
+
+    def per_call(f, reps, warm=20):
+        for _ in range(warm):
+            f()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    # kiss_fft, N = 1024 (kissfft.rs:19,26)
+    K = R.kisslib()
+    cfg = K.kiss_fft_alloc(1024, 0, None, None)
+    x = O.synth_iq(3, 0, 1024); y = np.empty_like(x)
+    xp, yp = x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)
+    gpu = per_call(lambda: K.kiss_fft(cfg, xp, yp), 2000)
+    cpu = per_call(lambda: O.fft(x, 1024), 2000)
+    res["kiss_fft_1024"] = {"gpu_us_per_call": gpu, "cpu_oracle_us_per_call": cpu, "samples_per_call": 1024, "gpu_msps": 1024 / gpu, "cpu_msps": 1024 / cpu}
+    K.kiss_fft_free(cfg)
+    # src_process, 4096 frames, ratio 0.02, medium converter, mono (samplerate.rs:61-76)
+    st, ost = samplerate.State(1, 1), O.Resampler(1)
+    xr = O.synth_f32(5, 0, 4096)
+    gpu = per_call(lambda: st.block(xr, 0.02), 300, warm=10)
+    cpu = per_call(lambda: ost.block(xr, 0.02), 300, warm=10)
+    res["src_process_4096"] = {"gpu_us_per_call": gpu, "cpu_oracle_us_per_call": cpu, "samples_per_call": 4096, "gpu_msps": 4096 / gpu, "cpu_msps": 4096 / cpu}
+    st.close()
+    # redio_convolve_f32, 1024 samples x 63 taps (C1's message, dsputils.rs:30)
+    u, v = O.synth_f32(1, 0, 1024), O.lpf_corrected(63, 0.1)
+    gpu = per_call(lambda: dsputils.convolve(u, v), 1000)
+    cpu = per_call(lambda: O.convolve(u, v), 1000)
+    res["convolve_1024x63"] = {"gpu_us_per_call": gpu, "cpu_oracle_us_per_call": cpu, "samples_per_call": 1024, "gpu_msps": 1024 / gpu, "cpu_msps": 1024 / cpu}
+    res["note"] = ("host clock around back-to-back calls through ctypes (about 1 us of Python per call on both sides); gpu = libkissfft.so / libsamplerate.so / "
+                   "libredio.so as the reference's Rust would call them (pageable host buffers in and out, result present on return); cpu = oracle/ restatement of "
+                   "the same call, one core.  At these message sizes a call is bound by PCIe + launch latency, not by the kernel: the device-resident plans "
+                   "(kpn_graph_c2) are the throughput path")
+    return res
+
+
+def other_configs(R, lib, stream, x, n, moved_json=None):
     """Outside the timed region, rank 0 only, never `value`: the other BASELINE.json configs at SURVEY.md 8d's sizes, each timed with HIP
     events on the launch stream after >= 100 ms of back-to-back warm-up launches (the chip raises its clock over the first ~100 ms of a
     burst; tools/bench_configs.py times its lines the same way).  Every entry: workload, alg_bytes per call (SURVEY.md 8d's per-sample
@@ -174,6 +360,21 @@ def other_configs(R, lib, stream, x, n):
 
     res = {}
     t_leg = time.perf_counter()
+    moved = {}
+    if moved_json and os.path.exists(moved_json):
+        moved = json.load(open(moved_json))
+
+    def moved_over_alg(key, kernel_prefix, alg_bytes):
+        """PMC-measured HBM bytes per call / algorithmic bytes, from profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+        tools/pmc_moved.sh, FETCH_SIZE doubled); refused when the file was recorded for other kernels.  Not measured by this run."""
+        m = moved.get(key)
+        if not m:
+            return {"moved_bytes_over_alg": None, "moved_source": "no PMC record for this config in %s" % (os.path.relpath(moved_json, ROOT) if moved_json else None)}
+        if not any(k.startswith(kernel_prefix) for k in m.get("kernels", [])):
+            return {"moved_bytes_over_alg": None, "moved_source": "%s REFUSED: recorded for kernels %r" % (os.path.relpath(moved_json, ROOT), m.get("kernels"))}
+        return {"moved_bytes_over_alg": m["bytes_per_call"] / alg_bytes, "moved_bytes_per_call": m["bytes_per_call"],
+                "moved_source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of tools/pmc_moved.sh (FETCH_SIZE doubled, the gfx950 "
+                                "correction), summed over kernels %s of one call; not measured by this run" % (os.path.relpath(moved_json, ROOT), m["kernels"])}
 
     # --- configs[3] on one GPU: 64-channel polyphase filterbank, 16 taps per branch, the whole 2^28-sample slice (16 B per sample) ---
     h = R.dsputils.lpf_corrected(1024, 0.45 / 64)
@@ -204,7 +405,8 @@ def other_configs(R, lib, stream, x, n):
                                          % (o5.numel() // hop, o5.numel(), (o5.numel() // hop * N5 * 8 + (64 << 20) - 1) // (64 << 20)),
                                          b5 * o5.numel(), ms, "ovsave64k_step_kernel (gather / middle / last tiles interleaved per chunk step)",
                                          o5.numel(), "MSamples/s (output)",
-                                         moved_bytes_over_alg=3.07, note="three passes at the L2 boundary move 3.07 x the algorithmic bytes: the scheme's ceiling is 25 % at this pool's copy rate")
+                                         note="three passes at the L2 boundary move about 3 x the algorithmic bytes: the scheme's ceiling is 25 % at this pool's copy rate",
+                                         **moved_over_alg("c5_overlap_save_65536", "ovsave64k", b5 * o5.numel()))
     del o5, ovs
 
     # --- the 65536-point transform alone (kissfft::fft at configs[4]'s block size), 2^26 points per call, 16 B per point ---
@@ -215,7 +417,7 @@ def other_configs(R, lib, stream, x, n):
     ms = timed(lambda: fft(xs, out=of), 50)
     res["fft_65536"] = entry("kissfft::fft, 65536-point forward transforms, %d blocks (2^%d points) per call" % (m // 65536, m.bit_length() - 1),
                              16.0 * m, ms, "fftbig_first_kernel + fftbig_mid_kernel (two passes, 32 B moved per point)", m, "MSamples/s",
-                             moved_bytes_over_alg=2.0)
+                             **moved_over_alg("fft_65536", "fftbig", 16.0 * m))
     del of, fft
 
     # --- configs[2]: 256 channels x 2^22 frames, ratio 48000 / 2400000 = 0.02, medium-quality sinc converter (4.08 B per input frame) ---
@@ -229,7 +431,7 @@ def other_configs(R, lib, stream, x, n):
     nout3 = nch * frames * ratio
     for key, mode, kern, what in (("c3_resample_exact", R.Src.EXACT, "src_window_rb_kernel",
                                    "bit-identical to the oracle's libsamplerate-0.1.8 arithmetic: f32 -> f64 convert, separately rounded v_mul_f64 + v_add_f64 per tap"),
-                                  ("c3_resample_fast", R.Src.FAST, "src_window_fastp_kernel",
+                                  ("c3_resample_fast", R.Src.FAST, "src_window_fastp2_kernel",
                                    "opt-in REDIO_SRC_FAST mode: the same filter as an f32 polyphase bank (v_pk_fma_f32), tolerance-tested, NOT bit-identical")):
         plan = R.Src(nch, 1, mode=mode)
         plan.process(x3, ratio)                             # first call: history of zeros, same work
@@ -508,8 +710,22 @@ def main():
     if rank == 0 and not a.no_other_configs and not a.exact and not a.unfused and a.log2_samples >= 26:
         del out
         torch.cuda.empty_cache()
-        others = other_configs(R, lib, stream, x, n)
+        others = other_configs(R, lib, stream, x, n, a.moved_json)
+        if not a.no_cpu_baseline:
+            cb = cpu_baseline_configs()
+            for key, ck in (("c3_resample_exact", "c3"), ("c3_resample_fast", "c3"), ("c4_channelizer_cf32", "c4"), ("c4_channelizer_u8", "c4"),
+                            ("c5_overlap_save_65536", "c5"), ("fft_65536", "fft_65536")):
+                others[key]["cpu_baseline"] = cb[ck]
 
+    cpu_rec = None
+    if rank == 0:
+        # rank 0 only, also at N > 1 (the other ranks have nothing left to do; they wait in destroy_process_group)
+        cpu_rec = None if a.no_cpu_baseline else cpu_baseline(a.cpu_log2_samples)
+        if others is not None and not a.no_graph_leg:
+            del x
+            torch.cuda.empty_cache()
+            others["kpn_graph_c2"] = kpn_graph_leg(cpu_rec["kpn_pipeline"]["value"] if cpu_rec else None)
+            others["dropin_calls"] = dropin_calls_leg(R)
     if rank == 0:
         kavg = sum(kms) / len(kms) / 1e3  # s per launch (launch-to-launch on the stream)
         alg_bytes = (12.8 if a.unfused else ALG_BYTES_PER_SAMPLE) * used
@@ -574,6 +790,11 @@ def main():
         if u8_ms is not None:
             rec["from_u8_bytes"] = {"kernel_ms": u8_ms, "value_per_gpu": used / u8_ms / 1e3, "unit": "MSamples/s",
                                     "alg_bytes_per_sample": 3.6, "frac": 3.6 * used / (u8_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    # the binding roofline of this leg is the vector unit, not HBM: the same 111.6 flops per sample as the headline
+                                    # (the byte -> f32 conversion's divide and subtract are not counted) against the 157.3 TFLOP/s f32 vector peak
+                                    "valu": {"flops_per_sample": 4.0 * NTAPS / DECIM + 10.0, "tflops": (4.0 * NTAPS / DECIM + 10.0) * used / (u8_ms * 1e-3) / 1e12,
+                                             "peak_tflops": 157.3, "frac_of_157": (4.0 * NTAPS / DECIM + 10.0) * used / (u8_ms * 1e-3) / 1e12 / 157.3},
+                                    "binding": "valu",
                                     "note": "the same chain from interleaved u8 I/Q bytes (rtlsdr::data_to_samples folded into the kernel's "
                                             "loader, redio_chain_enqueue_u8): 2 + 1.6 bytes per sample, VALU-bound; a different input "
                                             "format from BASELINE.json configs[1] (f32 IQ), so beside value, never as value"}
@@ -583,8 +804,7 @@ def main():
             rec["other_configs"] = others
         if ranks_seen is not None:
             rec["ranks_seen"] = ranks_seen
-        # rank 0 only, also at N > 1 (the other ranks have nothing left to do; they wait in destroy_process_group)
-        rec["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline(a.cpu_log2_samples)
+        rec["cpu_baseline"] = cpu_rec
         print(json.dumps(rec))
     if dist is not None:
         dist.destroy_process_group()

@@ -47,6 +47,7 @@ const char *redio_version(void);
 /* ---- device / memory / stream / event helpers (thin, so non-torch hosts can drive plans) ---- */
 int redio_device_count(int *count);
 int redio_set_device(int device);
+int redio_get_device(int *device); /* the calling thread's current device */
 int redio_malloc(void **dptr, size_t bytes);
 int redio_free(void *dptr);
 int redio_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
@@ -78,6 +79,17 @@ int redio_event_create(void **event);
 int redio_event_destroy(void *event);
 int redio_event_record(void *event, void *stream);
 int redio_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+/* Ordering between the streams of different blocks without the host: an event for synchronisation only (no time stamps: cheaper to
+ * record than redio_event_create's), the wait a consumer's stream performs on the event its producer recorded (work enqueued on `stream`
+ * after this call runs after everything the producer's stream held when it recorded `event`; returns at once, nothing blocks the
+ * host), and the host-side wait for the places that really hand data to the CPU.  include/kpn_dev.hpp carries such an event in every
+ * message (the reference's channels order host Vecs, src/kpn/src/kpn.rs:11; on the device the event is that order). */
+int redio_event_create_sync(void **event);
+int redio_stream_wait_event(void *stream, void *event);
+int redio_event_sync(void *event);
+/* device allocations made through redio_malloc since the library was loaded (all threads): lets a host check that a steady-state
+ * graph no longer allocates (tests/test_kpn_cpp.py: a bounded ring never allocates after warm-up) */
+unsigned long long redio_malloc_count(void);
 
 /* ---- tap generators: src/dsputils/src/dsputils.rs:38-94 (host side, run once per filter) ----
  * Quirk-faithful to the reference as written (window() returns m+1 values, lpf()[1] is NaN, ...);
@@ -377,6 +389,10 @@ int redio_mul_f32(const void *d_a, const void *d_b, void *d_out, size_t n, void 
 int redio_add_f32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 int redio_mul_c32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 int redio_add_c32(const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+
+/* order-free 64-bit sum of the n 32-bit words at d_words, ADDED to the u64 at d_sum_u64 (device memory the caller zeroed; one atomic
+ * per workgroup): the checking sink of a device-resident graph -- reads every word a block produced, exact whatever the order */
+int redio_checksum_u32(const void *d_words, size_t n, void *d_sum_u64, void *stream);
 
 /* ---- synthetic input: hash-generated cf32 / f32 in [-1, 1), device side ---- */
 int redio_synth_iq(void *d_out, uint32_t seed, uint64_t first_sample, size_t n, void *stream);

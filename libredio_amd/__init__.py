@@ -62,6 +62,7 @@ def lib():
     _sig(L.redio_version, C.c_char_p)
     _sig(L.redio_device_count, i, C.POINTER(i))
     _sig(L.redio_set_device, i, i)
+    _sig(L.redio_get_device, i, C.POINTER(i))
     _sig(L.redio_malloc, i, C.POINTER(vp), sz)
     _sig(L.redio_free, i, vp)
     _sig(L.redio_upload, i, vp, vp, sz, vp)
@@ -75,6 +76,11 @@ def lib():
     _sig(L.redio_event_destroy, i, vp)
     _sig(L.redio_event_record, i, vp, vp)
     _sig(L.redio_event_elapsed_ms, i, vp, vp, C.POINTER(f))
+    _sig(L.redio_event_create_sync, i, C.POINTER(vp))
+    _sig(L.redio_stream_wait_event, i, vp, vp)
+    _sig(L.redio_event_sync, i, vp)
+    _sig(L.redio_malloc_count, C.c_ulonglong)
+    _sig(L.redio_checksum_u32, i, vp, sz, vp, vp)
     _sig(L.redio_window, i, sz, pf)
     for n in ("redio_sinc", "redio_lpf", "redio_hpf", "redio_lpf_corrected"):
         _sig(getattr(L, n), i, sz, f, pf)

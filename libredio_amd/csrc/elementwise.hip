@@ -5,6 +5,7 @@
 // its own -- Rust never contracts).  HBM-bound: 3 words moved per word produced.
 #include "../../include/redio.h"
 #include "redio_internal.h"
+#include <algorithm>
 
 namespace redio {
 
@@ -106,3 +107,51 @@ ZIP_ENTRY(redio_mul_f32, float, zip_f32_kernel, 0)
 ZIP_ENTRY(redio_add_f32, float, zip_f32_kernel, 1)
 ZIP_ENTRY(redio_mul_c32, float2, zip_c32_kernel, 0)
 ZIP_ENTRY(redio_add_c32, float2, zip_c32_kernel, 1)
+
+// ---- the checking sink of a device-resident graph: an order-free 64-bit sum of 32-bit words ----
+// Integer addition commutes, so lanes, waves and workgroups may add in any order and the result is exact: 16-byte loads, a per-lane u64
+// partial, a wave reduction by __shfl_xor (the order-free case of SURVEY.md 8f rank 1), one atomic per workgroup.  HBM-bound: 4 B per word.
+namespace redio {
+__global__ __launch_bounds__(256) void checksum_u32_kernel(const uint4 *__restrict__ v, long n4, const uint32_t *__restrict__ t, long tail,
+                                                           unsigned long long *__restrict__ sum)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) { // four independent 16-byte loads in flight per lane
+        const uint4 a = v[i], b = v[i + stride], c = v[i + 2 * stride], d = v[i + 3 * stride];
+        acc += ((unsigned long long)a.x + a.y + a.z + a.w) + ((unsigned long long)b.x + b.y + b.z + b.w) +
+               ((unsigned long long)c.x + c.y + c.z + c.w) + ((unsigned long long)d.x + d.y + d.z + d.w);
+    }
+    for (; i < n4; i += stride) {
+        const uint4 w = v[i];
+        acc += (unsigned long long)w.x + w.y + w.z + w.w;
+    }
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < tail; k += stride) acc += t[k];
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+} // namespace redio
+
+extern "C" int redio_checksum_u32(const void *d_words, size_t n, void *d_sum_u64, void *stream)
+{
+    if (n == 0) return REDIO_OK;
+    if (!d_words || !d_sum_u64 || ((uintptr_t)d_words & 3) || ((uintptr_t)d_sum_u64 & 7)) return REDIO_ERR_ARG;
+    // words before the first 16-byte boundary and after the last whole group go through the scalar loop of the same launch
+    const size_t head = std::min(n, (size_t)((16 - ((uintptr_t)d_words & 15)) & 15) / 4);
+    const uint32_t *w = (const uint32_t *)d_words;
+    const size_t n4 = (n - head) / 4, rest = n - head - 4 * n4;
+    // two workgroups per CU at most: the sums meet in ONE atomic per workgroup, and 4096 of them on one address cost more than the reads
+    // of a 27 MB message (round 6: 53 us -> the read time)
+    long grid = (long)((n4 + 1023) / 1024);
+    grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+    if (head) // rare: an unaligned view; its few words take a launch of their own so that the main loop keeps one tail pointer
+        hipLaunchKernelGGL(checksum_u32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const uint4 *)nullptr, 0L, w, (long)head,
+                           (unsigned long long *)d_sum_u64);
+    hipLaunchKernelGGL(checksum_u32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)(w + head), (long)n4,
+                       w + head + 4 * n4, (long)rest, (unsigned long long *)d_sum_u64);
+    return hip_rc(hipGetLastError());
+}

@@ -2,6 +2,7 @@
 // happens on the host: every arithmetic entry point launches a gfx950 kernel or fails.
 #include "../../include/redio.h"
 #include "redio_internal.h"
+#include <atomic>
 #include <math.h>
 #include <mutex>
 #include <new>
@@ -50,11 +51,15 @@ extern "C" int redio_device_count(int *count)
     return REDIO_OK;
 }
 extern "C" int redio_set_device(int device) { return hip_rc(hipSetDevice(device)); }
+extern "C" int redio_get_device(int *device) { return device ? hip_rc(hipGetDevice(device)) : REDIO_ERR_ARG; }
+static std::atomic<unsigned long long> g_malloc_count{0};
 extern "C" int redio_malloc(void **dptr, size_t bytes)
 {
     if (!dptr) return REDIO_ERR_ARG;
+    g_malloc_count.fetch_add(1, std::memory_order_relaxed);
     return hip_rc(hipMalloc(dptr, bytes ? bytes : 1));
 }
+extern "C" unsigned long long redio_malloc_count(void) { return g_malloc_count.load(std::memory_order_relaxed); }
 extern "C" int redio_free(void *dptr) { return dptr ? hip_rc(hipFree(dptr)) : REDIO_OK; }
 extern "C" int redio_upload(void *dst, const void *src, size_t bytes, void *stream)
 {
@@ -152,6 +157,20 @@ extern "C" int redio_event_create(void **event)
     *event = e;
     return REDIO_OK;
 }
+extern "C" int redio_event_create_sync(void **event)
+{
+    if (!event) return REDIO_ERR_ARG;
+    hipEvent_t e;
+    RD_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return REDIO_OK;
+}
+extern "C" int redio_stream_wait_event(void *stream, void *event)
+{
+    if (!event) return REDIO_ERR_ARG;
+    return hip_rc(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+}
+extern "C" int redio_event_sync(void *event) { return event ? hip_rc(hipEventSynchronize((hipEvent_t)event)) : REDIO_ERR_ARG; }
 extern "C" int redio_event_destroy(void *event) { return event ? hip_rc(hipEventDestroy((hipEvent_t)event)) : REDIO_OK; }
 extern "C" int redio_event_record(void *event, void *stream) { return hip_rc(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); }
 extern "C" int redio_event_elapsed_ms(void *start, void *stop, float *ms)

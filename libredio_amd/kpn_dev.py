@@ -93,3 +93,14 @@ def mul_vecs(x, c):
 def sum_vecs(x, c):
     """kpn::sum_vecs (kpn.rs:227-231) on device tensors: x[i] + c[i] over the shorter length."""
     return _zip("redio_add_f32", "redio_add_c32", x, c)
+
+
+def checksum_u32(x, acc=None):
+    """The checking sink of a device-resident graph (redio_checksum_u32): the order-free 64-bit sum of every 32-bit word of x, ADDED to
+    acc (an int64 device tensor of one element; created zeroed when None).  Returns acc."""
+    import torch
+    assert x.is_contiguous() and (x.numel() * x.element_size()) % 4 == 0
+    if acc is None:
+        acc = torch.zeros(1, dtype=torch.int64, device=x.device)
+    check(lib().redio_checksum_u32(_dev_ptr(x), x.numel() * x.element_size() // 4, _dev_ptr(acc), current_stream()), "checksum_u32")
+    return acc

@@ -3,6 +3,10 @@
 //   kpn_tests c1 in.wav out.wav   BASELINE.json configs[0]: WAV -> shaper(1024) -> convolve(63 taps) -> WAV
 //   kpn_tests fft in.bin out.bin N inv      kissfft::fft block over raw cf32 messages of N samples
 //   kpn_tests resample in.bin out.bin ratio msg_len   samplerate::resample block over raw f32 messages
+//   kpn_tests devring msg nmsg depth warm policy host_sync   three device blocks on bounded rings: no allocation after message `warm`, checksum printed
+//   kpn_tests bench_c2 log2_msg nmsg depth resident|synth checksum|drop host_sync policy    one JSON line: graph against bare launches
+//   kpn_tests bench_c2_list log2:nmsg:depth:host_sync:policy:source:sink ...              the same for a list of points, one process
+//   kpn_tests bench_c2_sweep seconds_per_point before lo hi                          message sizes 2^lo ... 2^hi (step 4x)
 #include "../../include/kpn.hpp"
 #include "../../include/wavio.hpp"
 #include <sstream>
@@ -28,8 +32,190 @@ static std::vector<T> drain(Receiver<T> &r)
 template <typename T>
 static void feed(Sender<T> s, std::vector<T> v) { for (auto &x : v) s.send(x); }
 
+
+// ---- stand-ins for the device calls of dev::DeviceApi: host memory, counting "events" and "streams", so that the rings and the ordering
+// logic of include/kpn_dev.hpp (credits, recycling, who waits for whom, hand-over between threads, teardown) run here without a GPU and
+// under the sanitizers (tests/san_check.sh) ----
+namespace fake {
+static std::atomic<long> mallocs{0}, frees{0}, ev_live{0}, records{0}, waits{0}, streams_live{0};
+struct Ev { std::atomic<void *> on{nullptr}; };
+struct St { int dummy; };
+static int malloc_(void **p, size_t b) { *p = std::malloc(b ? b : 1); ++mallocs; return *p ? 0 : REDIO_ERR_NOMEM; }
+static int free_(void *p) { std::free(p); ++frees; return 0; }
+static int ev_create(void **e) { *e = new Ev; ++ev_live; return 0; }
+static int ev_destroy(void *e) { delete (Ev *)e; --ev_live; return 0; }
+static int ev_record(void *e, void *st) { ((Ev *)e)->on = st; ++records; return 0; }
+static int ev_wait(void *, void *e) { (void)((Ev *)e)->on.load(); ++waits; return 0; }
+static int st_create(void **s) { *s = new St; ++streams_live; return 0; }
+static int st_destroy(void *s) { delete (St *)s; --streams_live; return 0; }
+static int st_sync(void *) { return 0; }
+static int get_device(int *d) { *d = 0; return 0; }
+struct Install {
+    dev::DeviceApi saved;
+    Install() : saved(dev::api())
+    {
+        auto &a = dev::api();
+        a.malloc_ = malloc_; a.free_ = free_; a.event_create = ev_create; a.event_destroy = ev_destroy; a.event_record = ev_record;
+        a.stream_wait_event = ev_wait; a.stream_create = st_create; a.stream_destroy = st_destroy; a.stream_sync = st_sync; a.get_device = get_device;
+        mallocs = frees = ev_live = records = waits = streams_live = 0;
+    }
+    ~Install() { dev::api() = saved; }
+};
+} // namespace fake
+
+static int ring_logic()
+{
+    fake::Install inst;
+    using BS = dev::BlockStream;
+    { // credits: a ring of 2 parks the third acquire until a handle drops, and hands the SAME buffer back (no allocation).  Producer and
+      // consumer on different streams: the consumer orders itself behind the writer (one record THERE + one wait HERE), the recycled
+      // buffer's new writer behind the reader
+        BS sA(BS::TRANSFER), sB(BS::TRANSFER);
+        dev::Ring ring(2);
+        auto a = ring.acquire<float>(1000, sA);
+        auto b = ring.acquire<float>(1000, sA);
+        CHECK(fake::mallocs.load() == 2 && a.data() != b.data() && fake::records.load() == 0);
+        float *pa = a.data();
+        std::atomic<int> got{0};
+        float *pc = nullptr;
+        std::thread t([&] { auto c = ring.acquire<float>(1000, sA); pc = c.data(); got = 1; });
+        std::this_thread::sleep_for(std::chrono::milliseconds(30));
+        CHECK(got.load() == 0);            // no credit: parked
+        dev::publish(a, sA);
+        { dev::Reading<float> rd(a, sB); }
+        CHECK(fake::records.load() == 1 && fake::waits.load() == 1);
+        { dev::Reading<float> rd(a, sA); } // the writer's own stream reads it: same queue, nothing to do
+        CHECK(fake::records.load() == 1 && fake::waits.load() == 1);
+        a = dev::View<float>();            // last handle drops -> buffer back in the ring -> the parked acquire wakes
+        t.join();
+        CHECK(got.load() == 1 && pc == pa && fake::mallocs.load() == 2);
+        CHECK(fake::records.load() == 2 && fake::waits.load() == 2); // the new writer waited for reader sB only (sA is its own queue)
+    }
+    CHECK(fake::mallocs.load() == fake::frees.load() && fake::ev_live.load() == 0 && fake::streams_live.load() == 0);
+    { // the default policy: compute blocks share the device's graph stream -> producer, consumer and recycling need no event at all;
+      // a transfer block (own stream) reading the message does
+        BS s1, s2, sx(BS::TRANSFER);
+        CHECK((void *)s1 == (void *)s2 && (void *)sx != (void *)s1);
+        const long r0 = fake::records.load(), w0 = fake::waits.load();
+        dev::Ring ring(1);
+        for (int i = 0; i < 10; ++i) {
+            auto a = ring.acquire<int>(64, s1);
+            dev::publish(a, s1);
+            { dev::Reading<int> rd(a, s2); }
+        }
+        CHECK(fake::records.load() == r0 && fake::waits.load() == w0);
+        auto a = ring.acquire<int>(64, s1);
+        dev::publish(a, s1);
+        { dev::Reading<int> rd(a, sx); rd.complete(); }       // e.g. to_host: synchronised with the CPU, nothing left to wait for
+        CHECK(fake::records.load() == r0 + 1 && fake::waits.load() == w0 + 1);
+        a = dev::View<int>();
+        auto b2 = ring.acquire<int>(64, s1);
+        CHECK(fake::records.load() == r0 + 1);                 // no reader registered: the recycle is free
+        dev::set_stream_policy(dev::PER_BLOCK);
+        BS s3, s4;
+        CHECK((void *)s3 != (void *)s4);
+        dev::set_stream_policy(dev::SHARED);
+    }
+    { // size classes: a message a little longer reuses the buffer; a much longer one regrows it (one free + one malloc)
+        BS sA;
+        dev::Ring ring(1);
+        { auto a = ring.acquire<uint8_t>(1000, sA); }
+        const long m0 = fake::mallocs.load();
+        { auto a = ring.acquire<uint8_t>(1010, sA); }
+        CHECK(fake::mallocs.load() == m0);
+        { auto a = ring.acquire<uint8_t>(5000, sA); }
+        CHECK(fake::mallocs.load() == m0 + 1 && ring.grows() == 2);
+    }
+    { // the ring and the stream go (their block ended) while a message is still held downstream: the last handle frees the buffer,
+      // and the stream it names lives until then
+        dev::View<int> kept;
+        {
+            BS sA(BS::TRANSFER);
+            dev::Ring ring(3);
+            kept = ring.acquire<int>(10, sA);
+            dev::publish(kept, sA);
+            auto other = ring.acquire<int>(10, sA);
+        }
+        kept.data()[9] = 7; // still valid memory (ASan would object)
+        BS sB(BS::TRANSFER);
+        { dev::Reading<int> rd(kept, sB); } // records on the ended block's stream: still alive
+    }
+    { // depth 0: unpooled, one allocation per message (the before side of `bench_c2`)
+        BS sA;
+        const long m0 = fake::mallocs.load();
+        dev::Ring ring(0);
+        for (int i = 0; i < 5; ++i) { auto a = ring.acquire<int>(10, sA); }
+        CHECK(fake::mallocs.load() == m0 + 5);
+    }
+    for (int policy = 0; policy < 2; ++policy) {
+        // three block threads, rings of 2, 2000 messages, fork in the middle: every message arrives intact and in order at both sinks,
+        // and nothing is allocated after the first few messages (memory written and read by the host threads stands for the kernels)
+        dev::set_stream_policy(policy ? dev::PER_BLOCK : dev::SHARED);
+        auto [s1, r1] = channel<dev::View<uint32_t>>();
+        auto [s2a, r2a] = channel<dev::View<uint32_t>>();
+        auto [s2b, r2b] = channel<dev::View<uint32_t>>();
+        auto [s3, r3] = channel<dev::View<uint32_t>>();
+        const size_t N = 2000, L = 257;
+        std::atomic<long> mallocs_at_50{-1};
+        std::atomic<int> bad{0};
+        std::vector<std::thread> th;
+        th.push_back(spawn([s = std::move(s1), N, L]() mutable {
+            BS st;
+            dev::Ring ring(2);
+            for (size_t i = 0; i < N; ++i) {
+                auto d = ring.acquire<uint32_t>(L + i % 3, st);
+                for (size_t k = 0; k < d.len; ++k) d.data()[k] = (uint32_t)(i * 1000003u + k);
+                dev::publish(d, st);
+                s.send_unwrap(std::move(d));
+            }
+        }));
+        std::vector<Sender<dev::View<uint32_t>>> outs;
+        outs.push_back(std::move(s2a)); outs.push_back(std::move(s2b));
+        th.push_back(spawn([r = std::move(r1), o = std::move(outs)]() mutable { fork<dev::View<uint32_t>>(std::move(r), std::move(o)); }));
+        th.push_back(spawn([r = std::move(r2a), s = std::move(s3)]() mutable { // a map block: out = in + 1
+            BS st;
+            dev::Ring ring(2);
+            for (;;) {
+                auto d = r.recv();
+                auto o = ring.acquire<uint32_t>(d.len, st);
+                {
+                    dev::Reading<uint32_t> in(d, st);
+                    for (size_t k = 0; k < d.len; ++k) o.data()[k] = d.data()[k] + 1;
+                }
+                dev::publish(o, st);
+                s.send_unwrap(std::move(o));
+            }
+        }));
+        auto checker = [&bad, &mallocs_at_50, L](Receiver<dev::View<uint32_t>> r, uint32_t add) {
+            BS st(BS::TRANSFER);
+            size_t i = 0;
+            try {
+                for (;; ++i) {
+                    auto d = r.recv();
+                    dev::Reading<uint32_t> in(d, st);
+                    if (d.len != L + i % 3) ++bad;
+                    for (size_t k = 0; k < d.len; ++k) if (d.data()[k] != (uint32_t)(i * 1000003u + k) + add) { ++bad; break; }
+                    if (i == 50) mallocs_at_50 = fake::mallocs.load();
+                }
+            } catch (const hangup &) {}
+            if (i != 2000) ++bad;
+        };
+        th.push_back(spawn([&, r = std::move(r3)]() mutable { checker(std::move(r), 1); }));
+        th.push_back(spawn([&, r = std::move(r2b)]() mutable { checker(std::move(r), 0); }));
+        for (auto &t : th) t.join();
+        CHECK(bad.load() == 0);
+        CHECK(mallocs_at_50.load() > 0 && fake::mallocs.load() == mallocs_at_50.load()); // steady state: no allocation
+    }
+    dev::set_stream_policy(dev::SHARED);
+    CHECK(fake::mallocs.load() == fake::frees.load() && fake::ev_live.load() == 0);
+    CHECK(fake::streams_live.load() == 1); // the graph stream of device 0 lives for the process
+    std::puts("ring ok");
+    return 0;
+}
+
 static int plumbing()
 {
+    if (int rc = ring_logic()) return rc;
     { // channel: FIFO, blocking recv, hang-up when the last sender drops
         auto [tx, rx] = channel<int>();
         auto tx2 = tx;
@@ -667,6 +853,201 @@ static int dev_bytes_chain(const char *in, const char *out, size_t msg_bytes)
     return 0;
 }
 
+
+// A three-block device graph on bounded rings: synth source -> fused chain -> checksum sink, nmsg messages of msg samples, ring depth
+// `depth`.  A pass-through tap between chain and sink samples redio_malloc_count() after message `warm`: the graph must not allocate
+// after that (SURVEY.md 8b "credit/ring").  Prints the checksum of every spectrum word (checked against the oracle by the test).
+// policy 0: the blocks share the graph stream; 1: a stream per block (order made by events on demand); host_sync 1: the debugging mode.
+static int dev_ring_graph(size_t msg, size_t nmsg, size_t depth, size_t warm, int policy, int host_sync)
+{
+    using cf = std::complex<float>;
+    dev::set_default_ring_depth(depth);
+    dev::set_stream_policy(policy ? dev::PER_BLOCK : dev::SHARED);
+    dev::set_host_sync(host_sync != 0);
+    const std::vector<float> taps = dsputils::lpf_corrected(127, 0.08f);
+    auto [s1, r1] = channel<dev::View<cf>>();
+    auto [s2, r2] = channel<dev::View<cf>>();
+    auto [s3, r3] = channel<dev::View<cf>>();
+    std::atomic<unsigned long long> at_warm{0};
+    unsigned long long sum = 0;
+    size_t seen = 0;
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s1), msg, nmsg]() mutable { dev::synth_iq_source(std::move(s), 0x5EED0002u, msg, nmsg); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    th.push_back(spawn([r = std::move(r2), s = std::move(s3), &at_warm, warm]() mutable {
+        for (size_t i = 0;; ++i) {
+            auto d = r.recv();
+            if (i == warm) at_warm = redio_malloc_count();
+            s.send_unwrap(std::move(d));
+        }
+    }));
+    th.push_back(spawn([r = std::move(r3), &sum, &seen]() mutable { dev::checksum_sink<cf>(std::move(r), &sum, &seen); }));
+    for (auto &t : th) t.join();
+    std::printf("messages %zu checksum %llu mallocs_at_warm %llu mallocs_at_end %llu\n", seen, sum, at_warm.load(), redio_malloc_count());
+    return seen == nmsg ? 0 : 4;
+}
+
+// ---- bench_c2: what a LibRedio graph would actually run (one thread per block, messages through channels: kpn.rs:278-291,
+// kissfft.rs:18-31, ratpak.rs:60-185) against the bare plan launches the headline times ----
+// source -> dev::fir_fft_chain (127 taps / 5 -> 1024-point transform) -> sink, messages of 2^log2_msg cf32 samples.
+//   source "resident": views of R pre-generated messages, cycled (the bench contract: inputs resident in HBM when the timed region starts)
+//          "synth":    every message generated afresh by redio_synth_iq in the source block (8 more bytes per sample through HBM)
+//   sink   "checksum": redio_checksum_u32 over every spectrum word;  "drop": orders itself behind the message and drops it
+//   depth: ring buffers per block (0 = one hipMalloc + hipFree per message);  host_sync 1 = hipStreamSynchronize before every send;
+//   policy 0 = compute blocks share the graph stream, 1 = a stream per block (events on demand)
+//          (depth 0 + host_sync 1 + policy 1 is the round-5 behaviour: the "before" line)
+// bare = the same work without the graph: the same plan, the same R input and output buffers, redio_chain_enqueue (+ redio_checksum_u32
+// for the checksum sink) back to back from one thread on one stream.
+// Both are timed on the host clock between two completed synchronisations after >= 150 ms of warm-up work.
+struct BenchC2 { double bare_us, bare_chain_only_us, graph_us; size_t used; unsigned long long mallocs; unsigned long long checksum; size_t nmsg; };
+static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, bool checksum, bool host_sync, int policy, BenchC2 *res)
+{
+    using cf = std::complex<float>;
+    using clk = std::chrono::steady_clock;
+    const size_t msg = (size_t)1 << log2_msg, R = 4;
+    nmsg = (nmsg + R - 1) / R * R; // whole cycles of the R resident messages: the checksum does not depend on where the warm-up ended
+    const std::vector<float> taps = dsputils::lpf_corrected(127, 0.08f);
+    auto big = dev::make<cf>(R * msg); // R distinct resident messages
+    dev::check(redio_synth_iq(big.data(), 0x5EED0002u, 0, R * msg, nullptr));
+    dev::check(redio_stream_sync(nullptr));
+    // ---- bare launches ----
+    redio_chain *h = nullptr;
+    dev::check(redio_chain_create(&h, taps.data(), taps.size(), 5, 1024, REDIO_FIR_FUSED));
+    const size_t nblk = redio_chain_nblocks(h, msg), used = nblk * 5120, nout = nblk * 1024;
+    double bare_us = 0, bare_chain_us = 0;
+    size_t warm = 8;
+    {
+        auto outs = dev::make<cf>(R * nout);
+        auto acc = dev::make<unsigned long long>(1);
+        dev::BlockStream st(dev::BlockStream::TRANSFER);
+        auto burst = [&](size_t n, bool with_sink) {
+            for (size_t i = 0; i < n; ++i) {
+                dev::check(redio_chain_enqueue(h, big.data() + (i % R) * msg, msg, outs.data() + (i % R) * nout, st));
+                if (with_sink) dev::check(redio_checksum_u32(outs.data() + (i % R) * nout, nout * 2, acc.data(), st));
+            }
+            dev::check(redio_stream_sync(st));
+        };
+        burst(8, checksum);
+        auto t0 = clk::now();
+        size_t done = 0;
+        while (std::chrono::duration<double>(clk::now() - t0).count() < 0.15) { burst(32, checksum); done += 32; }
+        const double per = std::chrono::duration<double>(clk::now() - t0).count() / (double)done;
+        warm = std::max<size_t>(8, (size_t)(0.15 / per));
+        auto t1 = clk::now();
+        burst(nmsg, checksum);
+        bare_us = std::chrono::duration<double>(clk::now() - t1).count() / (double)nmsg * 1e6;
+        bare_chain_us = bare_us;
+        if (checksum) {
+            burst(std::min<size_t>(nmsg, 64), false);
+            auto t2 = clk::now();
+            burst(nmsg, false);
+            bare_chain_us = std::chrono::duration<double>(clk::now() - t2).count() / (double)nmsg * 1e6;
+        }
+    }
+    redio_chain_destroy(h);
+    // ---- the graph ----
+    dev::set_default_ring_depth(depth);
+    dev::set_host_sync(host_sync);
+    dev::set_stream_policy(policy ? dev::PER_BLOCK : dev::SHARED);
+    auto [s1, r1] = bounded_channel<dev::View<cf>>(8);
+    auto [s2, r2] = channel<dev::View<cf>>();
+    const size_t total = warm + nmsg;
+    clk::time_point t0, t1;
+    unsigned long long m0 = 0, m1 = 0, sum = 0;
+    std::vector<std::thread> th;
+    if (resident)
+        th.push_back(spawn([s = std::move(s1), big, msg, total, R]() mutable { for (size_t i = 0; i < total; ++i) s.send_unwrap(big.sub((i % R) * msg, msg)); }));
+    else
+        th.push_back(spawn([s = std::move(s1), msg, total]() mutable { dev::synth_iq_source(std::move(s), 0x5EED0002u, msg, total); }));
+    th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    th.push_back(spawn([&, r = std::move(r2)]() mutable {
+        dev::BlockStream st;
+        auto acc = dev::make<unsigned long long>(1);
+        const unsigned long long zero = 0;
+        dev::check(redio_upload(acc.data(), &zero, 8, st));
+        dev::check(redio_stream_sync(st));
+        for (size_t i = 0; i < total; ++i) {
+            auto d = r.recv();
+            {
+                dev::Reading<cf> in(d, st);
+                if (checksum && i >= warm) dev::check(redio_checksum_u32(d.data(), d.len * 2, acc.data(), st));
+            }
+            if (i + 1 == warm) { dev::check(redio_stream_sync(st)); m0 = redio_malloc_count(); t0 = clk::now(); }
+        }
+        dev::check(redio_stream_sync(st));
+        t1 = clk::now();
+        m1 = redio_malloc_count();
+        dev::check(redio_download(&sum, acc.data(), 8, st));
+        dev::check(redio_stream_sync(st));
+    }));
+    for (auto &t : th) t.join();
+    dev::set_host_sync(false);
+    dev::set_default_ring_depth(4);
+    dev::set_stream_policy(dev::SHARED);
+    res->bare_us = bare_us;
+    res->bare_chain_only_us = bare_chain_us;
+    res->graph_us = std::chrono::duration<double>(t1 - t0).count() / (double)nmsg * 1e6;
+    res->used = used; res->mallocs = m1 - m0; res->checksum = sum; res->nmsg = nmsg;
+    return 0;
+}
+
+static void bench_c2_print(int log2_msg, size_t depth, bool resident, bool checksum, bool host_sync, int policy, const BenchC2 &r)
+{
+    std::printf("{\"mode\": \"bench_c2\", \"log2_msg\": %d, \"used_samples_per_msg\": %zu, \"messages\": %zu, \"ring\": %zu, \"source\": \"%s\", "
+                "\"sink\": \"%s\", \"host_sync\": %d, \"streams\": \"%s\", \"bare_us_per_msg\": %.3f, \"bare_gsps\": %.3f, \"bare_chain_only_us_per_msg\": %.3f, "
+                "\"graph_us_per_msg\": %.3f, \"graph_gsps\": %.3f, \"frac_of_bare\": %.4f, \"frac_of_bare_chain_only\": %.4f, \"mallocs_in_timed_region\": %llu, "
+                "\"checksum\": %llu}\n",
+                log2_msg, r.used, r.nmsg, depth, resident ? "resident" : "synth", checksum ? "checksum" : "drop", (int)host_sync,
+                policy ? "per_block" : "shared", r.bare_us, (double)r.used / r.bare_us * 1e-3, r.bare_chain_only_us, r.graph_us,
+                (double)r.used / r.graph_us * 1e-3, r.bare_us / r.graph_us, r.bare_chain_only_us / r.graph_us, r.mallocs, r.checksum);
+    std::fflush(stdout);
+}
+
+static int bench_c2(int log2_msg, size_t nmsg, size_t depth, const std::string &source, const std::string &sink, int host_sync, int policy)
+{
+    BenchC2 r{};
+    if (int rc = bench_c2_one(log2_msg, nmsg, depth, source == "resident", sink == "checksum", host_sync != 0, policy, &r)) return rc;
+    bench_c2_print(log2_msg, depth, source == "resident", sink == "checksum", host_sync != 0, policy, r);
+    return 0;
+}
+
+// message sizes 2^lo ... 2^hi (step 4x), each about `seconds_per_point` of timed work: the graph as shipped (rings of 4, shared graph
+// stream), with before & 1 the round-5 behaviour beside it (no pool, host sync, a stream per block), with before & 2 the per-block-stream
+// policy (rings, events on demand)
+static int bench_c2_sweep(double seconds_per_point, int before, int lo, int hi)
+{
+    for (int k = lo; k <= hi; k += (k < 16 ? 16 - k : 2)) {
+        // messages per point from the kernel's rate (~0.5 ms per 2^28 samples) with a floor for the launch-bound sizes
+        const double est_us = std::max(12.0, 512.0 * std::ldexp(1.0, k - 28));
+        const size_t nmsg = std::max<size_t>(20, (size_t)(seconds_per_point * 1e6 / est_us));
+        BenchC2 r{};
+        if (int rc = bench_c2_one(k, nmsg, 4, true, true, false, 0, &r)) return rc;
+        bench_c2_print(k, 4, true, true, false, 0, r);
+        if (before & 2) {
+            if (int rc = bench_c2_one(k, nmsg, 4, true, true, false, 1, &r)) return rc;
+            bench_c2_print(k, 4, true, true, false, 1, r);
+        }
+        if (before & 1) {
+            if (int rc = bench_c2_one(k, std::max<size_t>(20, nmsg / 4), 0, true, true, true, 1, &r)) return rc;
+            bench_c2_print(k, 0, true, true, true, 1, r);
+        }
+    }
+    return 0;
+}
+
+// one process, many points: each spec is log2_msg:nmsg:depth:host_sync:policy:source:sink (bench.py's kpn_graph_c2 leg)
+static int bench_c2_list(int nspec, char **specs)
+{
+    for (int i = 0; i < nspec; ++i) {
+        int k = 0, sync = 0, policy = 0;
+        size_t nmsg = 0, depth = 0;
+        char src[16] = {0}, snk[16] = {0};
+        if (std::sscanf(specs[i], "%d:%zu:%zu:%d:%d:%15[a-z]:%15[a-z]", &k, &nmsg, &depth, &sync, &policy, src, snk) != 7) return 2;
+        if (int rc = bench_c2(k, nmsg, depth, src, snk, sync, policy)) return rc;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -681,6 +1062,12 @@ int main(int argc, char **argv)
         if (mode == "devshaper" && argc == 6) return dev_shaper_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]));
         if (mode == "devmix" && argc == 6) return dev_mix_graph(argv[2], argv[3], (size_t)std::atol(argv[4]), std::atof(argv[5]));
         if (mode == "devbank" && argc == 6) return dev_bank_graph(argv[2], argv[3], argv[4], (size_t)std::atol(argv[5]));
+        if (mode == "devring" && argc == 8)
+            return dev_ring_graph((size_t)std::atol(argv[2]), (size_t)std::atol(argv[3]), (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]), std::atoi(argv[6]), std::atoi(argv[7]));
+        if (mode == "bench_c2" && argc == 9)
+            return bench_c2(std::atoi(argv[2]), (size_t)std::atol(argv[3]), (size_t)std::atol(argv[4]), argv[5], argv[6], std::atoi(argv[7]), std::atoi(argv[8]));
+        if (mode == "bench_c2_list" && argc > 2) return bench_c2_list(argc - 2, argv + 2);
+        if (mode == "bench_c2_sweep" && argc == 6) return bench_c2_sweep(std::atof(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
         if (mode == "resample" && argc == 6) return resample_graph(argv[2], argv[3], std::atof(argv[4]), (size_t)std::atol(argv[5]));
         std::fprintf(stderr, "usage: see the header of kpn_tests.cpp\n");
         return 2;

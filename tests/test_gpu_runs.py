@@ -130,3 +130,20 @@ def test_mul_vecs_sum_vecs_operands_beyond_the_caches(gpu, redio, oracle, cplx):
     for dev, add in ((kpn_dev.mul_vecs(x, c), False), (kpn_dev.sum_vecs(x, c), True)):
         want = oracle.zip_vecs(xn, cn, add=add)
         assert np.array_equal(dev.cpu().numpy().view(np.uint32), want.view(np.uint32)), (cplx, add)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,off", [(1, 0), (3, 1), (4, 0), (1023, 0), (1024, 3), (65537, 2), ((1 << 24) + 5, 1)])
+def test_checksum_u32_is_the_exact_word_sum(gpu, redio, n, off):
+    """redio_checksum_u32 (the checking sink of include/kpn_dev.hpp graphs): the order-free u64 sum of 32-bit words, accumulating, on views
+    that start on and off the 16-byte grid."""
+    import torch
+    from libredio_amd import kpn_dev
+    g = torch.Generator(device="cuda"); g.manual_seed(n)
+    buf = torch.randint(-(1 << 31), 1 << 31, (n + off,), dtype=torch.int32, device="cuda", generator=g)
+    x = buf[off:]
+    want = int(x.cpu().numpy().view(np.uint32).astype(np.uint64).sum())
+    acc = kpn_dev.checksum_u32(x)
+    assert int(acc.cpu().numpy().view(np.uint64)[0]) == want
+    kpn_dev.checksum_u32(x, acc)                               # accumulates
+    assert int(acc.cpu().numpy().view(np.uint64)[0]) == (2 * want) % (1 << 64)

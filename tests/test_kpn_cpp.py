@@ -164,6 +164,50 @@ def test_sharded_channelizer_from_one_cpp_process(exe, gpu, oracle, tmp_path):
         assert np.array_equal(bits(got[g]), bits(np.ascontiguousarray(want[:, g * cpg:(g + 1) * cpg]))), g
 
 
+def _ring_graph(exe, msg, nmsg, depth, warm, policy, host_sync):
+    out = subprocess.run([exe, "devring", str(msg), str(nmsg), str(depth), str(warm), str(policy), str(host_sync)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    f = out.stdout.split()
+    return dict(zip(f[0::2], (int(v) for v in f[1::2])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,policy", [(2, 0), (1, 0), (2, 1), (1, 1)])
+def test_bounded_ring_graph_never_allocates_after_warm_up(exe, gpu, oracle, depth, policy):
+    """include/kpn_dev.hpp rings + queue order (SURVEY.md 8b "device-resident variant must bound memory (credit/ring)"): synth source -> fused
+    chain -> checksum sink, one thread per block, 1000 messages through rings of `depth` buffers, on the shared graph stream (policy 0) and on
+    a stream per block with events made on demand (policy 1).  No host synchronisation between the blocks, so a missing dependency would
+    show as a wrong checksum; redio_malloc_count() must not move after message 20."""
+    msg, nmsg = 2 * 5120 + 126 + 37, 1000
+    got = _ring_graph(exe, msg, nmsg, depth, 20, policy, 0)
+    assert got["messages"] == nmsg
+    assert got["mallocs_at_end"] == got["mallocs_at_warm"], "the graph allocated device memory after warm-up"
+    taps = oracle.lpf_corrected(127, 0.08)
+    x = oracle.synth_iq(0x5EED0002, 0, msg * nmsg)
+    want = 0
+    for i in range(nmsg):
+        want += int(bits(oracle.chain_fir_fft(x[i * msg:(i + 1) * msg], taps, 5, 1024, True)).astype(np.uint64).sum())
+    assert got["checksum"] == want % (1 << 64)
+
+
+@pytest.mark.gpu
+def test_host_sync_mode_and_unpooled_ring_give_the_same_bits(exe, gpu):
+    """dev::set_host_sync(true) + ring depth 0 + a stream per block (the round-5 behaviour, kept for debugging and for the before/after line of
+    bench_c2) and the queue-ordered rings produce the same checksum over the same 300 messages of 2^16 + 11 samples."""
+    sums = {_ring_graph(exe, (1 << 16) + 11, 300, depth, 5, policy, sync)["checksum"] for depth, policy, sync in ((4, 0, 0), (0, 1, 1), (3, 1, 0), (0, 0, 0))}
+    assert len(sums) == 1 and 0 not in sums
+
+
+@pytest.mark.gpu
+def test_bench_c2_mode_reports_graph_against_bare_launches(exe, gpu):
+    import json
+    out = subprocess.run([exe, "bench_c2", "18", "300", "4", "resident", "checksum", "0", "0"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["messages"] == 300 and rec["mallocs_in_timed_region"] == 0 and rec["checksum"] != 0
+    assert rec["graph_gsps"] > 0.2 * rec["bare_gsps"]          # a loose floor: the round-5 host path sat at 0.05 - 0.25
+
+
 @pytest.mark.gpu
 def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
     x = oracle.synth_f32(3, 0, 10000)
