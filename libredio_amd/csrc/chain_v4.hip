@@ -31,7 +31,9 @@ __device__ __forceinline__ void static_for4(F &&f)
 // IN_U8: `x` is the receiver's own format, interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162: i as f32 / 127.0 - 1.0):
 // a lane's 16-byte load of two cf32 samples becomes a 4-byte load of the same two samples, converted on the way into the LDS image --
 // 2 + 1.6 bytes per sample through HBM instead of 8 + 8 + 1.6 for the conversion kernel followed by this one.
-template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false>
+// PF2: TWO sub-tiles of loads in flight (round 6): a second register set of NLD pairs, the loop unrolled by two with the
+// roles of the sets swapped -- the request for sub-tile j + 2 is issued before the FIR of sub-tile j, the set holding j + 1 is parked behind it.
+template <int K, int D, bool FUSED, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false, bool PF2 = false>
 __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restrict__ x, const float *__restrict__ taps,
                                                            const float2 *__restrict__ tw, float2 *__restrict__ out,
                                                            long nblocks, long blocks_per_wave, unsigned long long *dbg, long dbg_cap)
@@ -67,31 +69,31 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
         else return w;
     };
 
-    pair_t pre[NLD];
-    auto fetch = [&](long j) { // new samples of sub-tile j: [HALO + j*SUB_NEW, HALO + (j+1)*SUB_NEW)
+    pair_t pre[NLD], pre2[PF2 ? NLD : 1];
+    auto fetch_to = [&](pair_t(&dst)[NLD], long j) { // new samples of sub-tile j: [HALO + j*SUB_NEW, HALO + (j+1)*SUB_NEW)
         const pair_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
         // the stream is read once: non-temporal loads (round 3: read streams run 5-9 % faster with them on this part,
         // profiles/r03_stream_probe3.txt; -DREDIO_EXP_CHAIN_NT=0 builds the default-policy form for comparison)
 #if REDIO_EXP_CHAIN_NT & 1
-        static_for4<NLD>([&](auto I) { pre[I.value] = __builtin_nontemporal_load(src + 64 * I.value); });
+        static_for4<NLD>([&](auto I) { dst[I.value] = __builtin_nontemporal_load(src + 64 * I.value); });
 #else
-        static_for4<NLD>([&](auto I) { pre[I.value] = src[64 * I.value]; });
+        static_for4<NLD>([&](auto I) { dst[I.value] = src[64 * I.value]; });
 #endif
     };
-    auto park = [&]() {
+    auto park_from = [&](pair_t(&from)[NLD]) {
 #if REDIO_EXP_ABLATE == 3 // timing-only experiment (tools/chain_variants.sh; results WRONG): the loads stay, the ten ds_write_b128 that
                           // park them in the image do not -- an upper bound on what staging by LDS-DMA instead of registers could buy
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) { pair_t keep = pre[i]; asm volatile("" : : "v"(keep)); }
+        for (int i = 0; i < NLD; ++i) { pair_t keep = from[i]; asm volatile("" : : "v"(keep)); }
 #else
-        static_for4<NLD>([&](auto I) { xs4[G::lds_index(HALO + 2 * (lane + 64 * I.value)) / 2] = samples(pre[I.value]); });
+        static_for4<NLD>([&](auto I) { xs4[G::lds_index(HALO + 2 * (lane + 64 * I.value)) / 2] = samples(from[I.value]); });
 #endif
     };
 
     // prologue: the head (the only halo this wave ever fetches) and the first sub-tile
     if (lane < HALO_V) xs4[G::lds_index(2 * lane) / 2] = samples(src0[0]);
-    fetch(0);
-    park();
+    fetch_to(pre, 0);
+    park_from(pre);
     wave_lds_fence();
 
     float2 a[16];
@@ -100,10 +102,12 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     // the 15 lane-dependent twiddles of the last two stages stay in registers for the life of the wave
     Fft1knTw34 t34;
     if (!FIR_ONLY && TWP) fft1kn_load_tw34(t34, lane, tw);
-#pragma unroll 1
-    for (long j = 0; j < nsub; ++j) {
+    // one sub-tile: request sub-tile j + AHEAD into `req` (if there is one), FIR of the image, transform when a block is complete,
+    // then park `parked` (= sub-tile j + 1, requested AHEAD - 1 sub-tiles ago; for AHEAD == 1 it is `req` itself) into the image
+    auto step = [&](long j, auto ahead, pair_t(&req)[NLD], pair_t(&parked)[NLD]) {
+        constexpr int AHEAD = decltype(ahead)::value;
         const bool more = j + 1 < nsub;
-        if (more) fetch(j + 1);
+        if (j + AHEAD < nsub) fetch_to(req, j + AHEAD);
         float2 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
@@ -136,9 +140,20 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
         }
         if (more) {
             if (lf < HALO_V) xs4[G::lds_index(2 * lf) / 2] = halo;
-            park();
+            park_from(parked);
         }
         wave_lds_fence();
+    };
+    if constexpr (PF2) {
+        if (nsub > 1) fetch_to(pre, 1);
+#pragma unroll 1
+        for (long j = 0; j < nsub; j += 2) { // nsub = 4 x blocks: even
+            step(j, std::integral_constant<int, 2>{}, pre2, pre);
+            step(j + 1, std::integral_constant<int, 2>{}, pre, pre2);
+        }
+    } else {
+#pragma unroll 1
+        for (long j = 0; j < nsub; ++j) step(j, std::integral_constant<int, 1>{}, pre, pre);
     }
     if (dbg && lane == 0 && (long)blockIdx.x < dbg_cap) { // the caller's buffer holds dbg_cap records: later waves leave no stamp
         dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
@@ -171,7 +186,7 @@ long chain_v4_blocks_per_wave(long nblocks, int WPS)
     return bpw;
 }
 
-template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false>
+template <int K, int D, int WPS, int CH, bool FIR_ONLY = false, bool TWP = false, bool IN_U8 = false, bool PF2 = false>
 static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *tw, float2 *out, long nblocks, bool fused,
                               hipStream_t s, unsigned long long *dbg, long dbg_cap = 0)
 {
@@ -188,8 +203,8 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
     static_assert((4 * WPS + 1) * LDS > 160 * 1024, "one more wave must not fit");
     const long bpw = chain_v4_blocks_per_wave(nblocks, WPS);
     const long grid = (nblocks + bpw - 1) / bpw;
-    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
-    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
+    if (fused) hipLaunchKernelGGL((chain_v4_kernel<K, D, true, WPS, CH, FIR_ONLY, TWP, IN_U8, PF2>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
+    else hipLaunchKernelGGL((chain_v4_kernel<K, D, false, WPS, CH, FIR_ONLY, TWP, IN_U8, PF2>), dim3((unsigned)grid), dim3(64), LDS, s, x, taps, tw, out, nblocks, bpw, dbg, dbg_cap);
     return hipGetLastError();
 }
 
@@ -200,6 +215,8 @@ hipError_t launch_chain_v4(const float2 *x, const float *taps, const float2 *tw,
     // 168 per lane, 0.56-0.60 against 0.517 ms)
 #ifdef REDIO_MEASURE // three wavefronts per SIMD without the resident last-stage twiddles (168 registers, 80 bytes of scratch): measured in round 4, see DESIGN.md 5.1
     if (measure_env("REDIO_CHAIN_WPS3")) return launch_v4_t<127, 5, 3, 8, false, false>(x, taps, tw, out, nblocks, fused, s, dbg, dbg_cap);
+    // two sub-tiles of loads in flight (round 6): A/B against the product form in one process, tools/chain_pf2_ab.py
+    if (measure_env("REDIO_CHAIN_PF2")) return launch_v4_t<127, 5, 2, 8, false, true, false, true>(x, taps, tw, out, nblocks, fused, s, dbg, dbg_cap);
 #endif
     return launch_v4_t<127, 5, 2, 8, false, true>(x, taps, tw, out, nblocks, fused, s, dbg, dbg_cap); // last-stage twiddles resident
 }

@@ -82,9 +82,14 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     // (vmcnt(0)) in the middle of the branch filters -- i.e. for the request it issued a few instructions earlier.
     auto load_rows = [&](set_t(&dst)[NSET], long first) {
         if constexpr (PAIRS) {
-            const unsigned soff = (unsigned)((first - t0) * (2 * PFB_M));
+            // the whole byte offset goes through the VECTOR offset (one v_add per request; the per-register part 4 * PFB_M * k folds into the
+            // instruction's immediate): the descriptor's range check -- what returns zeros for a row pair past the end of the stream --
+            // is documented for the immediate and the vector offset only (LLVM: the scalar offset is "excluded from bounds checking"; round 5
+            // passed the row offset there.  The probe in tests/test_gpu_channelizer.py measures that gfx950 does check it, so round 5 read
+            // nothing past the buffer -- but the documented rule is the one to build on; advisor, round 5)
+            const unsigned voff = 4u * (unsigned)lane + (unsigned)((first - t0) * (2 * PFB_M));
 #pragma unroll
-            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4u * (unsigned)lane, soff + 4u * PFB_M * k, 0);
+            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4u * PFB_M * k, 0, 0);
         } else {
 #pragma unroll
             for (int ti = 0; ti < PFB_TILE; ++ti) {

@@ -684,3 +684,11 @@ extern "C" int redio_synth_f32(void *d_out, uint32_t seed, uint64_t first, size_
     if (n && !d_out) return REDIO_ERR_ARG;
     return hip_rc(launch_synth_f32((float *)d_out, seed, first, (long)n, (hipStream_t)stream));
 }
+
+// test hook (not in include/redio.h): the gfx950 buffer range-check rule the u8 channelizer's row-pair loads rely on
+namespace redio { hipError_t launch_buffer_load_probe(const void *, uint32_t, uint32_t, uint32_t, void *, hipStream_t); }
+extern "C" int redio_debug_buffer_load_probe(const void *d_base, uint32_t num_records, uint32_t voffset, uint32_t soffset, void *d_out64, void *stream)
+{
+    if (!d_base || !d_out64) return REDIO_ERR_ARG;
+    return hip_rc(launch_buffer_load_probe(d_base, num_records, voffset, soffset, d_out64, (hipStream_t)stream));
+}

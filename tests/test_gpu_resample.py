@@ -245,6 +245,74 @@ def test_fast_mode_phase_split_kernel_over_decimations(gpu, redio, oracle, S, co
     assert total > 600
 
 
+def _fast_bound(oracle, ratio, xmax, conv=1):
+    tab, half, inc = oracle.src_table(conv)
+    pos = np.arange(0.0, half, inc * ratio)
+    K = 2 * len(pos)
+    sum_h = 2 * ratio * np.abs(np.interp(pos, np.arange(half + 2), tab.astype(np.float64))).sum()
+    return (K + 1) * 2.0 ** -24 * max(sum_h, 1.0) * xmax
+
+
+def _oracle_channels(oracle, x, chans, ratio, cuts):
+    """{channel: [output per message]} from one oracle converter state per channel fed the same messages; channels run on a thread pool
+    (the C oracle releases the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(c):
+        ref, outs = oracle.Resampler(1), []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            err, want, used = ref.process(x[c, lo:hi], ratio, int(ratio * (hi - lo) + 1.0))
+            assert err == 0 and used == hi - lo
+            outs.append(want)
+        return c, outs
+
+    with ThreadPoolExecutor(max_workers=min(32, len(os.sched_getaffinity(0)))) as ex:
+        return dict(ex.map(one, chans))
+
+
+def test_c3_all_256_channels_bit_exact(gpu, redio, oracle):
+    """BASELINE.json configs[2] to the standard of test_chain_full_size_properties: ALL 256 channels (samplerate.rs:61: one mono state each)
+    at 2^18 frames in two messages of unequal length, ratio 0.02 -- EXACT bit for bit against one oracle converter per channel, FAST
+    inside its stated bound on every channel."""
+    nch, n, ratio = 256, 1 << 18, 0.02
+    x = np.stack([oracle.synth_f32(0x5EED0003 + c, 0, n) for c in range(nch)])
+    d = gpu.from_numpy(x).cuda()
+    exact, fast = redio.Src(nch, 1), redio.Src(nch, 1, mode=redio.Src.FAST)
+    cuts = [0, 150001, n]
+    want = _oracle_channels(oracle, x, range(nch), ratio, cuts)
+    bound = _fast_bound(oracle, ratio, np.abs(x).max())
+    for m, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        a, ua = exact.process(d[:, lo:hi].contiguous(), ratio)
+        b, ub = fast.process(d[:, lo:hi].contiguous(), ratio)
+        assert ua == ub == hi - lo and a.shape == b.shape and a.shape[0] == nch
+        an = a.cpu().numpy()
+        bad = [c for c in range(nch) if an[c].shape != want[c][m].shape or not np.array_equal(bits(an[c]), bits(want[c][m]))]
+        assert not bad, ("channels that differ from the oracle in message", m, bad[:16])
+        assert (a - b).abs().max().item() <= bound
+
+
+def test_c3_bench_size_channels_from_every_group(gpu, redio, oracle):
+    """configs[2] at the size bench.py times (256 channels x 2^22 frames, one message): twelve channels spread over the four 64-channel
+    groups (first / last of each, and some inside), EXACT bit for bit against the oracle, FAST inside its bound on ALL channels
+    (against EXACT)."""
+    nch, n, ratio = 256, 1 << 22, 0.02
+    check = (0, 37, 63, 64, 101, 127, 128, 170, 191, 192, 230, 255)
+    d = gpu.empty((nch, n), dtype=gpu.float32, device="cuda")
+    for c in range(nch):
+        d[c] = redio.synth_f32(100 + c, 0, n)
+    x = {c: oracle.synth_f32(100 + c, 0, n) for c in check}
+    xs = np.stack([x[c] for c in check])
+    want = _oracle_channels(oracle, xs, range(len(check)), ratio, [0, n])
+    exact, fast = redio.Src(nch, 1), redio.Src(nch, 1, mode=redio.Src.FAST)
+    a, ua = exact.process(d, ratio)
+    b, ub = fast.process(d, ratio)
+    assert ua == ub == n and a.shape == b.shape
+    for i, c in enumerate(check):
+        assert np.array_equal(bits(a[c].cpu().numpy()), bits(want[i][0])), c
+    assert (a - b).abs().max().item() <= _fast_bound(oracle, ratio, 1.0)
+
+
 def test_c3_256_channels_two_messages(gpu, redio, oracle):
     """BASELINE.json configs[2] at its channel count: 256 independent mono states (samplerate.rs:61), 2.4 MS/s -> 48 kS/s
     (ratio 0.02), 2^18 frames per channel in two messages of unequal length.  EXACT is bit-identical to the oracle on

@@ -55,8 +55,8 @@ def test_hot_blocks_fail_loudly_without_gpu(exe, tmp_path):
 @pytest.mark.gpu
 def test_config1_wav_fir_wav(exe, gpu, oracle, tmp_path):
     """BASELINE.json configs[0]: wavio WAV in -> dsputils 63-tap FIR lowpass -> WAV out on a kpn graph.
-    Per-block valid mode: every 1024-sample block yields 1024-62 outputs."""
-    n = 1 << 16
+    Per-block valid mode: every 1024-sample block yields 1024-62 outputs.  2^20 samples: SURVEY.md 8d's size for C1."""
+    n = 1 << 20
     x = oracle.synth_f32(0x5EED0001, 0, n + 300)  # 300 trailing samples do not fill a block: dropped by shaper
     write_wav_f32(tmp_path / "in.wav", x, 48000)
     out = subprocess.run([exe, "c1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav")], capture_output=True, text=True, timeout=900)
