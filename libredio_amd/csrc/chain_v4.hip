@@ -70,15 +70,35 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     };
 
     pair_t pre[NLD], pre2[PF2 ? NLD : 1];
+    // PF2 reads the stream through a buffer descriptor of the wave's own run, [head of sub-tile 0, end of sub-tile nsub - 1): a request
+    // for a sub-tile behind the run's last one (the last two steps of a run ask for them) lies past num_records and returns zeros
+    // WITHOUT a memory access, so every step requests unconditionally and the number of loads in flight at every wait is a
+    // compile-time fact (a request under a condition makes the compiler wait for ALL loads at the next use, i.e. also for the
+    // request it issued a sub-tile ago -- which is the whole point of the second set)
+    __amdgpu_buffer_rsrc_t rs;
+    if constexpr (PF2) {
+        static_assert(!PF2 || !IN_U8, "PF2: cf32 input");
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x + b0 * 1024 * (long)D), 0, (int)((HALO + nsub * SUB_NEW) * 8), 0x00020000);
+    }
     auto fetch_to = [&](pair_t(&dst)[NLD], long j) { // new samples of sub-tile j: [HALO + j*SUB_NEW, HALO + (j+1)*SUB_NEW)
-        const pair_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
-        // the stream is read once: non-temporal loads (round 3: read streams run 5-9 % faster with them on this part,
-        // profiles/r03_stream_probe3.txt; -DREDIO_EXP_CHAIN_NT=0 builds the default-policy form for comparison)
+        if constexpr (PF2) {
+            typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+            const unsigned vo = 16u * (unsigned)lane + (unsigned)((HALO + j * SUB_NEW) * 8);
+            static_for4<NLD>([&](auto I) {
+                constexpr int k = I.value;
+                const v4u_t w = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 1024u * (k & 3), 4096 * (k >> 2), 2 /* nt */);
+                dst[k] = __builtin_bit_cast(v4f_t, w);
+            });
+        } else {
+            const pair_t *src = src0 + HALO_V + j * (SUB_NEW / 2);
+            // the stream is read once: non-temporal loads (round 3: read streams run 5-9 % faster with them on this part,
+            // profiles/r03_stream_probe3.txt; -DREDIO_EXP_CHAIN_NT=0 builds the default-policy form for comparison)
 #if REDIO_EXP_CHAIN_NT & 1
-        static_for4<NLD>([&](auto I) { dst[I.value] = __builtin_nontemporal_load(src + 64 * I.value); });
+            static_for4<NLD>([&](auto I) { dst[I.value] = __builtin_nontemporal_load(src + 64 * I.value); });
 #else
-        static_for4<NLD>([&](auto I) { dst[I.value] = src[64 * I.value]; });
+            static_for4<NLD>([&](auto I) { dst[I.value] = src[64 * I.value]; });
 #endif
+        }
     };
     auto park_from = [&](pair_t(&from)[NLD]) {
 #if REDIO_EXP_ABLATE == 3 // timing-only experiment (tools/chain_variants.sh; results WRONG): the loads stay, the ten ds_write_b128 that
@@ -92,6 +112,17 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
 
     // prologue: the head (the only halo this wave ever fetches) and the first sub-tile
     if (lane < HALO_V) xs4[G::lds_index(2 * lane) / 2] = samples(src0[0]);
+    // PF2: the 60 twiddles of the transform's middle stages (Fft1knTw12: 15 per lane, 4 distinct sets by lane >> 4) sit in LDS behind the
+    // image for the life of the wave, so the transform issues NO global load: its twiddle loads would queue behind the sub-tile request
+    // (loads return in order) and make the transform wait for it
+    constexpr int T12_OFF = G::lds_elems(SUB_OUT) > FFT1KN_LDS ? G::lds_elems(SUB_OUT) : FFT1KN_LDS;
+    if constexpr (PF2 && !FIR_ONLY) {
+        if (lane < 60) {
+            const int k4 = lane / 15, i = lane % 15;
+            const int idx = i < 3 ? 64 * k4 * (i + 1) : 16 * (k4 + 4 * ((i - 3) / 3)) * ((i - 3) % 3 + 1);
+            ex[T12_OFF + lane] = tw[idx];
+        }
+    }
     fetch_to(pre, 0);
     park_from(pre);
     wave_lds_fence();
@@ -102,12 +133,14 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
     // the 15 lane-dependent twiddles of the last two stages stay in registers for the life of the wave
     Fft1knTw34 t34;
     if (!FIR_ONLY && TWP) fft1kn_load_tw34(t34, lane, tw);
-    // one sub-tile: request sub-tile j + AHEAD into `req` (if there is one), FIR of the image, transform when a block is complete,
-    // then park `parked` (= sub-tile j + 1, requested AHEAD - 1 sub-tiles ago; for AHEAD == 1 it is `req` itself) into the image
-    auto step = [&](long j, auto ahead, pair_t(&req)[NLD], pair_t(&parked)[NLD]) {
-        constexpr int AHEAD = decltype(ahead)::value;
-        const bool more = j + 1 < nsub;
-        if (j + AHEAD < nsub) fetch_to(req, j + AHEAD);
+    // one sub-tile: request sub-tile j + AHEAD into `req`, FIR of the image, transform when a block is complete,
+    // then park `parked` (= sub-tile j + 1, requested AHEAD - 1 sub-tiles ago; for AHEAD == 1 it is `req` itself) into the image.
+    // S: the sub-tile's place in its block when that is a compile-time fact (PF2: the loop below is unrolled by a whole block, the
+    // transform sits in step 3 unconditionally, and so do the request, the halo move and the park), -1 when it is not.
+    auto step = [&](long j, auto ahead, auto place, pair_t(&req)[NLD], pair_t(&parked)[NLD]) {
+        constexpr int AHEAD = decltype(ahead)::value, S = decltype(place)::value;
+        const bool more = S >= 0 || j + 1 < nsub;
+        if (S >= 0 || j + AHEAD < nsub) fetch_to(req, j + AHEAD);
         float2 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
@@ -128,12 +161,18 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
         // the last HALO samples of this image are the first HALO samples of the next one
         v4f_t halo = v4f_t{0.f, 0.f, 0.f, 0.f};
         if (more && lf < HALO_V) halo = xs4[G::lds_index(SUB_NEW + 2 * lf) / 2];
-        if (!FIR_ONLY && (j & 3) == 3) { // a block is complete in registers: transform it, the image is scratch meanwhile
+        if (!FIR_ONLY && (S == 3 || (S < 0 && (j & 3) == 3))) { // a block is complete in registers: transform it, the image is scratch meanwhile
             wave_lds_fence();
             int ln = lane;
             asm volatile("" : "+v"(ln));
             Fft1knTw12 t12;
-            fft1kn_load_tw12(t12, ln, tw);
+            if constexpr (PF2) {
+                const float2 *T = ex + T12_OFF + 15 * (ln >> 4);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) t12.a[i] = T[i];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) t12.b[i] = T[3 + i];
+            } else fft1kn_load_tw12(t12, ln, tw);
             if (!TWP) fft1kn_load_tw34(t34, ln, tw);
             fft1kn_wave_tw<false>(a, ex, tw, t12, t34, out + (b0 + (j >> 2)) * 1024, ln);
             wave_lds_fence();
@@ -145,15 +184,18 @@ __global__ __launch_bounds__(64, WPS) void chain_v4_kernel(const float2 *__restr
         wave_lds_fence();
     };
     if constexpr (PF2) {
-        if (nsub > 1) fetch_to(pre, 1);
+        fetch_to(pre, 1);
+        using two = std::integral_constant<int, 2>;
 #pragma unroll 1
-        for (long j = 0; j < nsub; j += 2) { // nsub = 4 x blocks: even
-            step(j, std::integral_constant<int, 2>{}, pre2, pre);
-            step(j + 1, std::integral_constant<int, 2>{}, pre, pre2);
+        for (long j = 0; j < nsub; j += 4) { // one block per iteration
+            step(j, two{}, std::integral_constant<int, 0>{}, pre2, pre);
+            step(j + 1, two{}, std::integral_constant<int, 1>{}, pre, pre2);
+            step(j + 2, two{}, std::integral_constant<int, 2>{}, pre2, pre);
+            step(j + 3, two{}, std::integral_constant<int, 3>{}, pre, pre2);
         }
     } else {
 #pragma unroll 1
-        for (long j = 0; j < nsub; ++j) step(j, std::integral_constant<int, 1>{}, pre, pre);
+        for (long j = 0; j < nsub; ++j) step(j, std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{}, pre, pre);
     }
     if (dbg && lane == 0 && (long)blockIdx.x < dbg_cap) { // the caller's buffer holds dbg_cap records: later waves leave no stamp
         dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
@@ -192,7 +234,7 @@ static hipError_t launch_v4_t(const float2 *x, const float *taps, const float2 *
 {
     static_assert(WPS == 2 || WPS == 3, "two wavefronts per SIMD (the chain: its transform needs 197 registers) or three (the FIR alone: 94-145)");
     using G = FirGeomV<K, D, 4>;
-    constexpr int ELEMS = G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS;
+    constexpr int ELEMS = (G::lds_elems(256) > FFT1KN_LDS ? G::lds_elems(256) : FFT1KN_LDS) + (PF2 ? 64 : 0); // PF2: the middle stages' twiddles behind the image
     constexpr size_t LDS_NEED = (size_t)ELEMS * sizeof(float2);
     static_assert(4 * WPS * LDS_NEED <= 160 * 1024, "4*WPS waves per CU");
     // The grid is exactly one wave per residency slot.  Ask for 1/(4*WPS) of the CU's LDS (minus a
