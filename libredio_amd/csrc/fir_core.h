@@ -167,3 +167,51 @@ RD_HD void fir_lane_v(Lds4Ptr xs4, int lane_slot, TapPtr h, float2 (&acc)[R])
 }
 
 } // namespace redio
+
+// ---------------------------------------------------------------------------------------------
+// REAL samples without decimation, two outputs per packed multiply-add (round 6).  A lane owns R consecutive outputs as R/2
+// accumulator PAIRS (out[2p], out[2p+1]); tap j feeds pair p with the sample pair (x[2p + j], x[2p + 1 + j]) -- one v_pk_fma_f32 (or
+// v_pk_mul + v_pk_add) whose two halves are two outputs' strict left folds (dsputils.rs:31), each still receiving its products in
+// ascending tap order.  A pair that starts on an odd sample is no aligned 64-bit register pair of the even ones: the scalar lane
+// program above leaves that to the compiler, which builds them with one v_mov per pair (49 moves per 252 packed multiply-adds in
+// the 63-tap kernel).  Here the tile is stored TWICE in LDS, as E2[m] = (x[2m], x[2m+1]) and as O2[m] = (x[2m+1], x[2m+2]), so that
+// every pair is one aligned 8-byte read and the multiply-adds are the only vector instructions of the body.
+// Image element m (a float2) of either copy sits at lds_index(m): lane stride R/2 float2, one pad element per lane when that is even
+// (odd stride: the 32 lanes of a ds_read_b64 hit 32 different bank pairs).
+// ---------------------------------------------------------------------------------------------
+namespace redio {
+
+template <int K, int R>
+struct FirGeomPairs {
+    static_assert(R % 2 == 0, "pairs of outputs");
+    static constexpr int LSTR = R / 2;                    // float2 elements between neighbouring lanes
+    static constexpr bool PAD = (LSTR % 2) == 0;
+    static constexpr int LANE_STRIDE = LSTR + (PAD ? 1 : 0);
+    static constexpr int NPAIR = R / 2 + (K - 1) / 2 + ((K - 1) % 2 ? 1 : 0); // pair slots m one lane reads from EACH copy: m < R/2 + ceil((K-1)/2)
+    RD_HD static constexpr int lds_index(int m) { return PAD ? m + m / LSTR : m; }
+    RD_HD static constexpr int tile_in(int tile_out) { return tile_out - 1 + K; }
+    // float2 elements of ONE copy for a tile of tile_out outputs: the tile is staged in whole 16-byte loads (four samples = two
+    // elements of either copy), so a copy holds 2 * ceil(tile_in / 4) elements
+    RD_HD static constexpr int copy_elems(int tile_out) { return lds_index(2 * ((tile_in(tile_out) + 3) / 4) - 1) + 1; }
+};
+
+// e2 / o2: the two copies of the image (float2 views); acc[p] = (out[2p], out[2p+1]) of this lane
+template <int K, int R, bool FUSED, typename LdsPtr, typename TapPtr>
+RD_HD void fir_lane_pairs(LdsPtr e2, LdsPtr o2, int lane_slot, TapPtr h, float2 (&acc)[R / 2])
+{
+    using G = FirGeomPairs<K, R>;
+    const int base = lane_slot * G::LANE_STRIDE;
+#pragma unroll
+    for (int m = 0; m < G::NPAIR; ++m) {
+        const float2 e = e2[base + G::lds_index(m)]; // (x[2m], x[2m+1]) relative to the lane's first output
+        const float2 o = o2[base + G::lds_index(m)]; // (x[2m+1], x[2m+2])
+#pragma unroll
+        for (int p = 0; p < R / 2; ++p) {
+            const int j = 2 * (m - p);
+            if (j >= 0 && j < K) acc[p] = mac<FUSED>(e, h[j], acc[p]);
+            if (j + 1 >= 0 && j + 1 < K) acc[p] = mac<FUSED>(o, h[j + 1], acc[p]);
+        }
+    }
+}
+
+} // namespace redio

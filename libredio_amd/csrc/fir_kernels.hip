@@ -307,10 +307,97 @@ static hipError_t launch_tiled(const T *x, long n_in, const float *taps, T *y, l
     return hipGetLastError();
 }
 
+// ---- real samples, no decimation: the pair-image tile (fir_core.h FirGeomPairs / fir_lane_pairs, round 6) ------------------------
+// The tile of tile_in = TILE_OUT - 1 + K samples is staged twice, as even-start and as odd-start sample pairs, each lane then folds R
+// outputs as R / 2 packed accumulators with nothing but aligned 8-byte window reads and packed multiply-adds.
+template <int K, int R, bool FUSED, int NT>
+__global__ __launch_bounds__(NT) void fir_pairs_kernel(const float *__restrict__ x, long n_in, const float *__restrict__ taps,
+                                                       float *__restrict__ y, long n_out, int vec_ok)
+{
+    using G = FirGeomPairs<K, R>;
+    constexpr int TILE_OUT = NT * R, TILE_IN = G::tile_in(TILE_OUT), COPY = G::copy_elems(TILE_OUT);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *e2 = reinterpret_cast<float2 *>(smem), *o2 = e2 + COPY;
+    float *ef = reinterpret_cast<float *>(e2), *of = reinterpret_cast<float *>(o2);
+    const long in0 = (long)blockIdx.x * TILE_OUT;
+    const int tid = threadIdx.x;
+    // sample n of the tile -> E2[n / 2] half n % 2, and O2[(n - 1) / 2] half (n - 1) % 2 for n >= 1
+    auto put = [&](int n, float v) {
+        ef[2 * G::lds_index(n >> 1) + (n & 1)] = v;
+        if (n >= 1) of[2 * G::lds_index((n - 1) >> 1) + ((n - 1) & 1)] = v;
+    };
+    constexpr int NV = (TILE_IN + 3) / 4;
+    if (vec_ok) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + in0);
+#pragma unroll 2
+        for (int v = tid; v < NV; v += NT) {
+            const int n = 4 * v;
+            if (in0 + n + 4 <= n_in) {
+                const float4 q = fir_nt_ld(x4 + v);
+                e2[G::lds_index(2 * v)] = make_float2(q.x, q.y);      // n is a multiple of 4: two whole E2 elements ...
+                e2[G::lds_index(2 * v + 1)] = make_float2(q.z, q.w);
+                o2[G::lds_index(2 * v)] = make_float2(q.y, q.z);      // ... one whole O2 element and two halves
+                if (v > 0) of[2 * G::lds_index(2 * v - 1) + 1] = q.x;
+                of[2 * G::lds_index(2 * v + 1)] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) put(n + e, in0 + n + e < n_in ? x[in0 + n + e] : 0.f);
+            }
+        }
+    } else {
+        for (int n = tid; n < 4 * NV; n += NT) put(n, in0 + n < n_in ? x[in0 + n] : 0.f);
+    }
+    __syncthreads();
+    float2 acc[R / 2];
+#pragma unroll
+    for (int p = 0; p < R / 2; ++p) acc[p] = make_float2(0.f, 0.f);
+    fir_lane_pairs<K, R, FUSED>(e2, o2, tid, taps, acc);
+    const long o0 = in0 + (long)tid * R;
+    if (o0 + R <= n_out && vec_ok) {
+        fir_v4f *y4 = reinterpret_cast<fir_v4f *>(y + o0);
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) y4[q] = fir_v4f{acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y};
+    } else {
+#pragma unroll
+        for (int p = 0; p < R / 2; ++p) {
+            if (o0 + 2 * p < n_out) y[o0 + 2 * p] = acc[p].x;
+            if (o0 + 2 * p + 1 < n_out) y[o0 + 2 * p + 1] = acc[p].y;
+        }
+    }
+}
+
+template <int K, int R, int NT, bool FUSED>
+static hipError_t launch_pairs(const float *x, long n_in, const float *taps, float *y, long n_out, hipStream_t s)
+{
+    using G = FirGeomPairs<K, R>;
+    constexpr int TILE_OUT = NT * R;
+    constexpr size_t LDS = 2 * (size_t)G::copy_elems(TILE_OUT) * sizeof(float2);
+    static_assert(LDS <= 64 * 1024, "tile does not fit LDS");
+    const long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    hipLaunchKernelGGL((fir_pairs_kernel<K, R, FUSED, NT>), dim3((unsigned)ntiles), dim3(NT), LDS, s, x, n_in, taps, y, n_out, vec_ok);
+    return hipGetLastError();
+}
+
 template <typename T, bool FUSED>
 static hipError_t launch_fir_t(const T *x, long n_in, const float *taps, int K, long D, T *y, long n_out, hipStream_t s)
 {
     if (n_out <= 0) return hipSuccess;
+#ifdef REDIO_MEASURE
+    // real samples, no decimation: the pair-image tile (fir_pairs_kernel) -- bit-identical, measured SLOWER than the scalar lane program
+    // below in every tile shape (profiles/r06_fir_real_forms.txt): measurement builds only, REDIO_FIR_PAIRS = R x 1000 + threads
+    if constexpr (sizeof(T) == 4) {
+        const char *e = measure_env("REDIO_FIR_PAIRS");
+        const int sel = e ? atoi(e) : 0;
+        if (K == 63 && D == 1 && sel) {
+            if (sel == 16128) return launch_pairs<63, 16, 128, FUSED>(x, n_in, taps, y, n_out, s);
+            if (sel == 8256) return launch_pairs<63, 8, 256, FUSED>(x, n_in, taps, y, n_out, s);
+            if (sel == 16256) return launch_pairs<63, 16, 256, FUSED>(x, n_in, taps, y, n_out, s);
+            if (sel == 8128) return launch_pairs<63, 8, 128, FUSED>(x, n_in, taps, y, n_out, s);
+            if (sel == 16064) return launch_pairs<63, 16, 64, FUSED>(x, n_in, taps, y, n_out, s);
+        }
+    }
+#endif
     // specialisations for the configurations BASELINE.json names (63 / 127 taps, decimate 1 / 5)
     if (K == 127 && D == 5) return launch_tiled<T, 127, 5, 4, FUSED>(x, n_in, taps, y, n_out, s);
     if (K == 127 && D == 1) return launch_tiled<T, 127, 1, 8, FUSED>(x, n_in, taps, y, n_out, s);
@@ -337,6 +424,7 @@ static hipError_t launch_fir_t(const T *x, long n_in, const float *taps, int K, 
 }
 
 hipError_t launch_fir_v4(int K, int D, const float2 *x, const float *taps, float2 *y, long nblocks, bool fused, hipStream_t s); // chain_v4.hip
+hipError_t launch_fir_run_real(int K, int D, const float *x, long n_in, const float *taps, float *y, long n_out, bool fused, hipStream_t s, long *done); // fir_run.hip
 
 hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D, void *y, long n_out,
                       bool cplx, bool fused, hipStream_t s)
@@ -357,6 +445,22 @@ hipError_t launch_fir(const void *x, long n_in, const float *taps, int K, long D
             return e;
         }
     }
+#ifdef REDIO_MEASURE
+    // real samples (dsputils::convolve's own type): the shapes with a run-form instantiation (fir_run.hip) take whole sub-tiles there
+    if (!cplx && D <= 16 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && measure_env("REDIO_FIR_RUN")) { // measured slower than the tiled kernels (profiles/r06_fir_real_forms.txt): measurement builds only
+        long done = 0;
+        hipError_t e = launch_fir_run_real(K, (int)D, (const float *)x, n_in, taps, (float *)y, n_out, fused, s, &done);
+        if (e == hipSuccess) {
+            if (done == n_out) return hipSuccess;
+            x = (const float *)x + done * D;
+            y = (float *)y + done;
+            n_in -= done * D;
+            n_out -= done;
+        } else if (e != hipErrorNotSupported) {
+            return e;
+        }
+    }
+#endif
     if (cplx) {
         if (fused) return launch_fir_t<float2, true>((const float2 *)x, n_in, taps, K, D, (float2 *)y, n_out, s);
         return launch_fir_t<float2, false>((const float2 *)x, n_in, taps, K, D, (float2 *)y, n_out, s);

@@ -4,6 +4,7 @@
 // the very same headers, one lane at a time, against the oracle.  g++ -ffp-contract=off.
 #include "../../libredio_amd/csrc/fft_core.h"
 #include "../../libredio_amd/csrc/fir_core.h"
+#include "../../libredio_amd/csrc/fir_run_core.h"
 #include "../../libredio_amd/csrc/pfb_core.h"
 #include <stdlib.h>
 #include <string.h>
@@ -204,6 +205,116 @@ extern "C" long emu_fir_f32(const float *x, long n_in, const float *taps, int K,
     if (K == 127 && D == 5) return fused ? emu_fir_tiles<float, 127, 5, 4, true>(x, n_in, taps, y) : emu_fir_tiles<float, 127, 5, 4, false>(x, n_in, taps, y);
     if (K == 63 && D == 1) return fused ? emu_fir_tiles<float, 63, 1, 8, true>(x, n_in, taps, y) : emu_fir_tiles<float, 63, 1, 8, false>(x, n_in, taps, y);
     return -1;
+}
+
+// the wave-private run form of the real-sample FIR (libredio_amd/csrc/fir_run_core.h; device side fir_run.hip): one "wavefront" per
+// run of sub_per_wave sub-tiles, lane by lane -- head, parked new samples, the HALO_A samples carried from image to image -- on an LDS
+// image that starts as NaN, so a window that reads a slot nobody wrote cannot go unnoticed.  Returns the outputs produced
+// (whole sub-tiles only; the device runs the remainder on the tiled kernel).
+template <int K, int D, int R, bool FUSED>
+static long emu_fir_run_t(const float *x, long n_in, const float *taps, float *y, long sub_per_wave)
+{
+    using U = FirRunReal<K, D, R>;
+    using G = typename U::G;
+    const long n_out = n_in < K ? 0 : (n_in - K) / D + 1;
+    const long nsub = U::whole_subtiles(n_in, n_out);
+    for (long s0 = 0; s0 < nsub; s0 += sub_per_wave) {
+        const long s1 = std::min(nsub, s0 + sub_per_wave), n = s1 - s0;
+        std::vector<float> xs((size_t)U::lds_floats(), std::nanf(""));
+        const float *src0 = x + s0 * U::SUB_NEW;
+        auto park = [&](long j) { // every lane's NLD 16-byte loads of sub-tile j's new samples
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < U::NLD; ++i)
+                    for (int e = 0; e < 4; ++e) {
+                        const long g = U::HALO_A + j * U::SUB_NEW + 4 * (lane + 64 * i) + e; // run-relative input sample
+                        if (s0 * U::SUB_NEW + g >= n_in) return -1;                          // the launcher must never ask for this
+                        xs[(size_t)G::lds_index(U::new_sample(lane, i, e))] = src0[g];
+                    }
+            return 0;
+        };
+        for (int lane = 0; lane < U::HALO_A / 4; ++lane)
+            for (int e = 0; e < 4; ++e) xs[(size_t)G::lds_index(U::head_sample(lane, e))] = src0[4 * lane + e];
+        if (park(0)) return -1;
+        for (long j = 0; j < n; ++j) {
+            for (int lane = 0; lane < 64; ++lane) {
+                float acc[R];
+                for (int r = 0; r < R; ++r) acc[r] = 0.f;
+                fir_lane<float, K, D, R, FUSED>(xs.data(), lane, taps, acc);
+                for (int r = 0; r < R; ++r) y[(s0 + j) * U::SUB_OUT + (long)lane * R + r] = acc[r];
+            }
+            if (j + 1 < n) {
+                std::vector<float> halo((size_t)U::HALO_A);
+                for (int k = 0; k < U::HALO_A; ++k) halo[(size_t)k] = xs[(size_t)G::lds_index(U::SUB_NEW + k)];
+                std::fill(xs.begin(), xs.end(), std::nanf("")); // nothing else of the old image may survive into the next
+                for (int k = 0; k < U::HALO_A; ++k) xs[(size_t)G::lds_index(k)] = halo[(size_t)k];
+                if (park(j + 1)) return -1;
+            }
+        }
+    }
+    return nsub * U::SUB_OUT;
+}
+extern "C" long emu_fir_run_f32(const float *x, long n_in, const float *taps, int K, int D, int fused, float *y, long sub_per_wave)
+{
+    if (K == 63 && D == 1) return fused ? emu_fir_run_t<63, 1, 8, true>(x, n_in, taps, y, sub_per_wave) : emu_fir_run_t<63, 1, 8, false>(x, n_in, taps, y, sub_per_wave);
+    return -2;
+}
+
+// the pair-image tile of the real-sample FIR (fir_core.h FirGeomPairs / fir_lane_pairs; device side fir_pairs_kernel): both copies of
+// the tile built as the kernel builds them from whole 16-byte loads (NaN where nothing was written), every lane's packed fold
+template <int K, int R, int NT, bool FUSED>
+static long emu_fir_pairs_t(const float *x, long n_in, const float *taps, float *y)
+{
+    using G = FirGeomPairs<K, R>;
+    constexpr int TILE_OUT = NT * R, TILE_IN = G::tile_in(TILE_OUT), COPY = G::copy_elems(TILE_OUT), NV = (TILE_IN + 3) / 4;
+    const long n_out = n_in < K ? 0 : n_in - K + 1;
+    for (long tile = 0; tile * TILE_OUT < n_out; ++tile) {
+        std::vector<float2> e2((size_t)COPY, make_float2(std::nanf(""), std::nanf(""))), o2 = e2;
+        float *ef = reinterpret_cast<float *>(e2.data()), *of = reinterpret_cast<float *>(o2.data());
+        const long in0 = tile * (long)TILE_OUT;
+        for (int v = 0; v < NV; ++v) {
+            float q[4];
+            for (int e = 0; e < 4; ++e) q[e] = in0 + 4 * v + e < n_in ? x[in0 + 4 * v + e] : 0.f;
+            e2[(size_t)G::lds_index(2 * v)] = make_float2(q[0], q[1]);
+            e2[(size_t)G::lds_index(2 * v + 1)] = make_float2(q[2], q[3]);
+            o2[(size_t)G::lds_index(2 * v)] = make_float2(q[1], q[2]);
+            if (v > 0) of[2 * G::lds_index(2 * v - 1) + 1] = q[0];
+            of[2 * G::lds_index(2 * v + 1)] = q[3];
+        }
+        (void)ef;
+        for (int tid = 0; tid < NT; ++tid) {
+            float2 acc[R / 2];
+            for (int p = 0; p < R / 2; ++p) acc[p] = make_float2(0.f, 0.f);
+            fir_lane_pairs<K, R, FUSED>(e2.data(), o2.data(), tid, taps, acc);
+            for (int p = 0; p < R / 2; ++p) {
+                const long o = in0 + (long)tid * R + 2 * p;
+                if (o < n_out) y[o] = acc[p].x;
+                if (o + 1 < n_out) y[o + 1] = acc[p].y;
+            }
+        }
+    }
+    return n_out;
+}
+extern "C" long emu_fir_pairs_f32(const float *x, long n_in, const float *taps, int K, int R, int NT, int fused, float *y)
+{
+    if (K == 63 && R == 16 && NT == 128) return fused ? emu_fir_pairs_t<63, 16, 128, true>(x, n_in, taps, y) : emu_fir_pairs_t<63, 16, 128, false>(x, n_in, taps, y);
+    if (K == 63 && R == 8 && NT == 256) return fused ? emu_fir_pairs_t<63, 8, 256, true>(x, n_in, taps, y) : emu_fir_pairs_t<63, 8, 256, false>(x, n_in, taps, y);
+    return -2;
+}
+// ds_read_b64 of the pair images: 32 lanes reading pair slot m of their window must hit 32 different bank pairs
+extern "C" int emu_fir_pairs_bank_conflicts(void)
+{
+    int worst = 1;
+    auto chk = [&](auto g) {
+        using G = decltype(g);
+        for (int m = 0; m < G::NPAIR; ++m) {
+            int cnt[32] = {0};
+            for (int l = 0; l < 32; ++l) cnt[(l * G::LANE_STRIDE + G::lds_index(m)) % 32]++;
+            for (int b = 0; b < 32; ++b) if (cnt[b] > worst) worst = cnt[b];
+        }
+    };
+    chk(FirGeomPairs<63, 16>{});
+    chk(FirGeomPairs<63, 8>{});
+    return worst;
 }
 
 // FIR LDS bank check: 32 lanes reading sample m of their window must hit 32 different banks

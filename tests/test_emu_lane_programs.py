@@ -66,6 +66,45 @@ def test_fir_tile_program_real(emu, oracle):
             assert np.array_equal(bits(y[: len(want)]), bits(want))
 
 
+def test_fir_run_program_real(emu, oracle):
+    """The wave-private run form of the real-sample FIR (fir_run_core.h / fir_run.hip, round 6), lane by lane on the CPU: runs of 1, 3 and 8
+    sub-tiles, a shorter last run, inputs that end exactly where the last sub-tile's 16-byte loads end and a few samples beyond;
+    the NaN-initialised image proves every window sample was written (head, parked loads or the carried halo)."""
+    emu.emu_fir_run_f32.argtypes = [f32, C.c_long, f32, C.c_int, C.c_int, C.c_int, f32, C.c_long]
+    emu.emu_fir_run_f32.restype = C.c_long
+    k, d = 63, 1
+    taps = oracle.synth_f32(77, 0, k)
+    for n in (511, 512 + 63, 512 + 64, 512 + 66, 5 * 512 + 64, 11 * 512 + 64 + 300, 17 * 512 + 64 + 1):
+        x = oracle.synth_f32(9, 0, n)
+        for fused in (0, 1):
+            want = oracle.fir(x, taps, d, bool(fused)) if n >= k else np.empty(0, np.float32)
+            for spw in (1, 3, 8):
+                y = np.full(len(want) + 8, np.nan, np.float32)
+                done = emu.emu_fir_run_f32(x, n, taps, k, d, fused, y, spw)
+                assert done == max(0, (n - 64) // 512) * 512 and done <= len(want), (n, done)
+                assert np.array_equal(bits(y[:done]), bits(want[:done])), (n, fused, spw)
+                assert np.isnan(y[done:]).all()
+
+
+def test_fir_pair_image_program_real(emu, oracle):
+    """The pair-image tile of the real-sample FIR (fir_core.h fir_lane_pairs, round 6): two copies of the tile (even-start and odd-start
+    sample pairs), R / 2 packed accumulators per lane; every output's fold is still the reference's (dsputils.rs:31), bit for bit, for both
+    roundings; tiles that end inside the input, exactly at its end, and ragged lengths; NaN-initialised images."""
+    emu.emu_fir_pairs_f32.argtypes = [f32, C.c_long, f32, C.c_int, C.c_int, C.c_int, C.c_int, f32]
+    emu.emu_fir_pairs_f32.restype = C.c_long
+    assert emu.emu_fir_pairs_bank_conflicts() == 1
+    taps = oracle.synth_f32(78, 0, 63)
+    for r, nt in ((16, 128), (8, 256)):
+        for n in (62, 63, 64, 100, 2048 + 62, 2048 + 63, 2 * 2048 + 62, 5000, 3 * 2048 + 700):
+            x = oracle.synth_f32(11, 0, n)
+            for fused in (0, 1):
+                want = oracle.fir(x, taps, 1, bool(fused)) if n >= 63 else np.empty(0, np.float32)
+                y = np.full(len(want) + 8, np.nan, np.float32)
+                assert emu.emu_fir_pairs_f32(x, n, taps, 63, r, nt, fused, y) == len(want)
+                assert np.array_equal(bits(y[:len(want)]), bits(want)), (r, nt, n, fused)
+                assert np.isnan(y[len(want):]).all()
+
+
 def test_resampler_position_recurrence_short_form(emu):
     """src_position.h: for step < 1 (every upsampling ratio) the library's per-output recurrence (libsamplerate 0.1.8,
     sinc_mono_vari_process; samplerate.rs:61 drives it) reduces to add / compare / subtract.  Same doubles, same advances
