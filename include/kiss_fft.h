@@ -23,7 +23,8 @@ typedef struct { float r, i; } kiss_fft_cpx; /* = num::complex::Complex<f32>, in
 typedef struct kiss_fft_state *kiss_fft_cfg;
 
 /* mem/lenmem placement protocol of the published API: lenmem == NULL -> heap; otherwise *lenmem is
- * set to the bytes needed and mem is used when it is non-NULL, large enough and aligned for pointers (else NULL). */
+ * set to the bytes needed (alignment slack included) and the cfg is placed inside mem when it is non-NULL and large enough (else NULL);
+ * any alignment of mem is accepted, the cfg returned is the first suitably aligned address inside it. */
 kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, size_t *lenmem);
 void kiss_fft(kiss_fft_cfg cfg, const kiss_fft_cpx *fin, kiss_fft_cpx *fout);
 void kiss_fft_stride(kiss_fft_cfg cfg, const kiss_fft_cpx *fin, kiss_fft_cpx *fout, int fin_stride);
@@ -32,7 +33,7 @@ int kiss_fft_next_fast_size(int n);      /* next n whose only prime factors are 
 void kiss_fft_free(kiss_fft_cfg cfg);    /* releases the device plan (the published macro is free()) */
 /* Not in the published interface: the wall-time bound (nanoseconds, default 100 000) of the completion poll a call makes before it falls
  * back to an ordinary stream wait; 0 takes the fall-back on every call (a test hook). */
-void kiss_fft_set_spin_ns(long ns);
+void redio_kiss_fft_set_spin_ns(long ns);
 
 #ifdef __cplusplus
 }

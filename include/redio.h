@@ -256,6 +256,9 @@ int redio_pfb_reserve_u8(redio_pfb *h, size_t nbytes, int ngroups); /* as redio_
  * REDIO_ERR_NOT_RESERVED inside a capture). */
 #define REDIO_PFB_RESERVE_TWO_PASS 0x40000000
 int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups);
+/* the same as redio_pfb_reserve(h, n_in, ngroups | REDIO_PFB_RESERVE_TWO_PASS) under a name of its own: sizes the two-pass scratch of ANY
+ * shape without a fused 64-channel kernel, so that an output that is not 16-byte aligned never allocates (e.g. inside a capture) */
+int redio_pfb_reserve_two_pass(redio_pfb *h, size_t n_in, int ngroups);
 
 /* ---- the channelizer's one exchange step over RCCL / xGMI (the only collective on the path) ----
  * Time-sharded channelizer: every rank runs redio_pfb_enqueue(..., ngroups = G) on its own slice of the stream and

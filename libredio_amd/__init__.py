@@ -106,6 +106,7 @@ def lib():
     _sig(L.redio_chain_kernel_name, C.c_char_p, vp)
     _sig(L.redio_fft_reserve, i, vp, sz)
     _sig(L.redio_pfb_reserve, i, vp, sz, i)
+    _sig(L.redio_pfb_reserve_two_pass, i, vp, sz, i)
     for n in ("fir", "chain", "pfb", "ovsave"):
         _sig(getattr(L, f"redio_{n}_stream_create"), i, C.POINTER(vp), vp)
         _sig(getattr(L, f"redio_{n}_stream_destroy"), i, vp)
@@ -192,7 +193,7 @@ def kisslib():
     _sig(K.kiss_fft_cleanup, None)
     _sig(K.kiss_fft_next_fast_size, C.c_int, C.c_int)
     _sig(K.kiss_fft_free, None, C.c_void_p)
-    _sig(K.kiss_fft_set_spin_ns, None, C.c_long)
+    _sig(K.redio_kiss_fft_set_spin_ns, None, C.c_long)
     _kiss = K
     return K
 

@@ -312,8 +312,7 @@ hipError_t launch_fir_v4(int K, int D, const float2 *x, const float *taps, float
     if (K == 63 && D == 1) return launch_v4_t<63, 1, 2, 8, true>(x, taps, nullptr, y, nblocks, fused, s, nullptr);
 #endif
     // (127 taps, no decimation: VALU-bound, and the 256-thread tiled kernel with 8 outputs per lane is faster -- 0.44 against 0.56 ms per 2^26 samples;
-    //  127 taps / 3: the chunked tiled kernel since its window reads are immediate-offset ds_read_b64 -- 0.180 against 0.197 ms, 0.290 against 0.340
-    //  with the reference's rounding)
+    //  127 taps / 3 runs here since round 5 with three wavefronts per SIMD: 0.1589 against the chunked tiled kernel's 0.1713 ms, profiles/r05_fir_mid_shapes.txt)
     return hipErrorNotSupported;
 }
 

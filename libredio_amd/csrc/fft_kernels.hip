@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
     // The transform's twiddles live in LDS for the life of the workgroup (round 5): read from global memory inside the stages they are vector
     // loads whose wait (vmcnt: loads return in order) also waits for the NEXT iteration's rows requested at the top of this one -- and every
     // barrier below is an LDS-only barrier for the same reason (__syncthreads() waits for all requests in flight).  M <= 1024 entries.
-    float2 *Ltw = Ls + F::LDS_ELEMS, *Ltord = Ltw + 512; // the M-entry table; for 512 channels also the stage-ordered copy (510 entries) behind it
+    float2 *Ltw = Ls + F::LDS_ELEMS, *Ltord = Ltw + M; // the M-entry table; for 512 channels also the stage-ordered copy (510 entries) behind it
     for (int i = tid; i < M; i += 256) Ltw[i] = tw[i];
     if constexpr (LOG2M == 9)
         for (int i = tid; i < 510; i += 256) Ltord[i] = Tord[i];
@@ -470,14 +470,18 @@ static hipError_t launch_pfb_p2_t(const float2 *x, const float *h, const float2 
     using F = FftP2<LOG2M>;
     constexpr int M = F::N, NP = PAIR ? (M <= 512 ? 1 : M / 512) : (M <= 256 ? 1 : M / 256), CPT = PAIR ? 2 * NP : NP, G = 256 / (M / CPT), TR = 16 / CPT;
     if (LOG2M == 9 && !Tord) return hipErrorInvalidValue;
-    // contiguous row ranges per stream, a multiple of the iteration's rows; about four workgroups per CU; at least 64 rows (the P - 1 row prologue)
+    // the image + the twiddles the shape needs (M entries; 512 channels: + the 510-entry stage-ordered copy).  Round 5 reserved 1024 entries
+    // for every shape: 45.1 KB, three workgroups per CU where four were launched (advisor, round 5); now 37.2-39 KB up to 256 channels
+    const size_t lds = (size_t)(F::LDS_ELEMS + (LOG2M == 9 ? 1022 : M)) * sizeof(float2);
+    // contiguous row ranges per stream, a multiple of the iteration's rows; about four workgroups per CU -- also for 512 / 1024 channels,
+    // where three are resident: sized for three the launch is 16 % SLOWER (0.866 -> 1.027 ms, profiles/r06_c4gen_ab.txt: the fourth
+    // quarter of the streams is what evens out the tail); at least 64 rows (the P - 1 row prologue)
     long streams = 4L * num_cus() * G;
     long rps = (rows + streams - 1) / streams;
     rps = ((rps + TR - 1) / TR) * TR;
     if (rps < 64) rps = 64;
     const long nstreams = (rows + rps - 1) / rps;
     const unsigned grid = (unsigned)((nstreams + G - 1) / G);
-    const size_t lds = (size_t)(F::LDS_ELEMS + 1024) * sizeof(float2); // the image + the twiddles
     if (fused) hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, true, PAIR>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
     else hipLaunchKernelGGL((pfb_p2_kernel<LOG2M, P, false, PAIR>), dim3(grid), dim3(256), lds, s, x, h, tw, Tord, out, rows, rps, ngroups);
     return hipGetLastError();

@@ -25,22 +25,27 @@ struct kiss_fft_state {
     uint32_t seq;
 };
 enum { KISS_ZERO_COPY_MAX = 8192 };
-// wall-time bound of the completion poll (nanoseconds): 100 us by default; kiss_fft_set_spin_ns is a test hook (0 forces the fall-back
+// wall-time bound of the completion poll (nanoseconds): 100 us by default; redio_kiss_fft_set_spin_ns is a test hook (0 forces the fall-back
 // to redio_stream_sync on every call, tests/test_gpu_parity.py) and not part of the published kiss_fft interface
 static long g_kiss_spin_ns = 100000;
 static long kiss_spin_ns(void) { return __atomic_load_n(&g_kiss_spin_ns, __ATOMIC_RELAXED); }
-extern "C" void kiss_fft_set_spin_ns(long ns) { __atomic_store_n(&g_kiss_spin_ns, ns < 0 ? 0 : ns, __ATOMIC_RELAXED); }
+extern "C" void redio_kiss_fft_set_spin_ns(long ns) { __atomic_store_n(&g_kiss_spin_ns, ns < 0 ? 0 : ns, __ATOMIC_RELAXED); }
 
 extern "C" kiss_fft_cfg kiss_fft_alloc(int nfft, int inverse_fft, void *mem, size_t *lenmem)
 {
-    const size_t need = sizeof(kiss_fft_state);
+    // the published contract takes ANY mem with *lenmem >= the reported size (a cfg carved out of a byte arena): the size reported
+    // includes alignof - 1 bytes of slack and the state sits at the first suitably aligned address inside mem (advisor, round 5)
+    const size_t need = sizeof(kiss_fft_state) + alignof(kiss_fft_state) - 1;
     kiss_fft_state *st = NULL;
     if (lenmem == NULL) {
-        st = (kiss_fft_state *)malloc(need);
+        st = (kiss_fft_state *)malloc(sizeof(kiss_fft_state));
         if (st) st->on_heap = 1;
     } else {
-        // the state holds pointers: a caller's buffer that is not aligned for them is refused like one that is too small (NULL, *lenmem = need)
-        if (mem != NULL && *lenmem >= need && ((uintptr_t)mem % alignof(kiss_fft_state)) == 0) { st = (kiss_fft_state *)mem; st->on_heap = 0; }
+        if (mem != NULL && *lenmem >= need) {
+            const uintptr_t a = ((uintptr_t)mem + alignof(kiss_fft_state) - 1) & ~(uintptr_t)(alignof(kiss_fft_state) - 1);
+            st = (kiss_fft_state *)a;
+            st->on_heap = 0;
+        }
         *lenmem = need;
     }
     if (!st) return NULL;

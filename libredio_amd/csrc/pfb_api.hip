@@ -171,6 +171,11 @@ extern "C" int redio_pfb_reserve(redio_pfb *h, size_t n_in, int ngroups)
     }
     return REDIO_OK;
 }
+extern "C" int redio_pfb_reserve_two_pass(redio_pfb *h, size_t n_in, int ngroups)
+{
+    if (ngroups < 1) return REDIO_ERR_ARG;
+    return redio_pfb_reserve(h, n_in, ngroups | REDIO_PFB_RESERVE_TWO_PASS);
+}
 void redio_pfb_shape(const redio_pfb *h, int *nchan, int *taps_per_branch, int *device)
 {
     *nchan = h->nchan; *taps_per_branch = h->taps_per_branch; *device = h->device;

@@ -58,13 +58,15 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
         else return w;
     };
     // PAIRS: the wave's byte range [row t0, the last row any of its tiles can ask for) and the lane constants of the extraction
-    __amdgpu_buffer_rsrc_t rs;
+    const char *wave_base = nullptr;
+    long wave_bytes = 0;
     unsigned bp_addr = 0, bp_shift = 0;
     if constexpr (PAIRS) {
         long nrows_here = rows + P - 1 - t0, cap = rows_per_wave + 2 * PFB_TILE + P;
         nrows_here = nrows_here < cap ? nrows_here : cap;
         nrows_here = nrows_here < (1l << 23) ? nrows_here : (1l << 23);
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<raw_t *>(xraw + PFB_M * t0), 0, (int)(nrows_here * (2 * PFB_M)), 0x00020000);
+        wave_base = reinterpret_cast<const char *>(xraw + PFB_M * t0);
+        wave_bytes = nrows_here * (2 * PFB_M);
         bp_addr = 4u * ((unsigned)lane >> 1);
         bp_shift = 16u * ((unsigned)lane & 1u);
     }
@@ -82,14 +84,17 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     // (vmcnt(0)) in the middle of the branch filters -- i.e. for the request it issued a few instructions earlier.
     auto load_rows = [&](set_t(&dst)[NSET], long first) {
         if constexpr (PAIRS) {
-            // the whole byte offset goes through the VECTOR offset (one v_add per request; the per-register part 4 * PFB_M * k folds into the
-            // instruction's immediate): the descriptor's range check -- what returns zeros for a row pair past the end of the stream --
-            // is documented for the immediate and the vector offset only (LLVM: the scalar offset is "excluded from bounds checking"; round 5
-            // passed the row offset there.  The probe in tests/test_gpu_channelizer.py measures that gfx950 does check it, so round 5 read
-            // nothing past the buffer -- but the documented rule is the one to build on; advisor, round 5)
-            const unsigned voff = 4u * (unsigned)lane + (unsigned)((first - t0) * (2 * PFB_M));
+            // A descriptor per request, built with scalar arithmetic: its base is the request's first row, its num_records what is left of
+            // the wave's byte range from there, so every load is `4 * lane` in the vector offset + an immediate -- the two operands the
+            // range check (what returns zeros for a row pair past the end of the stream) is documented to cover.  Round 5 passed the row
+            // offset as the SCALAR offset, which LLVM documents as excluded from the check (the probe in tests/test_gpu_channelizer.py
+            // measures that gfx950 does check it, so nothing was read past the buffer -- but the documented rule is the one to build on;
+            // advisor, round 5); a running vector offset instead costs the grouped layout 1.7 % (profiles/r06_c4gen_ab.txt).
+            const long boff = (first - t0) * (2 * PFB_M);
+            const long left = wave_bytes - boff;
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wave_base + boff), 0, (int)(left > 0 ? left : 0), 0x00020000);
 #pragma unroll
-            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4u * PFB_M * k, 0, 0);
+            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rq, 4u * (unsigned)lane + 4u * PFB_M * k, 0, 0);
         } else {
 #pragma unroll
             for (int ti = 0; ti < PFB_TILE; ++ti) {

@@ -361,6 +361,12 @@ class Channelizer:
         check(lib().redio_pfb_enqueue(self._h, _dev_ptr(x), x.numel(), _dev_ptr(out), int(ngroups), current_stream()), "pfb_enqueue")
         return out
 
+    def reserve(self, n_in, ngroups=1, two_pass=False):
+        """redio_pfb_reserve / redio_pfb_reserve_two_pass: plan scratch for inputs of up to n_in samples (so that a call never allocates,
+        e.g. inside a Graph); two_pass: also for the one-kernel shapes, whose fall-back for an output that is not 16-byte aligned needs it."""
+        f = lib().redio_pfb_reserve_two_pass if two_pass else lib().redio_pfb_reserve
+        check(f(self._h, int(n_in), int(ngroups)), "pfb_reserve")
+
     def from_bytes(self, raw, ngroups=1, out=None):
         """redio_pfb_enqueue_u8: the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162) straight
         into the channelizer; the rows of bitfount.data_to_samples(raw) followed by this plan, bit for bit."""

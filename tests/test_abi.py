@@ -118,9 +118,19 @@ def test_oracle_is_test_infrastructure_only():
                     if pat.search(text):
                         offenders.append(os.path.relpath(os.path.join(dirpath, f), root))
     assert not offenders, offenders
-    bench = open(os.path.join(root, "bench.py")).read()
-    body = bench[bench.index("def cpu_baseline"): bench.index("def main")]
-    assert bench.count("import oracle") == 1 and "import oracle" in body      # bench.py: the cpu_baseline leg only
+    # bench.py: only the CPU-baseline legs (the headline's, the per-config ones, the CPU side of the per-call drop-in table) import the
+    # oracle -- never main(), other_configs() or anything inside the timed region
+    import ast
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    users = set()
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if (isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names)) or \
+               (isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle"):
+                users.add(fn.name)
+    assert users and users <= {"cpu_baseline", "cpu_baseline_configs", "dropin_calls_leg"}, users
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any("oracle" in ast.dump(n) for n in top)
 
 
 def test_public_headers_are_plain_c_and_a_c_program_links(redio, tmp_path):

@@ -110,3 +110,44 @@ def test_u8_entry_points_inside_a_capture(gpu, redio, oracle):
         g2.launch()
         gpu.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_channelizer_unaligned_output_inside_a_capture_needs_the_two_pass_reserve(gpu, redio, oracle):
+    """redio_pfb_reserve's contract for the one-kernel shapes (32 ... 1024 channels): their only use of plan scratch is the two-pass fall-back
+    for an output that is not 16-byte aligned, and a plain reserve holds nothing for it (2-4 GiB per 2^28-sample message otherwise).  Inside a
+    capture such a call returns REDIO_ERR_NOT_RESERVED unless redio_pfb_reserve_two_pass (or the flag bit) sized the scratch; then the
+    captured call replays the oracle's rows.  (advisor, round 5)"""
+    M, P, rows = 128, 8, 300
+    h = oracle.lpf_corrected(M * P, 0.45 / M)
+    x = oracle.synth_iq(5, 0, M * (rows + P - 1))
+    want = oracle.pfb_channelizer(x, h, M, P, True)
+    d = gpu.from_numpy(x).cuda()
+    buf = gpu.zeros(rows * M + 1, dtype=gpu.complex64, device="cuda")
+    out = buf[1:].view(rows, M)                                   # 8 bytes off the 16-byte grid
+    assert out.data_ptr() % 16 == 8
+    for how in ("nothing", "plain", "flag", "two_pass"):
+        plan = redio.Channelizer(h, M, P)
+        if how == "plain":
+            plan.reserve(x.size)
+        elif how == "flag":
+            redio.check(redio.lib().redio_pfb_reserve(plan._h, x.size, 1 | 0x40000000), "reserve")
+        elif how == "two_pass":
+            plan.reserve(x.size, two_pass=True)
+        g = redio.Graph()
+        if how in ("nothing", "plain"):
+            with pytest.raises(redio.RedioError) as ei:
+                with g:
+                    plan(d, out=out)
+            assert ei.value.code == -6                              # REDIO_ERR_NOT_RESERVED; the capture is closed by __exit__
+            continue
+        with g:
+            plan(d, out=out)
+        buf.zero_()
+        g.launch()
+        gpu.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), how
+    # un-captured, un-reserved: the fall-back sizes its scratch at first use
+    plan = redio.Channelizer(h, M, P)
+    buf.zero_()
+    plan(d, out=out)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))

@@ -297,7 +297,7 @@ def test_kiss_fft_placement_stride_and_helpers(gpu, redio, oracle):
     assert L.kiss_fft_alloc(256, 0, small, C.byref(got)) is None and got.value == need.value   # too small: the size comes back
     mem = C.create_string_buffer(need.value); got = C.c_size_t(need.value)
     cfg = L.kiss_fft_alloc(256, 1, mem, C.byref(got))
-    assert cfg == C.addressof(mem)                                                            # placed in the caller's memory
+    assert C.addressof(mem) <= cfg < C.addressof(mem) + 16 and cfg % 8 == 0                   # placed in the caller's memory (first aligned address)
     x = oracle.synth_iq(91, 0, 256); out = np.empty_like(x)
     L.kiss_fft(cfg, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert same_bits(out, oracle.fft(x, 256, True))
@@ -311,9 +311,9 @@ def test_kiss_fft_placement_stride_and_helpers(gpu, redio, oracle):
 
 
 def test_kiss_fft_misaligned_mem_and_completion_fallback(gpu, redio, oracle):
-    """kiss_fft_alloc refuses a caller's buffer that is not aligned for the state's pointers (NULL, the size comes back); a call whose
-    completion poll is cut to zero takes the ordinary stream wait and returns the same bits (kissfft_shim.cpp: the poll is bounded by
-    wall time, kiss_fft_set_spin_ns is the hook)."""
+    """kiss_fft_alloc takes a caller's buffer of ANY alignment (the published contract: a cfg carved out of a byte arena) and places the state
+    at the first aligned address inside it; a call whose completion poll is cut to zero takes the ordinary stream wait and returns the same
+    bits (kissfft_shim.cpp: the poll is bounded by wall time, redio_kiss_fft_set_spin_ns is the hook)."""
     L = redio.kisslib()
     need = C.c_size_t(0)
     L.kiss_fft_alloc(1024, 0, None, C.byref(need))
@@ -321,17 +321,26 @@ def test_kiss_fft_misaligned_mem_and_completion_fallback(gpu, redio, oracle):
     base = C.addressof(mem)
     odd = base + 1 if base % 2 == 0 else base + 2                                    # 1 (mod 2): never aligned for a pointer
     got = C.c_size_t(need.value)
-    assert L.kiss_fft_alloc(1024, 0, C.c_void_p(odd), C.byref(got)) is None and got.value == need.value
+    L.kiss_fft_alloc.restype = C.c_void_p
+    L.kiss_fft_alloc.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.kiss_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kiss_fft_free.argtypes = [C.c_void_p]
+    pc = L.kiss_fft_alloc(1024, 0, C.c_void_p(odd), C.byref(got))
+    assert pc is not None and odd <= pc < odd + 8 and pc % 8 == 0 and pc + (need.value - 7) <= odd + need.value and got.value == need.value
+    xo = oracle.synth_iq(78, 0, 1024); yo = np.empty_like(xo)
+    L.kiss_fft(pc, xo.ctypes.data_as(C.c_void_p), yo.ctypes.data_as(C.c_void_p))
+    assert same_bits(yo, oracle.fft(xo, 1024, False))
+    L.kiss_fft_free(pc)
     from libredio_amd import kissfft
     cfg = kissfft.Cfg(1024, 0)
     x = oracle.synth_iq(77, 0, 1024)
     want = oracle.fft(x, 1024, False)
     try:
-        L.kiss_fft_set_spin_ns(0)                                                       # every call: the fall-back branch
+        L.redio_kiss_fft_set_spin_ns(0)                                                       # every call: the fall-back branch
         for _ in range(3):
             assert same_bits(cfg(x), want)
     finally:
-        L.kiss_fft_set_spin_ns(100000)
+        L.redio_kiss_fft_set_spin_ns(100000)
     assert same_bits(cfg(x), want)
     cfg.close()
 
