@@ -368,6 +368,11 @@ static hipError_t launch_fft_p2(const float2 *in, float2 *out, const float2 *tw,
 // before this one's arithmetic.
 // PAIR: a thread owns two NEIGHBOURING channels (2 m, 2 m + 1) and loads them with one 16-byte access (M / 2 threads per row, so more
 // row streams per workgroup and 8 rows per iteration); otherwise one channel per thread (or M / 256 channels, 256 apart), 8-byte loads.
+#ifndef REDIO_EXP_PFB_NT
+#define REDIO_EXP_PFB_NT 3 // bit 0: non-temporal row loads, bit 1: non-temporal row stores (pfb_kernels.hip: why)
+#endif
+typedef float p2_v2f __attribute__((ext_vector_type(2)));
+typedef float p2_v4f __attribute__((ext_vector_type(4)));
 template <int LOG2M, int P, bool FUSED, bool PAIR>
 __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ x, const float *__restrict__ h, const float2 *__restrict__ tw,
                                                      const float2 *__restrict__ Tord, float2 *__restrict__ out, long rows, long rps, int ngroups)
@@ -405,9 +410,20 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (PAIR) {
+#if REDIO_EXP_PFB_NT & 1
+                const p2_v4f v = __builtin_nontemporal_load(reinterpret_cast<const p2_v4f *>(rowp + 2 * m + 512 * q));
+#else
                 const float4 v = *reinterpret_cast<const float4 *>(rowp + 2 * m + 512 * q);
+#endif
                 dst[(2 * q) * step] = make_float2(v.x, v.y); dst[(2 * q + 1) * step] = make_float2(v.z, v.w);
-            } else dst[q * step] = rowp[m + 256 * q];
+            } else {
+#if REDIO_EXP_PFB_NT & 1
+                const p2_v2f v = __builtin_nontemporal_load(reinterpret_cast<const p2_v2f *>(rowp + m + 256 * q));
+                dst[q * step] = make_float2(v.x, v.y);
+#else
+                dst[q * step] = rowp[m + 256 * q];
+#endif
+            }
         }
     };
 #pragma unroll
@@ -446,8 +462,14 @@ __global__ __launch_bounds__(256) void pfb_p2_kernel(const float2 *__restrict__ 
             const long sbase = (s0 + gg) * rps, row = sbase + (long)TR * it + ti, rend = sbase + rps < rows ? sbase + rps : rows;
             if (row < rend) {
                 const float2 v0 = Ls[F::phys(e)], v1 = Ls[F::phys(e + 1)];
-                if (ngroups == 1) *reinterpret_cast<float4 *>(out + row * M + n) = make_float4(v0.x, v0.y, v1.x, v1.y);
-                else if (cpg >= 2) *reinterpret_cast<float4 *>(out + (long)(n / cpg) * rows * cpg + row * cpg + (n % cpg)) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                float2 *o16 = ngroups == 1 ? out + row * M + n : out + (long)(n / cpg) * rows * cpg + row * cpg + (n % cpg);
+                if (ngroups == 1 || cpg >= 2) {
+#if REDIO_EXP_PFB_NT & 2
+                    __builtin_nontemporal_store(p2_v4f{v0.x, v0.y, v1.x, v1.y}, reinterpret_cast<p2_v4f *>(o16));
+#else
+                    *reinterpret_cast<float4 *>(o16) = make_float4(v0.x, v0.y, v1.x, v1.y);
+#endif
+                }
                 else { out[(long)n * rows + row] = v0; out[(long)(n + 1) * rows + row] = v1; }
             }
         }

@@ -12,6 +12,42 @@
 
 namespace redio {
 
+// Cache policy of the two streams (round 6), NT bit 0: non-temporal row loads, bit 1: non-temporal row stores.  Every input row is read
+// once and every output row written once, and the plain 1 : 1 copy of this pool runs 6 % faster with non-temporal accesses,
+// but what a kernel gains depends on its store pattern and on what else bounds it -- measured per kernel (profiles/r06_channelizer_nt.txt):
+//   the one-kernel shapes (pfb_p2_kernel, 16-byte stores of whole rows): both non-temporal, + 2-4 %;
+//   pfb64_kernel from cf32: the DEFAULT policy (non-temporal stores of its 32-byte-per-lane rows cost 11 %, loads alone 2 %);
+//   pfb64_kernel from u8 bytes: row-major both non-temporal (+ 5 %), the grouped layouts stores only (+ 4 %).
+typedef float pfb_v2f __attribute__((ext_vector_type(2)));
+typedef float pfb_v4f __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ float2 pfb_ld_row(const float2 *p)
+{
+    if constexpr (NT & 1) {
+        const pfb_v2f v = __builtin_nontemporal_load(reinterpret_cast<const pfb_v2f *>(p));
+        return make_float2(v.x, v.y);
+    } else return *p;
+}
+template <int NT>
+__device__ __forceinline__ unsigned short pfb_ld_row(const unsigned short *p)
+{
+    if constexpr (NT & 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int NT>
+__device__ __forceinline__ void pfb_st(float4 *p, float4 v)
+{
+    if constexpr (NT & 2) __builtin_nontemporal_store(pfb_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<pfb_v4f *>(p));
+    else *p = v;
+}
+template <int NT>
+__device__ __forceinline__ void pfb_st(float2 *p, float2 v)
+{
+    if constexpr (NT & 2) __builtin_nontemporal_store(pfb_v2f{v.x, v.y}, reinterpret_cast<pfb_v2f *>(p));
+    else *p = v;
+}
+
+
 // ROWMAJOR: the plain [row][64] output (ngroups == 1) with 32-byte stores and no index division.
 // IN_U8: `x` is the receiver's interleaved u8 I/Q bytes (rtlsdr::data_to_samples, rtlsdr.rs:159-162); a lane's 8-byte sample load
 // becomes a 2-byte load, converted when the sample enters the register window: 2 + 8 bytes per sample through HBM instead of 8 + 8
@@ -29,7 +65,7 @@ namespace redio {
 #ifndef REDIO_PFB_LATE_PREFETCH
 #define REDIO_PFB_LATE_PREFETCH (IN_U8 == 1)
 #endif
-template <int P, bool FUSED, bool ROWMAJOR, int IN_U8 = 0>
+template <int P, bool FUSED, bool ROWMAJOR, int IN_U8 = 0, int NT = 0>
 __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x, const float *__restrict__ h,
                                                     const float2 *__restrict__ tw, float2 *__restrict__ out, long rows,
                                                     long rows_per_wave, int ngroups)
@@ -94,13 +130,13 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
             const long left = wave_bytes - boff;
             const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wave_base + boff), 0, (int)(left > 0 ? left : 0), 0x00020000);
 #pragma unroll
-            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rq, 4u * (unsigned)lane + 4u * PFB_M * k, 0, 0);
+            for (int k = 0; k < NSET; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b32(rq, 4u * (unsigned)lane + 4u * PFB_M * k, 0, (NT & 1) ? 2 : 0);
         } else {
 #pragma unroll
             for (int ti = 0; ti < PFB_TILE; ++ti) {
                 long r = first + ti;
                 r = r < last_in_row ? r : last_in_row;
-                dst[ti] = (xraw + PFB_M * r)[(unsigned)lane];
+                dst[ti] = pfb_ld_row<NT>(xraw + PFB_M * r + (unsigned)lane);
             }
         }
     };
@@ -120,7 +156,7 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
     asm volatile("" : "+s"(twone.x), "+s"(twone.y));
     float2 win[P];
 #pragma unroll
-    for (int p = 0; p < P - 1; ++p) win[p] = sample((xraw + PFB_M * (t0 + p))[(unsigned)lane]);
+    for (int p = 0; p < P - 1; ++p) win[p] = sample(pfb_ld_row<NT>(xraw + PFB_M * (t0 + p) + (unsigned)lane));
     // One tile: rows tb .. tb + 15 from `cur`, the next tile's rows requested into `nx`.  The tile loop below is unrolled by two with the
     // roles of the two register sets swapped instead of copying nx -> cur: the copies of a loop-carried array land on the loop's back
     // edge, BEHIND the tile's eight stores, where their wait (vmcnt(0): stores count too on gfx950) made every tile pay the write
@@ -158,8 +194,8 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
                 float4 *orow = reinterpret_cast<float4 *>(out + PFB_M * tb) + (unsigned)(32 * (lane >> 2) + 2 * (lane & 3));
 #pragma unroll
                 for (int k0 = 0; k0 < 4; ++k0) {
-                    orow[8 * k0] = make_float4(v[k0].x, v[k0].y, v[k0 + 4].x, v[k0 + 4].y);
-                    orow[8 * k0 + 1] = make_float4(v[k0 + 8].x, v[k0 + 8].y, v[k0 + 12].x, v[k0 + 12].y);
+                    pfb_st<NT>(orow + 8 * k0, make_float4(v[k0].x, v[k0].y, v[k0 + 4].x, v[k0 + 4].y));
+                    pfb_st<NT>(orow + 8 * k0 + 1, make_float4(v[k0 + 8].x, v[k0 + 8].y, v[k0 + 12].x, v[k0 + 12].y));
                 }
             } else {
 #pragma unroll
@@ -167,10 +203,10 @@ __global__ __launch_bounds__(256) void pfb64_kernel(const float2 *__restrict__ x
                     if (ngroups <= 16) { // the four k2 of one k0 are consecutive channels of one group: a 32-byte run
                         float2 *dst = out + pfb_out_index(row, pfb_out_channel(lane, k0, 0), rows, ngroups);
 #pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) dst[k2] = v[k0 + 4 * k2];
+                        for (int k2 = 0; k2 < 4; ++k2) pfb_st<NT>(dst + k2, v[k0 + 4 * k2]);
                     } else {
 #pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) out[pfb_out_index(row, pfb_out_channel(lane, k0, k2), rows, ngroups)] = v[k0 + 4 * k2];
+                        for (int k2 = 0; k2 < 4; ++k2) pfb_st<NT>(out + pfb_out_index(row, pfb_out_channel(lane, k0, k2), rows, ngroups), v[k0 + 4 * k2]);
                     }
                 }
             }
@@ -207,13 +243,33 @@ static hipError_t launch_pfb_t(const float2 *x, const float *h, const float2 *tw
     const long nwaves = (rows + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((nwaves + 3) / 4);
     const size_t lds = 4 * PFB_LDS * sizeof(float2);
-    if (ngroups == 1) {
-        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, true, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
-        else hipLaunchKernelGGL((pfb64_kernel<P, false, true, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
-    } else {
-        if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, false, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
-        else hipLaunchKernelGGL((pfb64_kernel<P, false, false, IN_U8>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+    // cache policy per variant (the table at the top of this file); measurement builds: REDIO_PFB_NT = 0 .. 3 overrides it
+    constexpr int NT_NAT = IN_U8 == 0 ? 0 : 3, NT_GRP = IN_U8 == 0 ? 0 : 2;
+    auto go = [&](auto nt_nat, auto nt_grp) {
+        constexpr int A = decltype(nt_nat)::value, B = decltype(nt_grp)::value;
+        if (ngroups == 1) {
+            if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, true, IN_U8, A>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+            else hipLaunchKernelGGL((pfb64_kernel<P, false, true, IN_U8, A>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        } else {
+            if (fused) hipLaunchKernelGGL((pfb64_kernel<P, true, false, IN_U8, B>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+            else hipLaunchKernelGGL((pfb64_kernel<P, false, false, IN_U8, B>), dim3(grid), dim3(256), lds, s, x, h, tw, out, rows, rpw, ngroups);
+        }
+    };
+#ifdef REDIO_MEASURE
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    if (const char *e = measure_env("REDIO_PFB_NT")) {
+        if (P == 16) { // the BASELINE shape only: every policy of every variant is one more instantiation of a large kernel
+            switch (atoi(e)) {
+            case 0: go(I0{}, I0{}); return hipGetLastError();
+            case 1: go(I1{}, I1{}); return hipGetLastError();
+            case 2: go(I2{}, I2{}); return hipGetLastError();
+            case 3: go(I3{}, I3{}); return hipGetLastError();
+            default: break;
+            }
+        }
     }
+#endif
+    go(std::integral_constant<int, NT_NAT>{}, std::integral_constant<int, NT_GRP>{});
     return hipGetLastError();
 }
 
