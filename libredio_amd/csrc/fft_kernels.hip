@@ -13,6 +13,40 @@
 
 namespace redio {
 
+// Cache policy of the batched one-wave transforms' two streams (bit 0: non-temporal loads, bit 1: non-temporal stores).  Measured in round 6
+// (-DREDIO_EXP_FFT_NT=3 against this default, alternating processes on one box, profiles/r06_fft_nt.txt): 1024 points 16 % SLOWER non-temporal
+// (0.76 -> 0.91 ms per 2^28 points: a wavefront stores a block as sixteen 512-byte pieces 2 KiB apart, which the L2 merges into whole lines),
+// 256 and 64 points within 1 %.  The default policy stays.
+#ifndef REDIO_EXP_FFT_NT
+#define REDIO_EXP_FFT_NT 0
+#endif
+typedef float fft_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 fft_ld_once(const float2 *p)
+{
+#if REDIO_EXP_FFT_NT & 1
+    const fft_v2f v = __builtin_nontemporal_load(reinterpret_cast<const fft_v2f *>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+// a global destination whose element stores are non-temporal: dst[i] = v (the one-wave programs store through a templated pointer)
+struct FftOnceOut {
+    float2 *p;
+    struct Ref {
+        float2 *q;
+        __device__ __forceinline__ void operator=(float2 v) const
+        {
+#if REDIO_EXP_FFT_NT & 2
+            __builtin_nontemporal_store(fft_v2f{v.x, v.y}, reinterpret_cast<fft_v2f *>(q));
+#else
+            *q = v;
+#endif
+        }
+    };
+    __device__ __forceinline__ Ref operator[](long i) const { return Ref{p + i}; }
+};
+
 constexpr int FFT1K_PER_WAVE = 8; // blocks per wavefront of the 1024-point overlap-save kernel: its 54 lane-dependent twiddles are loaded once and reused
 constexpr int FFT1K_RUN = 4;      // transforms per wavefront of the plain transform (27 twiddles; round 3: 2 / 4 / 8 / 16 per wave 0.808 / 0.757 / 0.782 / 0.797 ms per 2^28 points)
 template <bool INV>
@@ -30,12 +64,12 @@ __global__ __launch_bounds__(256) void fft1k_wave_kernel(const float2 *in, float
     fft1k_load_tw(t, lane, tw);
     float2 v[16], nx[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = in[b0 * in_stride + lane + 64 * i];
+    for (int i = 0; i < 16; ++i) v[i] = fft_ld_once(in + b0 * in_stride + lane + 64 * i);
     for (long b = b0; b < b1; ++b) {
         const long bn = (b + 1 < b1) ? b + 1 : b; // prefetch the next transform's input under this one's arithmetic
 #pragma unroll
-        for (int i = 0; i < 16; ++i) nx[i] = in[bn * in_stride + lane + 64 * i];
-        fft1k_wave_regs<INV>(v, out + b * 1024, ex, tw, t, lane);
+        for (int i = 0; i < 16; ++i) nx[i] = fft_ld_once(in + bn * in_stride + lane + 64 * i);
+        fft1k_wave_regs<INV>(v, FftOnceOut{out + b * 1024}, ex, tw, t, lane);
         wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = nx[i];
@@ -118,7 +152,7 @@ __global__ __launch_bounds__(256) void fft256_kernel(const float2 *in, float2 *o
     const long bj = (b0 + (lane & 3) < nbatch) ? b0 + (lane & 3) : nbatch - 1;
     float2 v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = in[bj * in_stride + (lane >> 2) + 16 * t];
+    for (int t = 0; t < 16; ++t) v[t] = fft_ld_once(in + bj * in_stride + (lane >> 2) + 16 * t);
     const TwShift tw1k = {tw, 2};
     Fft1kTw t;
     fft1k_load_tw(t, lane, tw1k); // the last-stage entries are loaded but unused (indices stay inside the table)
@@ -127,7 +161,7 @@ __global__ __launch_bounds__(256) void fft256_kernel(const float2 *in, float2 *o
     for (int j = 0; j < 4; ++j) {
         if (b0 + j >= nbatch) break;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[(b0 + j) * 256 + lane + 64 * q] = v[4 * q + j];
+        for (int q = 0; q < 4; ++q) FftOnceOut{out}[(b0 + j) * 256 + lane + 64 * q] = v[4 * q + j];
     }
 }
 
@@ -153,7 +187,7 @@ __global__ __launch_bounds__(256) void fft64_kernel(const float2 *in, float2 *ou
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const long b = (b0 + t < nbatch) ? b0 + t : nbatch - 1;
-        v[t] = in[b * in_stride + lane];
+        v[t] = fft_ld_once(in + b * in_stride + lane);
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) ex[t * FFT64_ROW + lane] = v[t];
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(256) void fft64_kernel(const float2 *in, float2 *ou
         const long b = b0 + d1 + 4 * (lane & 3);
         if (b < nbatch) {
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) out[b * 64 + k + 16 * k2] = v[d1 + 4 * k2];
+            for (int k2 = 0; k2 < 4; ++k2) FftOnceOut{out}[b * 64 + k + 16 * k2] = v[d1 + 4 * k2];
         }
     }
 }
