@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-log2-samples", type=int, default=23, help="slice per CPU thread")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_traffic.json"), help="file with {'traffic': bytes_per_launch, 'kernel': name} from the PMC passes")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r06_traffic.json"), help="file with {'traffic': bytes_per_launch, 'kernel': name} from the PMC passes")
     ap.add_argument("--no-precondition", action="store_true", help="skip the clock pre-conditioning launches (the cold-burst figure of rounds 1-3)")
     ap.add_argument("--precondition-max", type=int, default=400, help="cap on the pre-conditioning launches")
     return ap.parse_args()

@@ -270,6 +270,7 @@ View<T> make(size_t n) { return View<T>{std::make_shared<Alloc>(n * sizeof(T)), 
 // the per-block ring of output buffers (header comment).  depth 0: every acquire allocates (unpooled).
 class Ring {
     std::shared_ptr<detail::RingState> s_;
+    bool first_fill_ = true; // acquire() is called by the ring's own block thread only
 
 public:
     explicit Ring(size_t depth = default_ring_depth_ref().load()) : s_(std::make_shared<detail::RingState>()) { s_->depth = depth; }
@@ -325,6 +326,16 @@ public:
                 { std::lock_guard<std::mutex> l(s_->m); --s_->live; }
                 s_->cv.notify_all();
                 check(rc);
+            }
+        }
+        if (first_fill_) { // the ring's first message: the other depth - 1 buffers of its size class now, so that a graph allocates during its
+            first_fill_ = false; // first message and never after (a fourth buffer first needed deep into a run would be a late hipMalloc)
+            for (size_t i = 1; i < s_->depth; ++i) {
+                std::unique_ptr<Buf> extra(new Buf);
+                if (extra->grow(b->cap) != REDIO_OK) break; // the ring then holds fewer buffers until a later acquire can allocate
+                std::lock_guard<std::mutex> l(s_->m);
+                ++s_->live; ++s_->grows;
+                s_->free.push_back(std::move(extra));
             }
         }
         auto a = std::make_shared<Alloc>();

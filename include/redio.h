@@ -163,7 +163,7 @@ int redio_chain_reserve_u8(redio_chain *h, size_t nbytes);
  * their stamp buffers from it. */
 size_t redio_chain_blocks_per_wave(const redio_chain *h, size_t nblocks);
 size_t redio_chain_launch_waves(const redio_chain *h, size_t nblocks);
-/* the fused kernel's name as rocprofv3 reports it, spaces removed (e.g. "chain_v4_kernel<127,5,true,2,8,false,true,false>"); NULL for a
+/* the fused kernel's name as rocprofv3 reports it, spaces removed (e.g. "chain_v4_kernel<127,5,true,2,8,false,true,false,false>"); NULL for a
  * two-kernel plan.  bench.py refuses a counter file (profiles/rNN_traffic.json) recorded for another kernel.  Owned by the plan. */
 const char *redio_chain_kernel_name(redio_chain *h);
 /* diagnostic, per plan: while d_buf (device memory, capacity_waves records of 4 x u64) is set, wavefront w < capacity_waves of the

@@ -41,7 +41,7 @@ hipError_t launch_chain(const FftPlanDev &p, const float2 *x, long n_in, const f
 const char *chain_kernel_name(int K, long D, bool fused_math, char *buf, size_t cap)
 {
     if (!chain_supported(K, D, 1024)) return nullptr;
-    snprintf(buf, cap, "chain_v4_kernel<%d,%ld,%s,2,8,false,true,false>", K, D, fused_math ? "true" : "false");
+    snprintf(buf, cap, "chain_v4_kernel<%d,%ld,%s,2,8,false,true,false,false>", K, D, fused_math ? "true" : "false");
     return buf;
 }
 

@@ -426,7 +426,7 @@ def test_chain_stamp_buffer_capacity_is_honoured(gpu, redio, oracle):
     assert (g[4 * cap:] == -7).all(), "a wavefront beyond the buffer's capacity wrote a stamp"
     assert (g[: 4 * cap].reshape(cap, 4)[:, 1] > 0).all(), "every wavefront below the capacity leaves its record"
     assert same_bits(out.cpu().numpy()[-2:], oracle.chain_fir_fft(oracle.synth_iq(0x5EED0002, (nblocks - 2) * 5120, 2 * 5120 + 126), taps, 5, 1024, fused=True))
-    assert chain.kernel_name == "chain_v4_kernel<127,5,true,2,8,false,true,false>"
+    assert chain.kernel_name == "chain_v4_kernel<127,5,true,2,8,false,true,false,false>"
     two = redio.Chain(taps, 2, 64, fused=False)
     assert two.kernel_name is None and two.launch_waves(100) == 0 and two.blocks_per_wave(100) == 0
 
