@@ -390,7 +390,7 @@ def other_configs(R, lib, stream, x, n, moved_json=None):
     ms = timed(lambda: pfb.from_bytes(raw, out=o4), 50)
     res["c4_channelizer_u8"] = entry("the same filterbank fed with the receiver's u8 I/Q bytes (rtlsdr::data_to_samples folded into the window loads): "
                                      "2 B in + 8 B out per sample", 10.0 * n, ms, "pfb64_kernel<16, u8>", n, "MSamples/s",
-                                     binding="valu (37+ vector instructions per sample; see DESIGN.md 5.6)")
+                                     binding="valu (37+ vector instructions per sample; DESIGN.md 5.6)")
     del raw, o4, pfb
 
     # --- configs[4] on one GPU: overlap-save, 65536-point blocks, 8193 taps (17.14 B per output sample), >= 2 work-buffer chunks ---

@@ -13,7 +13,7 @@
 namespace redio {
 
 // Cache policy of the two streams (round 6), NT bit 0: non-temporal row loads, bit 1: non-temporal row stores.  Every input row is read
-// once and every output row written once, and the plain 1 : 1 copy of this pool runs 6 % faster with non-temporal accesses (DESIGN.md 4),
+// once and every output row written once, and the plain 1 : 1 copy of this pool runs 6 % faster with non-temporal accesses (DESIGN.md 5),
 // but what a kernel gains depends on its store pattern and on what else bounds it -- measured per kernel (profiles/r06_channelizer_nt.txt):
 //   the one-kernel shapes (pfb_p2_kernel, 16-byte stores of whole rows): both non-temporal, + 2-4 %;
 //   pfb64_kernel from cf32: the DEFAULT policy (non-temporal stores of its 32-byte-per-lane rows cost 11 %, loads alone 2 %);
