@@ -99,16 +99,16 @@ RD_HD float2 cadd_rn(float2 a, float2 b) { return make_float2(add_rn(a.x, b.x), 
 RD_HD float2 csub_rn(float2 a, float2 b) { return make_float2(sub_rn(a.x, b.x), sub_rn(a.y, b.y)); }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
-// rtlsdr.rs:159: i as f32 / 127.0 - 1.0.  The IEEE quotient without the division sequence: q0 = b*r with
-// r = fl(1/127), one residual step e = b - 127*q0 (exact in an FMA), q = q0 + e*r.  This is the correctly
-// rounded b/127 for every byte b -- the domain has 256 points and tests/test_gpu_ingest.py checks all of
-// them against the oracle's plain division.
+// rtlsdr.rs:159: i as f32 / 127.0 - 1.0.  The IEEE quotient without the division sequence: 1/127 as a two-float constant r_hi + r_lo
+// (r_hi = fl(1/127), r_lo = fl(1/127 - r_hi)), q = fma(b, r_hi, fl(b * r_lo)): b * r_lo is far below half an ulp of the result, and the sum is
+// rounded once -- the correctly rounded b/127 for every byte b (the domain has 256 points: tests/test_gpu_ingest.py checks all of them, and
+// all 65536 byte pairs, against the oracle's plain division).  One multiply + one FMA per component; round 5's form (b * r, the exact
+// residual b - 127 q0 in an FMA, q0 + e * r) took three.
 __device__ __forceinline__ float i2f(unsigned b)
 {
-    const float fb = (float)b, r = 1.0f / 127.0f;
-    const float q0 = mul_rn(fb, r);
-    const float e = fma_rn(-q0, 127.0f, fb);
-    return sub_rn(fma_rn(e, r, q0), 1.0f);
+    const float fb = (float)b;
+    constexpr float r_hi = 0x1.020408p-7f, r_lo = 0x1.020408p-35f;
+    return sub_rn(fma_rn(fb, r_hi, mul_rn(fb, r_lo)), 1.0f);
 }
 #endif
 

@@ -1052,6 +1052,9 @@ int main(int argc, char **argv)
 {
     try {
         std::string mode = argc > 1 ? argv[1] : "plumbing";
+        // the device graphs of this driver under the other stream policy / ring depth (tests/test_kpn_cpp.py runs them both ways)
+        if (const char *e = std::getenv("KPN_DEV_STREAMS")) dev::set_stream_policy(std::string(e) == "per_block" ? dev::PER_BLOCK : dev::SHARED);
+        if (const char *e = std::getenv("KPN_DEV_RING")) dev::set_default_ring_depth((size_t)std::atol(e));
         if (mode == "plumbing") return plumbing();
         if (mode == "c1" && argc == 4) return c1(argv[2], argv[3]);
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));

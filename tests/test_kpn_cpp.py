@@ -17,6 +17,18 @@ def exe(redio):
     return EXE
 
 
+@pytest.fixture(params=["shared", "per_block", "ring1"])
+def devenv(request):
+    """The device graphs run three ways: compute blocks on the shared graph stream (the default), a stream per block (order made by events on
+    demand), and rings of ONE buffer per block (every message waits for its predecessor's handle: the tightest credit)."""
+    env = dict(os.environ)
+    if request.param == "per_block":
+        env["KPN_DEV_STREAMS"] = "per_block"
+    elif request.param == "ring1":
+        env["KPN_DEV_RING"] = "1"
+    return env
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
@@ -93,13 +105,13 @@ def test_resample_block_in_cpp_graph(exe, gpu, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_device_resident_graph_fork_chain_and_fir(exe, gpu, oracle, tmp_path):
+def test_device_resident_graph_fork_chain_and_fir(exe, gpu, oracle, tmp_path, devenv):
     """include/kpn_dev.hpp: to_device -> fork (shares the allocation) -> {fused chain, FIR} -> to_host."""
     msg = 4 * 5120 + 126
     x = oracle.synth_iq(0x5EED0002, 0, 3 * msg)
     x.tofile(tmp_path / "in.bin")
     out = subprocess.run([exe, "devchain", str(tmp_path / "in.bin"), str(tmp_path / "spec.bin"), str(tmp_path / "fir.bin"), str(msg)],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env=devenv)
     assert out.returncode == 0, out.stderr
     taps = oracle.lpf_corrected(127, 0.08)
     spec = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
@@ -111,14 +123,14 @@ def test_device_resident_graph_fork_chain_and_fir(exe, gpu, oracle, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1, 2])
-def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tmp_path, seed):
+def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tmp_path, seed, devenv):
     """include/kpn_dev.hpp stream blocks (redio_*_stream_*): a stream cut into messages of 1 ... 70000 samples gives, message
     seams or not, exactly the outputs of one stateless call on the whole stream (SURVEY.md 8d C2 "history carried")."""
     n = 300000 + 7
     x = oracle.synth_iq(0x5EED0002, 0, n)
     x.tofile(tmp_path / "in.bin")
     out = subprocess.run([exe, "devstream", str(tmp_path / "in.bin"), str(tmp_path / "spec.bin"), str(tmp_path / "fir.bin"),
-                          str(tmp_path / "ovs.bin"), str(seed)], capture_output=True, text=True, timeout=900)
+                          str(tmp_path / "ovs.bin"), str(seed)], capture_output=True, text=True, timeout=900, env=devenv)
     assert out.returncode == 0, out.stderr
     taps = oracle.lpf_corrected(127, 0.08)
     spec = np.fromfile(tmp_path / "spec.bin", dtype=np.complex64)
@@ -130,14 +142,14 @@ def test_device_stream_blocks_carry_history_across_messages(exe, gpu, oracle, tm
 
 
 @pytest.mark.gpu
-def test_byte_messages_through_the_one_kernel_chain_block(exe, gpu, oracle, tmp_path):
+def test_byte_messages_through_the_one_kernel_chain_block(exe, gpu, oracle, tmp_path, devenv):
     """dev::bytes_fir_fft_chain in a C++ kpn graph: the receiver's Vec<u8> messages (rtlsdr.rs:127-152) -> device -> data_to_samples +
     FIR + FFT in one kernel per message -> host.  Per message the spectra of the oracle's data_to_samples (rtlsdr.rs:159-162) and
     chain on that message (stateless blocks: the reference's own message semantics)."""
     msg = 2 * (5 * 1024 * 6 + 122 + 777)           # six blocks and a ragged tail per message
     raw = np.random.default_rng(3).integers(0, 256, 3 * msg + 2 * (5 * 1024 + 122), dtype=np.uint8)
     raw.tofile(tmp_path / "raw.bin")
-    out = subprocess.run([exe, "devbytes", str(tmp_path / "raw.bin"), str(tmp_path / "spec.bin"), str(msg)], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, "devbytes", str(tmp_path / "raw.bin"), str(tmp_path / "spec.bin"), str(msg)], capture_output=True, text=True, timeout=900, env=devenv)
     assert out.returncode == 0, out.stderr
     taps = oracle.lpf_corrected(127, 0.08)
     want = np.concatenate([oracle.chain_fir_fft(oracle.data_to_samples(raw[o:o + msg]), taps, 5, 1024, True).reshape(-1)
@@ -209,22 +221,22 @@ def test_bench_c2_mode_reports_graph_against_bare_launches(exe, gpu):
 
 
 @pytest.mark.gpu
-def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path):
+def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path, devenv):
     x = oracle.synth_f32(3, 0, 10000)
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "devshaper", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "3000", "1024"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, "devshaper", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "3000", "1024"], capture_output=True, text=True, timeout=900, env=devenv)
     assert out.returncode == 0, out.stderr
     y = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     assert np.array_equal(bits(y), bits(x[: (10000 // 1024) * 1024]))   # the trailing partial chunk is dropped (kpn.rs:278-282)
 
 
 @pytest.mark.gpu
-def test_device_vector_maps_and_resampler_blocks(exe, gpu, oracle, tmp_path):
+def test_device_vector_maps_and_resampler_blocks(exe, gpu, oracle, tmp_path, devenv):
     # f32 stream -> dev::sum_vecs -> dev::mul_vecs -> dev::resample, all in HBM between the PCIe crossings
     msg, ratio = 4000, 0.5
     x = oracle.synth_f32(21, 0, 5 * msg + 123)          # the last message is short: zip truncates to it
     x.tofile(tmp_path / "in.bin")
-    out = subprocess.run([exe, "devmix", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(msg), str(ratio)], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, "devmix", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(msg), str(ratio)], capture_output=True, text=True, timeout=900, env=devenv)
     assert out.returncode == 0, out.stderr
     i = np.arange(msg)
     c = ((i % 7).astype(np.float32) * np.float32(0.25) - np.float32(0.5)).astype(np.float32)
@@ -238,12 +250,12 @@ def test_device_vector_maps_and_resampler_blocks(exe, gpu, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_device_channelizer_and_overlap_save_blocks(exe, gpu, oracle, tmp_path):
+def test_device_channelizer_and_overlap_save_blocks(exe, gpu, oracle, tmp_path, devenv):
     msg = 64 * 300
     x = oracle.synth_iq(22, 0, 2 * msg)
     x.tofile(tmp_path / "in.bin")
     out = subprocess.run([exe, "devbank", str(tmp_path / "in.bin"), str(tmp_path / "pfb.bin"), str(tmp_path / "ovs.bin"), str(msg)],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env=devenv)
     assert out.returncode == 0, out.stderr
     proto, taps = oracle.lpf_corrected(64 * 16, 0.45 / 64), oracle.lpf_corrected(127, 0.08)
     want_pfb = np.concatenate([oracle.pfb_channelizer(x[i * msg:(i + 1) * msg], proto, 64, 16, True).reshape(-1) for i in range(2)])
