@@ -239,6 +239,7 @@ def kpn_graph_leg(cpu_kpn_msps, timeout=90):
     specs += [f"{k}:{n}:4:0:0:resident:drop" for k, n in ((24, 4000), (28, 340))]
     specs += [f"{k}:{n}:0:1:1:resident:checksum" for k, n in ((16, 4000), (24, 200), (28, 28))]          # the round-5 host path
     specs += ["28:200:4:0:0:synth:drop"]                                                                     # input generated per message
+    specs += [f"{k}:{n}:4:0:0:carried:checksum" for k, n in ((16, 8000), (24, 2000), (28, 340))]             # the chain as a STREAM: history carried
     t0 = time.perf_counter()
     try:
         p = subprocess.run([exe, "bench_c2_list"] + specs, capture_output=True, text=True, timeout=timeout)
@@ -256,14 +257,17 @@ def kpn_graph_leg(cpu_kpn_msps, timeout=90):
                 "frac_of_bare_chain_only": r["frac_of_bare_chain_only"], "graph_us_per_msg": r["graph_us_per_msg"], "bare_us_per_msg": r["bare_us_per_msg"],
                 "mallocs_in_timed_region": r["mallocs_in_timed_region"]}
 
+    for r in pts:
+        r.setdefault("history", "per_message")
     sel = lambda **kw: [slim(r) for r in pts if all(r[k] == v for k, v in kw.items())]
-    ship = sel(ring=4, host_sync=0, source="resident", sink="checksum")
+    ship = sel(ring=4, host_sync=0, source="resident", sink="checksum", history="per_message")
     over = [r["log2_msg"] for r in ship if r["graph_gsps"] * 1e3 > cpu_kpn_msps] if cpu_kpn_msps else []
     return {"workload": "BASELINE.json configs[1] behind the operator API (include/kpn_dev.hpp; kpn.rs:278-291, kissfft.rs:18-31, ratpak.rs:60-185): source -> "
                         "dev::fir_fft_chain (127 taps / 5 -> 1024-point transform) -> sink, one OS thread per block, messages through channels, bounded rings of 4 "
                         "buffers per block, compute blocks on the shared graph stream; GS/s of input samples that reach a spectrum; bare = the same launches "
                         "(redio_chain_enqueue [+ redio_checksum_u32]) back to back from one thread on one stream, same buffers, same process",
             "checksum_sink": ship, "drop_sink": sel(ring=4, host_sync=0, source="resident", sink="drop"),
+            "carried_history_stream_block": sel(history="carried"),
             "round5_host_path": sel(ring=0, host_sync=1),
             "synth_source_drop_sink": sel(source="synth"),
             "overtakes_cpu_kpn_pipeline_from_log2_msg": min(over) if over else None,
@@ -271,7 +275,9 @@ def kpn_graph_leg(cpu_kpn_msps, timeout=90):
             "note": "frac_of_bare: graph rate / bare rate for the same work (chain + sink kernel); frac_of_bare_chain_only: against the chain launches alone "
                     "(the checksum sink reads every spectrum word once more: 1.6 of 11.2 B per sample).  round5_host_path = no pool (hipMalloc + hipFree per message), "
                     "hipStreamSynchronize before every send, a stream per block.  synth_source: every message generated afresh in the source block "
-                    "(8 more bytes per sample through HBM).  A message of 2^13 samples holds one 1024-point spectrum.",
+                    "(8 more bytes per sample through HBM).  carried_history_stream_block: dev::fir_fft_chain_stream (redio_chain_stream_*: the unconsumed tail of "
+                    "every message stays on the device, SURVEY.md 8d C2 'history carried') against redio_chain_stream_enqueue + checksum launched bare; every "
+                    "sample of a message counts.  A message of 2^13 samples holds one 1024-point spectrum.",
             "leg_seconds": time.perf_counter() - t0}
 
 

@@ -900,7 +900,7 @@ static int dev_ring_graph(size_t msg, size_t nmsg, size_t depth, size_t warm, in
 // for the checksum sink) back to back from one thread on one stream.
 // Both are timed on the host clock between two completed synchronisations after >= 150 ms of warm-up work.
 struct BenchC2 { double bare_us, bare_chain_only_us, graph_us; size_t used; unsigned long long mallocs; unsigned long long checksum; size_t nmsg; };
-static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, bool checksum, bool host_sync, int policy, BenchC2 *res)
+static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, bool checksum, bool host_sync, int policy, BenchC2 *res, bool carried = false)
 {
     using cf = std::complex<float>;
     using clk = std::chrono::steady_clock;
@@ -913,7 +913,11 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
     // ---- bare launches ----
     redio_chain *h = nullptr;
     dev::check(redio_chain_create(&h, taps.data(), taps.size(), 5, 1024, REDIO_FIR_FUSED));
-    const size_t nblk = redio_chain_nblocks(h, msg), used = nblk * 5120, nout = nblk * 1024;
+    // carried: the chain as a STREAM (redio_chain_stream_*: the unconsumed tail of every message kept on the device, SURVEY.md 8d C2 "history
+    // carried"): every message of 2^k samples then yields 2^k / 5120 spectra on average instead of dropping its last 126 + samples
+    redio_chain_stream *hs = nullptr;
+    if (carried) dev::check(redio_chain_stream_create(&hs, h));
+    const size_t nblk = carried ? (msg / 5120 + 1) : redio_chain_nblocks(h, msg), used = carried ? msg : nblk * 5120, nout = nblk * 1024;
     double bare_us = 0, bare_chain_us = 0;
     size_t warm = 8;
     {
@@ -922,8 +926,10 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
         dev::BlockStream st(dev::BlockStream::TRANSFER);
         auto burst = [&](size_t n, bool with_sink) {
             for (size_t i = 0; i < n; ++i) {
-                dev::check(redio_chain_enqueue(h, big.data() + (i % R) * msg, msg, outs.data() + (i % R) * nout, st));
-                if (with_sink) dev::check(redio_checksum_u32(outs.data() + (i % R) * nout, nout * 2, acc.data(), st));
+                size_t got = nout;
+                if (carried) dev::check(redio_chain_stream_enqueue(hs, big.data() + (i % R) * msg, msg, outs.data() + (i % R) * nout, &got, st));
+                else dev::check(redio_chain_enqueue(h, big.data() + (i % R) * msg, msg, outs.data() + (i % R) * nout, st));
+                if (with_sink && got) dev::check(redio_checksum_u32(outs.data() + (i % R) * nout, got * 2, acc.data(), st));
             }
             dev::check(redio_stream_sync(st));
         };
@@ -944,6 +950,7 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
             bare_chain_us = std::chrono::duration<double>(clk::now() - t2).count() / (double)nmsg * 1e6;
         }
     }
+    if (hs) redio_chain_stream_destroy(hs);
     redio_chain_destroy(h);
     // ---- the graph ----
     dev::set_default_ring_depth(depth);
@@ -959,7 +966,8 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
         th.push_back(spawn([s = std::move(s1), big, msg, total, R]() mutable { for (size_t i = 0; i < total; ++i) s.send_unwrap(big.sub((i % R) * msg, msg)); }));
     else
         th.push_back(spawn([s = std::move(s1), msg, total]() mutable { dev::synth_iq_source(std::move(s), 0x5EED0002u, msg, total); }));
-    th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    if (carried) th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain_stream(std::move(r), std::move(s), taps, 5, 1024, true); }));
+    else th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain(std::move(r), std::move(s), taps, 5, 1024, true); }));
     th.push_back(spawn([&, r = std::move(r2)]() mutable {
         dev::BlockStream st;
         auto acc = dev::make<unsigned long long>(1);
@@ -991,23 +999,25 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
     return 0;
 }
 
-static void bench_c2_print(int log2_msg, size_t depth, bool resident, bool checksum, bool host_sync, int policy, const BenchC2 &r)
+static void bench_c2_print(int log2_msg, size_t depth, bool resident, bool checksum, bool host_sync, int policy, const BenchC2 &r, bool carried = false)
 {
     std::printf("{\"mode\": \"bench_c2\", \"log2_msg\": %d, \"used_samples_per_msg\": %zu, \"messages\": %zu, \"ring\": %zu, \"source\": \"%s\", "
-                "\"sink\": \"%s\", \"host_sync\": %d, \"streams\": \"%s\", \"bare_us_per_msg\": %.3f, \"bare_gsps\": %.3f, \"bare_chain_only_us_per_msg\": %.3f, "
+                "\"sink\": \"%s\", \"host_sync\": %d, \"streams\": \"%s\", \"history\": \"%s\", \"bare_us_per_msg\": %.3f, \"bare_gsps\": %.3f, \"bare_chain_only_us_per_msg\": %.3f, "
                 "\"graph_us_per_msg\": %.3f, \"graph_gsps\": %.3f, \"frac_of_bare\": %.4f, \"frac_of_bare_chain_only\": %.4f, \"mallocs_in_timed_region\": %llu, "
                 "\"checksum\": %llu}\n",
                 log2_msg, r.used, r.nmsg, depth, resident ? "resident" : "synth", checksum ? "checksum" : "drop", (int)host_sync,
-                policy ? "per_block" : "shared", r.bare_us, (double)r.used / r.bare_us * 1e-3, r.bare_chain_only_us, r.graph_us,
+                policy ? "per_block" : "shared", carried ? "carried" : "per_message", r.bare_us, (double)r.used / r.bare_us * 1e-3, r.bare_chain_only_us, r.graph_us,
                 (double)r.used / r.graph_us * 1e-3, r.bare_us / r.graph_us, r.bare_chain_only_us / r.graph_us, r.mallocs, r.checksum);
     std::fflush(stdout);
 }
 
+// source "carried" = resident messages through dev::fir_fft_chain_stream (the chain as a stream: history carried across messages)
 static int bench_c2(int log2_msg, size_t nmsg, size_t depth, const std::string &source, const std::string &sink, int host_sync, int policy)
 {
     BenchC2 r{};
-    if (int rc = bench_c2_one(log2_msg, nmsg, depth, source == "resident", sink == "checksum", host_sync != 0, policy, &r)) return rc;
-    bench_c2_print(log2_msg, depth, source == "resident", sink == "checksum", host_sync != 0, policy, r);
+    const bool carried = source == "carried";
+    if (int rc = bench_c2_one(log2_msg, nmsg, depth, source != "synth", sink == "checksum", host_sync != 0, policy, &r, carried)) return rc;
+    bench_c2_print(log2_msg, depth, source != "synth", sink == "checksum", host_sync != 0, policy, r, carried);
     return 0;
 }
 
