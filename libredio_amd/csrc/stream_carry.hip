@@ -27,6 +27,34 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : RED
 #define SC_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_rc(_e); } while (0)
 
 namespace {
+// The seam copies (at most W - 1 samples: 42 KB for the chain) as a kernel of this library instead of a device-to-device hipMemcpyAsync.
+// Measured (round 6, tools/exp/carry_ab.sh: the chain as a stream block, messages of 2^13 ... 2^20 samples): 19.1 against 19.4 us per message,
+// 23.3 against 23.7 -- 1-2 %: a call's cost at these sizes is the in-order execution of its four dependent operations on the stream (seam copy,
+// the head's launch, the body's launch, tail copy: ~5 us each), not their enqueue.  Kept because it is never slower and takes the copy engines and
+// their blit path out of the picture.  The widest access the three alignments allow, one element per thread.
+template <typename V>
+__global__ __launch_bounds__(256) void seam_copy_kernel(V *__restrict__ dst, const V *__restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+hipError_t seam_copy(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    const uintptr_t a = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+#define SEAM_GO(V)                                                                                                               \
+    {                                                                                                                            \
+        const size_t n = bytes / sizeof(V);                                                                                      \
+        hipLaunchKernelGGL(seam_copy_kernel<V>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (V *)dst, (const V *)src, n); \
+        return hipGetLastError();                                                                                                \
+    }
+    if ((a & 15) == 0) SEAM_GO(uint4)
+    if ((a & 7) == 0) SEAM_GO(uint2)
+    if ((a & 3) == 0) SEAM_GO(uint32_t)
+    if ((a & 1) == 0) SEAM_GO(uint16_t)
+    SEAM_GO(uint8_t)
+#undef SEAM_GO
+}
 enum Kind { K_FIR, K_CHAIN, K_PFB, K_OVSAVE, K_CHAIN_U8, K_PFB_U8 }; // _U8: the samples are interleaved u8 I/Q byte pairs
 struct Carry {
     int device = 0;
@@ -118,7 +146,7 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     // the carried tail, and writes the same bytes again if the call is repeated); the state is committed at the end.
     char *S = c->d_s[c->cur], *T = c->d_s[c->cur ^ 1];
     const size_t m = n < c->W - 1 ? n : c->W - 1;
-    if (c->hist > 0 && m > 0) SC_TRY(hipMemcpyAsync(S + c->hist * c->in_elem, src, m * c->in_elem, hipMemcpyDeviceToDevice, st));
+    if (c->hist > 0 && m > 0) SC_TRY(seam_copy(S + c->hist * c->in_elem, src, m * c->in_elem, st));
     char *out = (char *)d_out;
     if (s.nh) {
         const int rc = run(*c, S, s.head_in, out, stream);
@@ -137,10 +165,10 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     } else {
         new_hist = c->hist + n - consumed;
         if (consumed >= c->hist) { // lies entirely in the caller's buffer
-            if (new_hist) SC_TRY(hipMemcpyAsync(T, src + (consumed - c->hist) * c->in_elem, new_hist * c->in_elem, hipMemcpyDeviceToDevice, st));
+            if (new_hist) SC_TRY(seam_copy(T, src + (consumed - c->hist) * c->in_elem, new_hist * c->in_elem, st));
         } else { // starts inside the old tail: then n < W - 1 and the staging buffer holds all of [tail | new]
-            if (c->hist == 0) SC_TRY(hipMemcpyAsync(T, src, n * c->in_elem, hipMemcpyDeviceToDevice, st));
-            else SC_TRY(hipMemcpyAsync(T, S + consumed * c->in_elem, new_hist * c->in_elem, hipMemcpyDeviceToDevice, st));
+            if (c->hist == 0) SC_TRY(seam_copy(T, src, n * c->in_elem, st));
+            else SC_TRY(seam_copy(T, S + consumed * c->in_elem, new_hist * c->in_elem, st));
         }
         flip = true;
     }
