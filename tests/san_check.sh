@@ -10,7 +10,7 @@
 # leak checking off: the interpreter never frees its own arenas).  usage: bash tests/san_check.sh [logfile]
 set -e -o pipefail   # a sanitizer abort or a failing test ends the script non-zero (tail / tee no longer hide the status)
 R=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$R/profiles/r05_sanitizers.txt}
+LOG=${1:-$R/profiles/r06_sanitizers.txt}
 cd $R
 make -C oracle -s SAN=1
 make -C tests/emu -s SAN=1
@@ -22,7 +22,7 @@ UBSAN_LIB=$(gcc -print-file-name=libubsan.so)
 {
   echo "# tests/san_check.sh: $(date -u +%Y-%m-%dT%H:%MZ), $(gcc --version | head -1)"
   echo "# flags: -fsanitize=address,undefined -fno-sanitize-recover=undefined (any report aborts the process: a clean log is a clean run)"
-  echo "== kpn_tests_san plumbing (include/kpn.hpp CPU blocks, a block that throws mid-stream, bounded channels)"
+  echo "== kpn_tests_san plumbing (include/kpn.hpp CPU blocks, a block that throws mid-stream, bounded channels; the rings and the stream ordering of include/kpn_dev.hpp on stand-in device calls)"
   ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 tests/_build/kpn_tests_san plumbing 2>&1 | tail -5
   echo "== kpn_tests_tsan plumbing (ThreadSanitizer: the channels and every block thread; exit code 66 on a report)"
   TSAN_OPTIONS="exitcode=66" tests/_build/kpn_tests_tsan plumbing 2>&1 | grep -E "ThreadSanitizer|plumbing ok" | sort | uniq -c
