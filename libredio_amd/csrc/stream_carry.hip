@@ -65,7 +65,8 @@ struct Carry {
     size_t unit_out = 0, out_elem = 0;    // output samples per unit, bytes per output sample
     char *d_s[2] = {nullptr, nullptr};    // staging buffers, 2*W input samples each
     int cur = 0;
-    size_t hist = 0;                      // samples of the stream's tail held in d_s[cur]
+    size_t off = 0;                       // where the tail starts inside d_s[cur], in samples (off * in_elem is a multiple of 16)
+    size_t hist = 0;                      // samples of the stream's tail held in d_s[cur] from `off` on
     size_t skip = 0;                      // H > W only: samples still to be dropped before the next unit starts (then hist == 0)
     unsigned long long total_in = 0, total_units = 0;
     std::atomic_flag busy = ATOMIC_FLAG_INIT; // one thread at a time inside enqueue / reset
@@ -144,8 +145,16 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     if (n == 0) { c->skip -= drop; c->total_in += n_call; return REDIO_OK; }
     // Everything up to the last launch leaves the handle's state alone (the seam copy below only writes staging memory behind
     // the carried tail, and writes the same bytes again if the call is repeated); the state is committed at the end.
-    char *S = c->d_s[c->cur], *T = c->d_s[c->cur ^ 1];
     const size_t m = n < c->W - 1 ? n : c->W - 1;
+    // The tail may sit at an offset inside its staging buffer (below: a small call that consumes whole units out of [tail | new] leaves the
+    // new tail where it lies instead of copying it to the other buffer's front).  When this call's samples no longer fit behind it, the tail
+    // moves to the other buffer's front first; that only re-seats the same samples, so it is committed at once.
+    if (c->hist > 0 && c->off + c->hist + m > 2 * c->W) {
+        SC_TRY(seam_copy(c->d_s[c->cur ^ 1], c->d_s[c->cur] + c->off * c->in_elem, c->hist * c->in_elem, st));
+        c->cur ^= 1;
+        c->off = 0;
+    }
+    char *S = c->d_s[c->cur] + c->off * c->in_elem, *T = c->d_s[c->cur ^ 1];
     if (c->hist > 0 && m > 0) SC_TRY(seam_copy(S + c->hist * c->in_elem, src, m * c->in_elem, st));
     char *out = (char *)d_out;
     if (s.nh) {
@@ -158,7 +167,7 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
     }
     // the new tail: everything from the start of the first unit not yet produced
     const size_t consumed = (s.nh + s.nb) * c->H; // staging coordinates ([tail | new])
-    size_t new_hist = 0, new_skip = c->skip - drop;
+    size_t new_hist = 0, new_skip = c->skip - drop, new_off = 0;
     bool flip = false;
     if (consumed >= c->hist + n) { // only when H > W: the next unit starts beyond what has arrived
         new_skip = consumed - (c->hist + n);
@@ -166,14 +175,22 @@ int carry_enqueue(Carry *c, const void *d_new, size_t n, void *d_out, size_t *no
         new_hist = c->hist + n - consumed;
         if (consumed >= c->hist) { // lies entirely in the caller's buffer
             if (new_hist) SC_TRY(seam_copy(T, src + (consumed - c->hist) * c->in_elem, new_hist * c->in_elem, st));
-        } else { // starts inside the old tail: then n < W - 1 and the staging buffer holds all of [tail | new]
-            if (c->hist == 0) SC_TRY(seam_copy(T, src, n * c->in_elem, st));
-            else SC_TRY(seam_copy(T, S + consumed * c->in_elem, new_hist * c->in_elem, st));
+            flip = true;
+        } else if (c->hist == 0) { // a first piece shorter than a window
+            SC_TRY(seam_copy(T, src, n * c->in_elem, st));
+            flip = true;
+        } else if ((consumed * c->in_elem) % 16 == 0) {
+            // starts inside the old tail: then n < W - 1 and the staging buffer holds all of [tail | new] -- the new tail stays where it is
+            // (round 6: one dependent operation less per small message; 16-byte alignment of the next call's window kept)
+            new_off = c->off + consumed;
+        } else {
+            SC_TRY(seam_copy(T, S + consumed * c->in_elem, new_hist * c->in_elem, st));
+            flip = true;
         }
-        flip = true;
     }
     // commit
     if (flip) c->cur ^= 1;
+    c->off = new_off;
     c->hist = new_hist;
     c->skip = new_skip;
     c->total_in += n_call;
@@ -185,7 +202,7 @@ int carry_reset(Carry *c)
 {
     const Entered guard(c);
     if (!guard.ok()) return REDIO_ERR_ARG;
-    c->hist = 0; c->skip = 0; c->total_in = 0; c->total_units = 0;
+    c->hist = 0; c->off = 0; c->skip = 0; c->total_in = 0; c->total_units = 0;
     return REDIO_OK;
 }
 } // namespace

@@ -962,8 +962,15 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
     clk::time_point t0, t1;
     unsigned long long m0 = 0, m1 = 0, sum = 0;
     std::vector<std::thread> th;
+    clk::time_point t0_src; // carried: the stream block sends only when a spectrum completes, so the sink cannot count input messages: the
+                            // timed region then starts when the SOURCE hands over message `warm` (the queues behind it hold at most ~16 messages)
     if (resident)
-        th.push_back(spawn([s = std::move(s1), big, msg, total, R]() mutable { for (size_t i = 0; i < total; ++i) s.send_unwrap(big.sub((i % R) * msg, msg)); }));
+        th.push_back(spawn([&t0_src, warm, s = std::move(s1), big, msg, total, R]() mutable {
+            for (size_t i = 0; i < total; ++i) {
+                if (i == warm) t0_src = clk::now();
+                s.send_unwrap(big.sub((i % R) * msg, msg));
+            }
+        }));
     else
         th.push_back(spawn([s = std::move(s1), msg, total]() mutable { dev::synth_iq_source(std::move(s), 0x5EED0002u, msg, total); }));
     if (carried) th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain_stream(std::move(r), std::move(s), taps, 5, 1024, true); }));
@@ -974,6 +981,17 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
         const unsigned long long zero = 0;
         dev::check(redio_upload(acc.data(), &zero, 8, st));
         dev::check(redio_stream_sync(st));
+        if (carried) { // until hang-up: every spectrum the stream block completes
+            m0 = redio_malloc_count();
+            try {
+                for (;;) {
+                    auto d = r.recv();
+                    dev::Reading<cf> in(d, st);
+                    if (checksum) dev::check(redio_checksum_u32(d.data(), d.len * 2, acc.data(), st));
+                }
+            } catch (const hangup &) {
+            }
+        } else
         for (size_t i = 0; i < total; ++i) {
             auto d = r.recv();
             {
@@ -989,6 +1007,7 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
         dev::check(redio_stream_sync(st));
     }));
     for (auto &t : th) t.join();
+    if (carried) t0 = t0_src;
     dev::set_host_sync(false);
     dev::set_default_ring_depth(4);
     dev::set_stream_policy(dev::SHARED);

@@ -21,6 +21,12 @@ def cuts(rng, n, style):
             k = int(min(left, rng.integers(0, 40)))
             out.append(k); left -= k
         return out
+    if style == "small":      # a few hundred samples per message: a window fills over several calls, the tail stays in place inside its staging
+        out, left = [], n     # buffer (round 6) and is moved to the other buffer's front only when the next message would not fit behind it
+        while left:
+            k = int(min(left, rng.integers(1, 900)))
+            out.append(k); left -= k
+        return out
     if style == "odd":        # odd lengths: the body starts on an odd sample (8-byte aligned only)
         out, left = [], n
         while left:
@@ -45,11 +51,11 @@ def feed(stream, x, pieces, gpu):
     return gpu.cat(outs) if outs else None
 
 
-@pytest.mark.parametrize("style", ["one", "tiny", "odd", "mixed"])
+@pytest.mark.parametrize("style", ["one", "tiny", "small", "odd", "mixed"])
 @pytest.mark.parametrize("k,d,cplx,fused", [(127, 5, True, True), (127, 5, True, False), (63, 1, False, False), (100, 3, True, False), (1, 1, False, False), (17, 4, False, True), (5, 9, True, False)])
 def test_fir_stream_any_segmentation(gpu, redio, oracle, k, d, cplx, fused, style):
     rng = np.random.default_rng(k * 131 + d)
-    n = 30000 if style == "tiny" else 300000
+    n = 30000 if style == "tiny" else (120000 if style == "small" else 300000)
     taps = oracle.synth_f32(5, 0, k)
     xh = (oracle.synth_iq if cplx else oracle.synth_f32)(77, 0, n)
     x = gpu.from_numpy(xh).cuda()
@@ -65,7 +71,7 @@ def test_fir_stream_any_segmentation(gpu, redio, oracle, k, d, cplx, fused, styl
     assert np.array_equal(bits(plan(x).cpu().numpy()), bits(want))
 
 
-@pytest.mark.parametrize("style", ["one", "tiny", "odd", "mixed"])
+@pytest.mark.parametrize("style", ["one", "tiny", "small", "odd", "mixed"])
 @pytest.mark.parametrize("k,d,nfft,fused", [(127, 5, 1024, True), (127, 5, 1024, False), (63, 1, 1024, True), (31, 4, 256, False)])
 def test_chain_stream_any_segmentation(gpu, redio, oracle, k, d, nfft, fused, style):
     rng = np.random.default_rng(k + nfft)
@@ -81,7 +87,7 @@ def test_chain_stream_any_segmentation(gpu, redio, oracle, k, d, nfft, fused, st
     assert st.pending == n - nb * nfft * d
 
 
-@pytest.mark.parametrize("style", ["one", "odd", "mixed"])
+@pytest.mark.parametrize("style", ["one", "small", "odd", "mixed"])
 @pytest.mark.parametrize("nchan,p", [(64, 16), (64, 4), (32, 5)])
 def test_channelizer_stream_any_segmentation(gpu, redio, oracle, nchan, p, style):
     rng = np.random.default_rng(nchan + p)
@@ -95,7 +101,7 @@ def test_channelizer_stream_any_segmentation(gpu, redio, oracle, nchan, p, style
     assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (nchan, p, style)
 
 
-@pytest.mark.parametrize("style", ["one", "odd", "mixed"])
+@pytest.mark.parametrize("style", ["one", "small", "odd", "mixed"])
 @pytest.mark.parametrize("nfft,k", [(1024, 127), (4096, 1025), (65536, 8193), (1000, 100)])
 def test_overlap_save_stream_any_segmentation(gpu, redio, oracle, nfft, k, style):
     rng = np.random.default_rng(nfft + k)
