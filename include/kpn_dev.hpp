@@ -27,6 +27,8 @@
 //     asks for (the reference's unbounded mpsc has no back-pressure: a documented deviation).  After warm-up a graph performs no device
 //     allocation and no hipFree (redio_malloc_count() stays put; tests/test_kpn_cpp.py).  A sink that hoards more than `depth`
 //     messages of one producer without dropping them stalls that producer: drop handles, or give that block a deeper ring.
+//     The rings bound MEMORY, not how far the host threads run ahead of the GPU: a buffer is recycled when its handles drop (the queue
+//     orders the reuse), so hundreds of messages' kernels may sit in the HIP queue; a block that needs a result on the CPU synchronises.
 //   * Blocks written elsewhere use the same three calls: `auto o = ring.acquire<T>(n, st)`, `{ Reading<T> in(view, st); enqueue...; }`,
 //     `publish(o, st)` before sending o, with `BlockStream st;`.
 #pragma once
@@ -321,7 +323,9 @@ public:
             if (b->cap < bytes || !b->ptr) ++s_->grows;
         }
         if (b->cap < bytes || !b->ptr) {
-            const int rc = b->grow(detail::size_class(bytes)); // rare: warm-up, or the largest message so far (hipFree + hipMalloc)
+            // rare: warm-up, or the largest message so far (hipFree + hipMalloc).  One eighth of headroom on top of the size class: a block whose
+            // messages wobble across a class boundary (the stream blocks send 12 or 13 spectra per 2^16-sample message) then settles at once
+            const int rc = b->grow(detail::size_class(bytes + bytes / 8));
             if (rc != REDIO_OK) {
                 { std::lock_guard<std::mutex> l(s_->m); --s_->live; }
                 s_->cv.notify_all();

@@ -960,17 +960,11 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
     auto [s2, r2] = channel<dev::View<cf>>();
     const size_t total = warm + nmsg;
     clk::time_point t0, t1;
+    size_t carried_spectra = 0; // carried: spectra inside the timed region
     unsigned long long m0 = 0, m1 = 0, sum = 0;
     std::vector<std::thread> th;
-    clk::time_point t0_src; // carried: the stream block sends only when a spectrum completes, so the sink cannot count input messages: the
-                            // timed region then starts when the SOURCE hands over message `warm` (the queues behind it hold at most ~16 messages)
     if (resident)
-        th.push_back(spawn([&t0_src, warm, s = std::move(s1), big, msg, total, R]() mutable {
-            for (size_t i = 0; i < total; ++i) {
-                if (i == warm) t0_src = clk::now();
-                s.send_unwrap(big.sub((i % R) * msg, msg));
-            }
-        }));
+        th.push_back(spawn([s = std::move(s1), big, msg, total, R]() mutable { for (size_t i = 0; i < total; ++i) s.send_unwrap(big.sub((i % R) * msg, msg)); }));
     else
         th.push_back(spawn([s = std::move(s1), msg, total]() mutable { dev::synth_iq_source(std::move(s), 0x5EED0002u, msg, total); }));
     if (carried) th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps]() mutable { dev::fir_fft_chain_stream(std::move(r), std::move(s), taps, 5, 1024, true); }));
@@ -981,13 +975,19 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
         const unsigned long long zero = 0;
         dev::check(redio_upload(acc.data(), &zero, 8, st));
         dev::check(redio_stream_sync(st));
-        if (carried) { // until hang-up: every spectrum the stream block completes
-            m0 = redio_malloc_count();
+        if (carried) { // the stream block sends only when spectra complete, so the sink counts SPECTRA: the timed region starts when those of the first
+                       // `warm` messages have arrived and been waited for (the host threads run far ahead of the GPU: a host-side start time would not do)
+            const auto spectra_of = [](size_t n) { return n < 5246 ? (size_t)0 : ((n - 127) / 5 + 1) / 1024; };
+            const size_t s_warm = spectra_of(warm * msg), s_total = spectra_of(total * msg);
+            size_t seen = 0;
+            bool started = false;
             try {
                 for (;;) {
                     auto d = r.recv();
                     dev::Reading<cf> in(d, st);
-                    if (checksum) dev::check(redio_checksum_u32(d.data(), d.len * 2, acc.data(), st));
+                    if (checksum && started) dev::check(redio_checksum_u32(d.data(), d.len * 2, acc.data(), st));
+                    seen += d.len / 1024;
+                    if (!started && seen >= s_warm) { dev::check(redio_stream_sync(st)); m0 = redio_malloc_count(); t0 = clk::now(); started = true; carried_spectra = s_total - seen; }
                 }
             } catch (const hangup &) {
             }
@@ -1007,13 +1007,13 @@ static int bench_c2_one(int log2_msg, size_t nmsg, size_t depth, bool resident, 
         dev::check(redio_stream_sync(st));
     }));
     for (auto &t : th) t.join();
-    if (carried) t0 = t0_src;
     dev::set_host_sync(false);
     dev::set_default_ring_depth(4);
     dev::set_stream_policy(dev::SHARED);
     res->bare_us = bare_us;
     res->bare_chain_only_us = bare_chain_us;
     res->graph_us = std::chrono::duration<double>(t1 - t0).count() / (double)nmsg * 1e6;
+    if (carried) res->graph_us *= (double)nmsg * (double)msg / ((double)carried_spectra * 5120.0); // per message's worth of samples actually inside the timed region
     res->used = used; res->mallocs = m1 - m0; res->checksum = sum; res->nmsg = nmsg;
     return 0;
 }
