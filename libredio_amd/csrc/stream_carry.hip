@@ -28,7 +28,7 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? REDIO_OK : RED
 
 namespace {
 // The seam copies (at most W - 1 samples: 42 KB for the chain) as a kernel of this library instead of a device-to-device hipMemcpyAsync.
-// Measured (round 6, tools/exp/carry_ab.sh: the chain as a stream block, messages of 2^13 ... 2^20 samples): 19.1 against 19.4 us per message,
+// Measured (round 6, tools/carry_ab.sh: the chain as a stream block, messages of 2^13 ... 2^20 samples): 19.1 against 19.4 us per message,
 // 23.3 against 23.7 -- 1-2 %: a call's cost at these sizes is the in-order execution of its four dependent operations on the stream (seam copy,
 // the head's launch, the body's launch, tail copy: ~5 us each), not their enqueue.  Kept because it is never slower and takes the copy engines and
 // their blit path out of the picture.  The widest access the three alignments allow, one element per thread.
