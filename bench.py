@@ -770,6 +770,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": kavg * 1e3,
+                         # "report median and min" of the timed repetitions (the same per-launch HIP events)
+                         "kernel_ms_median": sorted(kms)[len(kms) // 2], "kernel_ms_min": min(kms),
                          "frac_of_measured_copy_6290": ach / 6290.0,
                          # "report min(HBM, VALU) honestly": 4K/D = 101.6 (FIR, complex samples x real taps) + 5 log2(1024) / 5 = 10
                          # (transform on the decimated stream) flops per input sample against the 157.3 TFLOP/s f32 vector peak
