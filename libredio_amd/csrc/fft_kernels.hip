@@ -248,6 +248,10 @@ struct FftP2 {
     static constexpr bool ODD = (LOG2N & 1) != 0; // a radix-2 stage innermost
     static constexpr int E = N >= 4096 ? N : 4096; // points per workgroup
     static constexpr int T = E / N;                // transforms per workgroup
+    // one pad float2 per 8.  Round 6 modelled every LDS access of the kernels on this image (tools/p2_lds_model.py: 50 % of the LDS-array cycles at 256
+    // points are bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE measures 47 %) and tried one pad per 16 for 128 points and more, which halves
+    // them in the model -- measured: 256 channels + 0.8 %, 1024 channels - 3.7 %, 512 - 1.5 %, the 128-point transform - 2.3 %
+    // (profiles/r06_p2_lds_padding.txt): the LDS array is not what these kernels wait for.  Kept at 8.
     __device__ static __forceinline__ int phys(int e) { return e + (e >> 3); }
     static constexpr int LDS_ELEMS = E + (E >> 3) + 8;
     // leaf position of input index n: the top bit is the radix-2 digit, base-4 digits reverse onto N/4, N/16, ...

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run ONE plan shape a few times (for rocprofv3 passes on a secondary kernel):
     python3 tools/shape_probe.py fir|firr|firx|firrx K D [log2n] [launches]
-    python3 tools/shape_probe.py pfb M P [log2n] [launches]
+    python3 tools/shape_probe.py pfb|pfbu8 M P [log2n] [launches]      (pfbu8: the 64-channel channelizer from u8 I/Q bytes)
     python3 tools/shape_probe.py src|srcfast CHANNELS LOG2FRAMES
     python3 tools/shape_probe.py fft N 0 [log2n] [launches]
 Prints the HIP-event mean per launch."""
@@ -13,7 +13,7 @@ import libredio_amd as R
 kind, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 26)
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
-x = R.synth_iq(1, 0, n) if kind not in ("src", "srcfast", "u8chain") else None
+x = R.synth_iq(1, 0, n) if kind not in ("src", "srcfast", "u8chain", "pfbu8") else None
 if kind in ("fir", "firr", "firx", "firrx"):   # r: real samples; x: reference rounding (multiply and add rounded separately)
     cplx = kind in ("fir", "firx")
     if not cplx:
@@ -33,6 +33,12 @@ elif kind in ("src", "srcfast"):   # a = channels, b = log2 frames per channel; 
     n = a << b
     def run():
         plan.reset(); plan.process(xr, 0.02)
+elif kind == "pfbu8":
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    raw = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    plan = R.Channelizer(R.dsputils.lpf_corrected(a * b, 0.45 / a), a, b)
+    out = torch.empty((plan.nrows(n), a), dtype=torch.complex64, device="cuda")
+    run = lambda: plan.from_bytes(raw, out=out)
 elif kind == "pfb":
     plan = R.Channelizer(R.dsputils.lpf_corrected(a * b, 0.45 / a), a, b)
     out = torch.empty((plan.nrows(n), a), dtype=torch.complex64, device="cuda")
