@@ -36,8 +36,8 @@ transform alone, each {workload, alg_bytes, kernel_ms by HIP events after >= 100
 cpu_baseline = the oracle's restatement of that config on this host, one core and all cores on a stated prefix}; `kpn_graph_c2` = the
 chain behind the operator API (include/kpn_dev.hpp: one thread per block, messages through channels, bounded rings) against the bare
 plan launches, messages of 2^13 ... 2^28 samples, with the round-5 host path beside it (`tests/_build/kpn_tests bench_c2_list`, a child
-process); `dropin_calls` = microseconds per call of the host-buffer drop-ins (kiss_fft, src_process, redio_convolve_f32) with the
-oracle's CPU microseconds for the same call beside them.  `--no-graph-leg` skips those two (about 25 s).
+process; `.other_blocks` = dev::channelizer, dev::overlap_save, dev::fft, dev::fir the same way, `kpn_tests bench_block_list`); `dropin_calls` = microseconds per call of the host-buffer drop-ins (kiss_fft, src_process, redio_convolve_f32) with the
+oracle's CPU microseconds for the same call beside them.  `--no-graph-leg` skips those two (about 35 s).
 """
 import argparse
 import ctypes as C
@@ -257,6 +257,21 @@ def kpn_graph_leg(cpu_kpn_msps, timeout=90):
                 "frac_of_bare_chain_only": r["frac_of_bare_chain_only"], "graph_us_per_msg": r["graph_us_per_msg"], "bare_us_per_msg": r["bare_us_per_msg"],
                 "mallocs_in_timed_region": r["mallocs_in_timed_region"]}
 
+    # the other hot blocks through the same machinery (kpn_tests bench_block): source -> block -> checksum sink against the bare launches
+    blocks = []
+    bspecs = ["channelizer:24:2000", "channelizer:28:200", "ovsave:24:800", "ovsave:28:100", "fft:24:2000", "fft:28:300", "fir:24:2000", "fir:28:300"]
+    try:
+        pb = subprocess.run([exe, "bench_block_list"] + bspecs, capture_output=True, text=True, timeout=timeout)
+        for line in pb.stdout.splitlines():
+            if line.startswith("{"):
+                r = json.loads(line)
+                blocks.append({k: r[k] for k in ("block", "msg_samples", "messages", "graph_gsps", "bare_gsps", "frac_of_bare", "graph_us_per_msg", "bare_us_per_msg",
+                                                 "mallocs_in_timed_region")})
+        if pb.returncode != 0:
+            blocks.append({"error": f"kpn_tests bench_block_list rc={pb.returncode}: {pb.stderr[-300:]}"})
+    except subprocess.TimeoutExpired:
+        blocks.append({"error": f"kpn_tests bench_block_list did not finish in {timeout} s"})
+
     for r in pts:
         r.setdefault("history", "per_message")
     sel = lambda **kw: [slim(r) for r in pts if all(r[k] == v for k, v in kw.items())]
@@ -270,6 +285,7 @@ def kpn_graph_leg(cpu_kpn_msps, timeout=90):
             "carried_history_stream_block": sel(history="carried"),
             "round5_host_path": sel(ring=0, host_sync=1),
             "synth_source_drop_sink": sel(source="synth"),
+            "other_blocks": blocks,
             "overtakes_cpu_kpn_pipeline_from_log2_msg": min(over) if over else None,
             "cpu_kpn_pipeline_msps": cpu_kpn_msps,
             "note": "frac_of_bare: graph rate / bare rate for the same work (chain + sink kernel); frac_of_bare_chain_only: against the chain launches alone "
@@ -277,7 +293,10 @@ def kpn_graph_leg(cpu_kpn_msps, timeout=90):
                     "hipStreamSynchronize before every send, a stream per block.  synth_source: every message generated afresh in the source block "
                     "(8 more bytes per sample through HBM).  carried_history_stream_block: dev::fir_fft_chain_stream (redio_chain_stream_*: the unconsumed tail of "
                     "every message stays on the device, SURVEY.md 8d C2 'history carried') against redio_chain_stream_enqueue + checksum launched bare; every "
-                    "sample of a message counts.  A message of 2^13 samples holds one 1024-point spectrum.",
+                    "sample of a message counts.  A message of 2^13 samples holds one 1024-point spectrum.  other_blocks: dev::channelizer (64 x 16, configs[3]), "
+                    "dev::overlap_save (65536-point blocks, 8193 taps, configs[4]), dev::fft (1024 points), dev::fir (127 taps / 5): source -> block -> checksum "
+                    "sink against the same two launches bare (four output buffers in rotation); above 1.0 where the ring's byte budget keeps a message in the "
+                    "last-level cache between its producer and its reader (include/kpn_dev.hpp, profiles/r06_kpn_ring_bytes.txt).",
             "leg_seconds": time.perf_counter() - t0}
 
 

@@ -27,6 +27,8 @@
 //     asks for (the reference's unbounded mpsc has no back-pressure: a documented deviation).  After warm-up a graph performs no device
 //     allocation and no hipFree (redio_malloc_count() stays put; tests/test_kpn_cpp.py).  A sink that hoards more than `depth`
 //     messages of one producer without dropping them stalls that producer: drop handles, or give that block a deeper ring.
+//     A ring also has a BYTE budget (default_ring_bytes_ref below): with the compute blocks on one stream, a producer that runs k
+//     messages ahead puts k outputs between a message and the kernel that reads it -- past the last-level cache that reader goes to HBM.
 //     The rings bound MEMORY, not how far the host threads run ahead of the GPU: a buffer is recycled when its handles drop (the queue
 //     orders the reuse), so hundreds of messages' kernels may sit in the HIP queue; a block that needs a result on the CPU synchronises.
 //   * Blocks written elsewhere use the same three calls: `auto o = ring.acquire<T>(n, st)`, `{ Reading<T> in(view, st); enqueue...; }`,
@@ -83,6 +85,18 @@ inline std::atomic<size_t> &default_ring_depth_ref()
 // buffers per block ring for the blocks below: >= 1 bounded (credits); 0 = no pooling, one allocation per message (the round-5 behaviour,
 // kept for the before/after measurement of `kpn_tests bench_c2`)
 inline void set_default_ring_depth(size_t d) { default_ring_depth_ref().store(d); }
+// bytes one ring may have out with the blocks downstream (beyond the first message, which always goes).  Blocks that share the graph
+// stream run in the order their threads enqueued, so a producer that runs k messages ahead puts k outputs between a message and the
+// kernel that reads it: past the last-level cache (256 MB of Infinity Cache on MI355X) the reader finds its input in HBM instead.
+// Half of that cache, measured (profiles/r06_kpn_ring_bytes.txt): 2^24-sample messages through dev::fft run at 107 % of the bare
+// launches with one 128 MiB output out, at 92 % with two or four; small messages keep the full depth, which hides the host threads,
+// and so do messages larger than the budget itself (nothing keeps those in the cache; measured equal or 1-3 % better unbounded).
+inline std::atomic<size_t> &default_ring_bytes_ref()
+{
+    static std::atomic<size_t> b{(size_t)128 << 20};
+    return b;
+}
+inline void set_default_ring_bytes(size_t b) { default_ring_bytes_ref().store(b); }
 
 // a HIP stream with shared ownership: buffers remember the streams that touched them, so a stream outlives its block while a message
 // that names it is still in flight
@@ -194,6 +208,7 @@ struct RingState {
     std::condition_variable cv;
     std::vector<std::unique_ptr<Buf>> free; // buffers nobody holds
     size_t depth = 0, live = 0;             // live: buffers that exist (free + leased)
+    size_t budget = (size_t)-1, out = 0, out_bytes = 0; // leased buffers and the message bytes in them, against the byte budget
     bool closed = false;
     unsigned long long grows = 0;           // device allocations this ring made (warm-up, or a message larger than any before)
 };
@@ -229,6 +244,8 @@ struct Alloc {
         if (!home || !buf) return; // standalone: ~Buf frees
         {
             std::lock_guard<std::mutex> l(home->m);
+            --home->out;
+            home->out_bytes -= bytes;
             if (home->closed) { --home->live; return; } // the block is gone: ~Buf frees
             home->free.push_back(std::move(buf));
         }
@@ -275,7 +292,12 @@ class Ring {
     bool first_fill_ = true; // acquire() is called by the ring's own block thread only
 
 public:
-    explicit Ring(size_t depth = default_ring_depth_ref().load()) : s_(std::make_shared<detail::RingState>()) { s_->depth = depth; }
+    explicit Ring(size_t depth = default_ring_depth_ref().load(), size_t byte_budget = default_ring_bytes_ref().load())
+        : s_(std::make_shared<detail::RingState>())
+    {
+        s_->depth = depth;
+        s_->budget = byte_budget;
+    }
     Ring(const Ring &) = delete;
     Ring &operator=(const Ring &) = delete;
     ~Ring()
@@ -295,7 +317,8 @@ public:
         std::lock_guard<std::mutex> l(s_->m);
         return s_->grows;
     }
-    // a buffer of n elements for work to be enqueued on `stream`; waits for a credit when all `depth` buffers are held downstream
+    // a buffer of n elements for work to be enqueued on `stream`; waits for a credit while all `depth` buffers, or the byte budget's
+    // worth of messages, are held downstream
     template <typename T>
     View<T> acquire(size_t n, void *stream)
     {
@@ -304,11 +327,13 @@ public:
         std::unique_ptr<Buf> b;
         {
             std::unique_lock<std::mutex> l(s_->m);
-            s_->cv.wait(l, [&] { return !s_->free.empty() || s_->live < s_->depth; });
-            // best fit among the free buffers; else a new one while the ring is not full; else the largest free one is regrown
+            // a message larger than the whole budget cannot be kept in the cache whatever the order: holding its producer back gains nothing
+            s_->cv.wait(l, [&] { return s_->out == 0 || (s_->out < s_->depth && (bytes > s_->budget || s_->out_bytes + bytes <= s_->budget)); });
+            // best fit among the free buffers, the one released last among equals (the likeliest to be in the cache still); else a new
+            // one while the ring is not full; else the largest free one is regrown
             size_t best = s_->free.size();
             for (size_t i = 0; i < s_->free.size(); ++i)
-                if (s_->free[i]->cap >= bytes && (best == s_->free.size() || s_->free[i]->cap < s_->free[best]->cap)) best = i;
+                if (s_->free[i]->cap >= bytes && (best == s_->free.size() || s_->free[i]->cap <= s_->free[best]->cap)) best = i;
             if (best == s_->free.size() && s_->live >= s_->depth) {
                 best = 0;
                 for (size_t i = 1; i < s_->free.size(); ++i) if (s_->free[i]->cap > s_->free[best]->cap) best = i;
@@ -321,20 +346,24 @@ public:
                 ++s_->live;
             }
             if (b->cap < bytes || !b->ptr) ++s_->grows;
+            ++s_->out;
+            s_->out_bytes += bytes;
         }
         if (b->cap < bytes || !b->ptr) {
             // rare: warm-up, or the largest message so far (hipFree + hipMalloc).  One eighth of headroom on top of the size class: a block whose
             // messages wobble across a class boundary (the stream blocks send 12 or 13 spectra per 2^16-sample message) then settles at once
             const int rc = b->grow(detail::size_class(bytes + bytes / 8));
             if (rc != REDIO_OK) {
-                { std::lock_guard<std::mutex> l(s_->m); --s_->live; }
+                { std::lock_guard<std::mutex> l(s_->m); --s_->live; --s_->out; s_->out_bytes -= bytes; }
                 s_->cv.notify_all();
                 check(rc);
             }
         }
-        if (first_fill_) { // the ring's first message: the other depth - 1 buffers of its size class now, so that a graph allocates during its
-            first_fill_ = false; // first message and never after (a fourth buffer first needed deep into a run would be a late hipMalloc)
-            for (size_t i = 1; i < s_->depth; ++i) {
+        if (first_fill_) { // the ring's first message: the other buffers of its size class now, so that a graph allocates during its
+            first_fill_ = false; // first message and never after (a fourth buffer first needed deep into a run would be a late hipMalloc).
+            // As many as the byte budget lets out at this message size, and one to spare for lengths that wobble
+            const size_t want = bytes > s_->budget ? s_->depth : std::min(s_->depth, s_->budget / std::max<size_t>(bytes, 1) + 1);
+            for (size_t i = 1; i < want; ++i) {
                 std::unique_ptr<Buf> extra(new Buf);
                 if (extra->grow(b->cap) != REDIO_OK) break; // the ring then holds fewer buffers until a later acquire can allocate
                 std::lock_guard<std::mutex> l(s_->m);
@@ -368,7 +397,7 @@ template <typename T>
 void to_device(Receiver<std::vector<T>> u, Sender<View<T>> v)
 {
     BlockStream st(BlockStream::TRANSFER);
-    Ring ring;
+    Ring ring(default_ring_depth_ref().load(), (size_t)-1); // no byte budget: the copy engine fills the next message while the graph works on this one
     for (;;) {
         auto x = u.recv();
         auto d = ring.acquire<T>(x.size(), st);

@@ -6,6 +6,8 @@
 //   kpn_tests devring msg nmsg depth warm policy host_sync   three device blocks on bounded rings: no allocation after message `warm`, checksum printed
 //   kpn_tests bench_c2 log2_msg nmsg depth resident|synth checksum|drop host_sync policy    one JSON line: graph against bare launches
 //   kpn_tests bench_c2_list log2:nmsg:depth:host_sync:policy:source:sink ...              the same for a list of points, one process
+//   kpn_tests bench_block_list channelizer|ovsave|fft|fir:log2_msg:nmsg ...                the other hot blocks, graph against bare launches
+//   environment: KPN_DEV_STREAMS=per_block, KPN_DEV_RING=depth, KPN_DEV_RING_MIB=byte budget of a ring (dev::set_default_ring_bytes)
 //   kpn_tests bench_c2_sweep seconds_per_point before lo hi                          message sizes 2^lo ... 2^hi (step 4x)
 #include "../../include/kpn.hpp"
 #include "../../include/wavio.hpp"
@@ -125,6 +127,38 @@ static int ring_logic()
         CHECK(fake::mallocs.load() == m0);
         { auto a = ring.acquire<uint8_t>(5000, sA); }
         CHECK(fake::mallocs.load() == m0 + 1 && ring.grows() == 2);
+    }
+    { // the byte budget: a ring of 4 with 1000 bytes to have out lets one 600-byte message go at a time (the first always goes, whatever
+      // its size) and hands the buffer released last back; 200-byte messages use the whole depth.  Pre-allocation follows the budget
+        BS sA;
+        const long m0 = fake::mallocs.load();
+        dev::Ring ring(4, 1000);
+        auto a = ring.acquire<uint8_t>(600, sA);
+        CHECK(fake::mallocs.load() == m0 + 2); // one out at this size, one to spare
+        uint8_t *pa = a.data();
+        std::atomic<int> got{0};
+        uint8_t *pb = nullptr;
+        std::thread t([&] { auto b = ring.acquire<uint8_t>(600, sA); pb = b.data(); got = 1; });
+        std::this_thread::sleep_for(std::chrono::milliseconds(30));
+        CHECK(got.load() == 0);            // 600 + 600 > 1000: parked although three buffers may still be had
+        a = dev::View<uint8_t>();
+        t.join();
+        CHECK(got.load() == 1 && pb == pa && fake::mallocs.load() == m0 + 2);
+        { // larger than the whole budget: the cache cannot hold it anyway, so only the depth bounds it
+            auto big = ring.acquire<uint8_t>(5000, sA);
+            auto big2 = ring.acquire<uint8_t>(5000, sA);
+            CHECK(big.len == 5000 && big2.data() != big.data());
+        }
+        std::vector<dev::View<uint8_t>> held;
+        for (int i = 0; i < 4; ++i) held.push_back(ring.acquire<uint8_t>(200, sA)); // 800 bytes out: within the budget, the full depth
+        CHECK(held.size() == 4);
+        std::atomic<int> got5{0};
+        std::thread t5([&] { auto e = ring.acquire<uint8_t>(100, sA); got5 = 1; });
+        std::this_thread::sleep_for(std::chrono::milliseconds(30));
+        CHECK(got5.load() == 0);           // within the budget now, but all four buffers are out
+        held.pop_back();
+        t5.join();
+        CHECK(got5.load() == 1);
     }
     { // the ring and the stream go (their block ended) while a message is still held downstream: the last handle frees the buffer,
       // and the stream it names lives until then
@@ -1077,6 +1111,120 @@ static int bench_c2_list(int nspec, char **specs)
     return 0;
 }
 
+// ---- bench_block: the other hot blocks behind the operator API, same method as bench_c2 (source of 4 resident messages -> block -> checksum sink, one thread
+// per block, against the same launches made bare from one thread on one stream):
+//   channelizer  dev::channelizer, 64 channels x 16 taps per branch (BASELINE.json configs[3])        16 B per sample
+//   ovsave       dev::overlap_save, 65536-point blocks, 8193 taps (configs[4])                        message = 65536 + k * 57344 samples
+//   fft          dev::fft, 1024-point forward transforms (kissfft::fft, kissfft.rs:18-31)
+//   fir          dev::fir, 127 taps, decimate by 5 (dsputils::convolve's decimating form)
+// One JSON line; GS/s of input samples.
+static int bench_block(const std::string &kind, int log2_msg, size_t nmsg)
+{
+    using cf = std::complex<float>;
+    using clk = std::chrono::steady_clock;
+    const size_t R = 4;
+    nmsg = (nmsg + R - 1) / R * R;
+    size_t msg = (size_t)1 << log2_msg;
+    if (kind == "ovsave") msg = 65536 + ((msg - 65536) / 57344) * 57344; // whole blocks: nothing of a message is dropped
+    auto big = dev::make<cf>(R * msg);
+    dev::check(redio_synth_iq(big.data(), 0x5EED0004u, 0, R * msg, nullptr));
+    dev::check(redio_stream_sync(nullptr));
+    const std::vector<float> taps127 = dsputils::lpf_corrected(127, 0.08f), proto = dsputils::lpf_corrected(64 * 16, 0.45f / 64.0f), taps8k = dsputils::lpf_corrected(8193, 0.08f);
+    redio_pfb *hp = nullptr; redio_ovsave *ho = nullptr; redio_fft *hf = nullptr; redio_fir *hr = nullptr;
+    size_t nout = 0;
+    if (kind == "channelizer") { dev::check(redio_pfb_create(&hp, proto.data(), 64, 16, REDIO_FIR_FUSED)); nout = redio_pfb_nrows(hp, msg) * 64; }
+    else if (kind == "ovsave") { dev::check(redio_ovsave_create(&ho, taps8k.data(), taps8k.size(), 65536)); nout = redio_ovsave_nout(ho, msg); }
+    else if (kind == "fft") { dev::check(redio_fft_create(&hf, 1024, 0)); nout = msg; }
+    else if (kind == "fir") { dev::check(redio_fir_create(&hr, taps127.data(), taps127.size(), 5, REDIO_FIR_COMPLEX | REDIO_FIR_FUSED)); nout = redio_fir_nout(hr, msg); }
+    else return 2;
+    auto enqueue = [&](const cf *in, cf *out, void *st) {
+        if (hp) return redio_pfb_enqueue(hp, in, msg, out, 1, st);
+        if (ho) return redio_ovsave_enqueue(ho, in, msg, out, st);
+        if (hf) return redio_fft_enqueue(hf, in, out, msg / 1024, st);
+        return redio_fir_enqueue(hr, in, msg, out, st);
+    };
+    double bare_us = 0;
+    size_t warm = 8;
+    {
+        // KPN_BENCH_SEPARATE_OUTS=1: the bare leg's outputs as R allocations instead of one (what the device's page mapping of a buffer is worth)
+        const bool separate = std::getenv("KPN_BENCH_SEPARATE_OUTS") != nullptr;
+        auto outs = dev::make<cf>(separate ? 1 : R * nout);
+        std::vector<dev::View<cf>> each;
+        for (size_t i = 0; i < R; ++i) each.push_back(separate ? dev::make<cf>(nout + nout / 8) : outs.sub(i * nout, nout));
+        auto acc = dev::make<unsigned long long>(1);
+        dev::BlockStream st(dev::BlockStream::TRANSFER);
+        auto burst = [&](size_t n) {
+            for (size_t i = 0; i < n; ++i) {
+                dev::check(enqueue(big.data() + (i % R) * msg, each[i % R].data(), st));
+                dev::check(redio_checksum_u32(each[i % R].data(), nout * 2, acc.data(), st));
+            }
+            dev::check(redio_stream_sync(st));
+        };
+        burst(4);
+        auto t0 = clk::now();
+        size_t done = 0;
+        while (std::chrono::duration<double>(clk::now() - t0).count() < 0.15) { burst(8); done += 8; }
+        warm = std::max<size_t>(8, (size_t)(0.15 / (std::chrono::duration<double>(clk::now() - t0).count() / (double)done)));
+        auto t1 = clk::now();
+        burst(nmsg);
+        bare_us = std::chrono::duration<double>(clk::now() - t1).count() / (double)nmsg * 1e6;
+    }
+    if (hp) redio_pfb_destroy(hp);
+    if (ho) redio_ovsave_destroy(ho);
+    if (hf) redio_fft_destroy(hf);
+    if (hr) redio_fir_destroy(hr);
+    auto [s1, r1] = bounded_channel<dev::View<cf>>(8);
+    auto [s2, r2] = channel<dev::View<cf>>();
+    const size_t total = warm + nmsg;
+    clk::time_point t0, t1;
+    unsigned long long m0 = 0, m1 = 0, sum = 0;
+    std::vector<std::thread> th;
+    th.push_back(spawn([s = std::move(s1), big, msg, total, R]() mutable { for (size_t i = 0; i < total; ++i) s.send_unwrap(big.sub((i % R) * msg, msg)); }));
+    if (kind == "channelizer") th.push_back(spawn([r = std::move(r1), s = std::move(s2), proto]() mutable { dev::channelizer(std::move(r), std::move(s), proto, 64, 16, true); }));
+    else if (kind == "ovsave") th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps8k]() mutable { dev::overlap_save(std::move(r), std::move(s), taps8k, 65536); }));
+    else if (kind == "fft") th.push_back(spawn([r = std::move(r1), s = std::move(s2)]() mutable { dev::fft(std::move(r), std::move(s), 1024, 0); }));
+    else th.push_back(spawn([r = std::move(r1), s = std::move(s2), taps127]() mutable { dev::fir(std::move(r), std::move(s), taps127, 5, true); }));
+    th.push_back(spawn([&, r = std::move(r2)]() mutable {
+        dev::BlockStream st;
+        auto acc = dev::make<unsigned long long>(1);
+        const unsigned long long zero = 0;
+        dev::check(redio_upload(acc.data(), &zero, 8, st));
+        dev::check(redio_stream_sync(st));
+        for (size_t i = 0; i < total; ++i) {
+            auto d = r.recv();
+            {
+                dev::Reading<cf> in(d, st);
+                if (i >= warm) dev::check(redio_checksum_u32(d.data(), d.len * 2, acc.data(), st));
+            }
+            if (i + 1 == warm) { dev::check(redio_stream_sync(st)); m0 = redio_malloc_count(); t0 = clk::now(); }
+        }
+        dev::check(redio_stream_sync(st));
+        t1 = clk::now();
+        m1 = redio_malloc_count();
+        dev::check(redio_download(&sum, acc.data(), 8, st));
+        dev::check(redio_stream_sync(st));
+    }));
+    for (auto &t : th) t.join();
+    const double graph_us = std::chrono::duration<double>(t1 - t0).count() / (double)nmsg * 1e6;
+    std::printf("{\"mode\": \"bench_block\", \"block\": \"%s\", \"msg_samples\": %zu, \"messages\": %zu, \"bare_us_per_msg\": %.3f, \"bare_gsps\": %.3f, \"graph_us_per_msg\": %.3f, "
+                "\"graph_gsps\": %.3f, \"frac_of_bare\": %.4f, \"mallocs_in_timed_region\": %llu, \"checksum\": %llu}\n",
+                kind.c_str(), msg, nmsg, bare_us, (double)msg / bare_us * 1e-3, graph_us, (double)msg / graph_us * 1e-3, bare_us / graph_us, m1 - m0, sum);
+    std::fflush(stdout);
+    return 0;
+}
+// kind:log2_msg:nmsg ...
+static int bench_block_list(int nspec, char **specs)
+{
+    for (int i = 0; i < nspec; ++i) {
+        char kind[24] = {0};
+        int k = 0;
+        size_t n = 0;
+        if (std::sscanf(specs[i], "%23[a-z]:%d:%zu", kind, &k, &n) != 3) return 2;
+        if (int rc = bench_block(kind, k, n)) return rc;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -1084,6 +1232,7 @@ int main(int argc, char **argv)
         // the device graphs of this driver under the other stream policy / ring depth (tests/test_kpn_cpp.py runs them both ways)
         if (const char *e = std::getenv("KPN_DEV_STREAMS")) dev::set_stream_policy(std::string(e) == "per_block" ? dev::PER_BLOCK : dev::SHARED);
         if (const char *e = std::getenv("KPN_DEV_RING")) dev::set_default_ring_depth((size_t)std::atol(e));
+        if (const char *e = std::getenv("KPN_DEV_RING_MIB")) dev::set_default_ring_bytes((size_t)std::atol(e) << 20); // 0: one message out at a time
         if (mode == "plumbing") return plumbing();
         if (mode == "c1" && argc == 4) return c1(argv[2], argv[3]);
         if (mode == "fft" && argc == 6) return fft_graph(argv[2], argv[3], (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
@@ -1098,6 +1247,7 @@ int main(int argc, char **argv)
             return dev_ring_graph((size_t)std::atol(argv[2]), (size_t)std::atol(argv[3]), (size_t)std::atol(argv[4]), (size_t)std::atol(argv[5]), std::atoi(argv[6]), std::atoi(argv[7]));
         if (mode == "bench_c2" && argc == 9)
             return bench_c2(std::atoi(argv[2]), (size_t)std::atol(argv[3]), (size_t)std::atol(argv[4]), argv[5], argv[6], std::atoi(argv[7]), std::atoi(argv[8]));
+        if (mode == "bench_block_list" && argc > 2) return bench_block_list(argc - 2, argv + 2);
         if (mode == "bench_c2_list" && argc > 2) return bench_c2_list(argc - 2, argv + 2);
         if (mode == "bench_c2_sweep" && argc == 6) return bench_c2_sweep(std::atof(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
         if (mode == "resample" && argc == 6) return resample_graph(argv[2], argv[3], std::atof(argv[4]), (size_t)std::atol(argv[5]));

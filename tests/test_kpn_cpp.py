@@ -221,6 +221,37 @@ def test_bench_c2_mode_reports_graph_against_bare_launches(exe, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ring_mib", ["128", "0", "1"])
+def test_bench_block_mode_checksums_match_the_oracle_under_every_byte_budget(exe, gpu, oracle, ring_mib):
+    # source -> dev::fft | dev::fir | dev::channelizer | dev::overlap_save -> checksum sink: the sum over the timed messages is the oracle's, whatever
+    # the ring's byte budget lets out at a time (0: one message; 1 MiB: one or two of these; 128 MiB: the full depth)
+    import json
+    k, nmsg, R = 17, 40, 4
+    msg = 1 << k
+    env = dict(os.environ, KPN_DEV_RING_MIB=ring_mib)
+    out = subprocess.run([exe, "bench_block_list", f"fft:{k}:{nmsg}", f"fir:{k}:{nmsg}", f"channelizer:{k}:{nmsg}", f"ovsave:{k}:{nmsg}"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr
+    recs = {r["block"]: r for r in map(json.loads, out.stdout.strip().splitlines())}
+    words = lambda y: int(np.ascontiguousarray(y).view(np.uint32).astype(np.uint64).sum())
+    omsg = 65536 + ((msg - 65536) // 57344) * 57344
+    want = {"fft": 0, "fir": 0, "channelizer": 0, "ovsave": 0}
+    x = oracle.synth_iq(0x5EED0004, 0, R * msg)
+    xo = oracle.synth_iq(0x5EED0004, 0, R * omsg)
+    t127, proto, t8k = oracle.lpf_corrected(127, 0.08), oracle.lpf_corrected(64 * 16, 0.45 / 64.0), oracle.lpf_corrected(8193, 0.08)
+    for r in range(R):
+        m = x[r * msg:(r + 1) * msg]
+        want["fft"] += words(oracle.fft(m, 1024))
+        want["fir"] += words(oracle.fir(m, t127, 5, fused=True))
+        want["channelizer"] += words(oracle.pfb_channelizer(m, proto, 64, 16, fused=True))
+        want["ovsave"] += words(oracle.overlap_save(xo[r * omsg:(r + 1) * omsg], t8k, 65536))
+    for b, rec in recs.items():
+        assert rec["messages"] == nmsg and rec["mallocs_in_timed_region"] == 0, rec
+        assert rec["checksum"] == (want[b] * (nmsg // R)) % (1 << 64), b
+    assert set(recs) == set(want)
+
+
+@pytest.mark.gpu
 def test_device_shaper_rechunks_views(exe, gpu, oracle, tmp_path, devenv):
     x = oracle.synth_f32(3, 0, 10000)
     x.tofile(tmp_path / "in.bin")
