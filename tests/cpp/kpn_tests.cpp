@@ -132,6 +132,7 @@ static int ring_logic()
       // its size) and hands the buffer released last back; 200-byte messages use the whole depth.  Pre-allocation follows the budget
         BS sA;
         const long m0 = fake::mallocs.load();
+        dev::set_ring_patience_ms(20000);
         dev::Ring ring(4, 1000);
         auto a = ring.acquire<uint8_t>(600, sA);
         CHECK(fake::mallocs.load() == m0 + 2); // one out at this size, one to spare
@@ -158,7 +159,30 @@ static int ring_logic()
         CHECK(got5.load() == 0);           // within the budget now, but all four buffers are out
         held.pop_back();
         t5.join();
-        CHECK(got5.load() == 1);
+        CHECK(got5.load() == 1 && ring.budget_yields() == 0);
+    }
+    { // the budget is a preference about order, not a bound: a consumer that KEEPS a message while it waits for the next (600 + 600 >
+      // 1000) gets it once the ring's patience is over, and the ring stops using its budget; the depth still binds
+        BS sA;
+        dev::set_ring_patience_ms(20);
+        dev::Ring ring(3, 1000);
+        auto kept = ring.acquire<uint8_t>(600, sA);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto next = ring.acquire<uint8_t>(600, sA);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        CHECK(next.data() != kept.data() && ms >= 15.0 && ring.budget_yields() == 1);
+        const auto t1 = std::chrono::steady_clock::now();
+        auto third = ring.acquire<uint8_t>(600, sA);
+        const double ms3 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        CHECK(ms3 < 15.0 && ring.budget_yields() == 1);
+        std::atomic<int> got{0};
+        std::thread t([&] { auto d = ring.acquire<uint8_t>(600, sA); got = 1; });
+        std::this_thread::sleep_for(std::chrono::milliseconds(60));
+        CHECK(got.load() == 0);            // three out of three: the depth is a bound
+        third = dev::View<uint8_t>();
+        t.join();
+        CHECK(got.load() == 1);
+        dev::set_ring_patience_ms(50);
     }
     { // the ring and the stream go (their block ended) while a message is still held downstream: the last handle frees the buffer,
       // and the stream it names lives until then
