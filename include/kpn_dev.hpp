@@ -99,14 +99,20 @@ inline std::atomic<size_t> &default_ring_bytes_ref()
 }
 inline void set_default_ring_bytes(size_t b) { default_ring_bytes_ref().store(b); }
 // The byte budget is a preference about ORDER, never a reason to stop: a consumer that keeps a message while it waits for the next one
-// (a block with memory of its own) would otherwise wait for ever on a producer held back by its budget.  A ring whose budget wait lasts
-// this long stops using its budget; only `depth` bounds it from then on, as it always did.
+// (a block with memory of its own) would otherwise wait for ever on a producer held back by its budget.  A budget wait that lasts this
+// long ends with the message going out anyway (a consumer that sat in a long host synchronisation with a message in hand: once); after
+// three such waits in a row the ring stops using its budget, and only `depth` bounds it from then on, as it always did.
 inline std::atomic<int> &ring_patience_ms_ref()
 {
     static std::atomic<int> ms{50};
     return ms;
 }
 inline void set_ring_patience_ms(int ms) { ring_patience_ms_ref().store(ms); }
+inline std::atomic<unsigned long long> &budget_yields_ref() // budget waits of this process that ran out of patience (diagnostics)
+{
+    static std::atomic<unsigned long long> n{0};
+    return n;
+}
 
 // a HIP stream with shared ownership: buffers remember the streams that touched them, so a stream outlives its block while a message
 // that names it is still in flight
@@ -220,7 +226,8 @@ struct RingState {
     size_t depth = 0, live = 0;             // live: buffers that exist (free + leased)
     size_t budget = (size_t)-1, out = 0, out_bytes = 0; // leased buffers and the message bytes in them, against the byte budget
     bool closed = false;
-    unsigned long long yields = 0;          // times the byte budget gave way (0 or 1)
+    unsigned long long yields = 0;          // times the byte budget gave way
+    int impatient = 0;                      // ... in a row
     unsigned long long grows = 0;           // device allocations this ring made (warm-up, or a message larger than any before)
 };
 // size classes: the request rounded up to 1/8 of its leading power of two (<= 12.5 % slack), so that messages whose length wobbles
@@ -347,9 +354,12 @@ public:
             const auto in_budget = [&] { return s_->out == 0 || (s_->out < s_->depth && (bytes > s_->budget || s_->out_bytes + bytes <= s_->budget)); };
             while (!in_budget()) {
                 if (s_->out >= s_->depth) s_->cv.wait(l); // no credit: the bound
-                else if (!s_->cv.wait_for(l, std::chrono::milliseconds(ring_patience_ms_ref().load()), in_budget)) {
-                    s_->budget = (size_t)-1; // downstream keeps what it has until it gets more (comment at ring_patience_ms_ref)
+                else if (s_->cv.wait_for(l, std::chrono::milliseconds(ring_patience_ms_ref().load()), in_budget)) s_->impatient = 0;
+                else { // comment at ring_patience_ms_ref: this message goes now (out < depth); three in a row and the budget is off
                     ++s_->yields;
+                    ++budget_yields_ref();
+                    if (++s_->impatient >= 3) s_->budget = (size_t)-1;
+                    break;
                 }
             }
             // best fit among the free buffers, the one released last among equals (the likeliest to be in the cache still); else a new
