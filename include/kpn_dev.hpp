@@ -354,7 +354,10 @@ public:
             const auto in_budget = [&] { return s_->out == 0 || (s_->out < s_->depth && (bytes > s_->budget || s_->out_bytes + bytes <= s_->budget)); };
             while (!in_budget()) {
                 if (s_->out >= s_->depth) s_->cv.wait(l); // no credit: the bound
-                else if (s_->cv.wait_for(l, std::chrono::milliseconds(ring_patience_ms_ref().load()), in_budget)) s_->impatient = 0;
+                // (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer follows; wait_for goes through
+                // pthread_cond_clockwait, which gcc 11's does not: it then believes the waiter still holds the mutex)
+                else if (s_->cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(ring_patience_ms_ref().load()), in_budget))
+                    s_->impatient = 0;
                 else { // comment at ring_patience_ms_ref: this message goes now (out < depth); three in a row and the budget is off
                     ++s_->yields;
                     ++budget_yields_ref();
