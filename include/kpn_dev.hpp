@@ -28,7 +28,8 @@
 //     allocation and no hipFree (redio_malloc_count() stays put; tests/test_kpn_cpp.py).  A sink that hoards more than `depth`
 //     messages of one producer without dropping them stalls that producer: drop handles, or give that block a deeper ring.
 //     A ring also has a BYTE budget (default_ring_bytes_ref below): with the compute blocks on one stream, a producer that runs k
-//     messages ahead puts k outputs between a message and the kernel that reads it -- past the last-level cache that reader goes to HBM.
+//     messages ahead puts k outputs between a message and the kernel that reads it, and rotates k + 1 buffers -- past the last-level
+//     cache both cost time (measured: 6 us each on a 128 MiB message that takes 69 us with neither).
 //     The rings bound MEMORY, not how far the host threads run ahead of the GPU: a buffer is recycled when its handles drop (the queue
 //     orders the reuse), so hundreds of messages' kernels may sit in the HIP queue; a block that needs a result on the CPU synchronises.
 //   * Blocks written elsewhere use the same three calls: `auto o = ring.acquire<T>(n, st)`, `{ Reading<T> in(view, st); enqueue...; }`,
@@ -88,9 +89,12 @@ inline std::atomic<size_t> &default_ring_depth_ref()
 inline void set_default_ring_depth(size_t d) { default_ring_depth_ref().store(d); }
 // bytes one ring may have out with the blocks downstream (beyond the first message, which always goes).  Blocks that share the graph
 // stream run in the order their threads enqueued, so a producer that runs k messages ahead puts k outputs between a message and the
-// kernel that reads it: past the last-level cache (256 MB of Infinity Cache on MI355X) the reader finds its input in HBM instead.
-// Half of that cache, measured (profiles/r06_kpn_ring_bytes.txt): 2^24-sample messages through dev::fft run at 107 % of the bare
-// launches with one 128 MiB output out, at 92 % with two or four; small messages keep the full depth, which hides the host threads,
+// kernel that reads it and writes k + 1 buffers in rotation: past the last-level cache (256 MB of Infinity Cache on MI355X) the pair
+// "transform, then checksum of its output" takes 80-82 us per 128 MiB message with the reader one or more messages behind, 75 us with
+// the reader directly behind, 69 us when in addition the writer gets back the buffer just read (tools/out_buffer_reuse.py; in the
+// kernel trace it is the WRITER that runs 45 instead of 52 us, the reader takes 24.5 us throughout).  Half of that cache, measured
+// (profiles/r06_kpn_ring_bytes.txt): 2^24-sample messages through dev::fft run at 107 % of the bare launches (which rotate four
+// buffers) with one 128 MiB output out, at 92 % with two or four; small messages keep the full depth, which hides the host threads,
 // and so do messages larger than the budget itself (nothing keeps those in the cache; measured equal or 1-3 % better unbounded).
 inline std::atomic<size_t> &default_ring_bytes_ref()
 {
