@@ -95,7 +95,8 @@ inline void set_default_ring_depth(size_t d) { default_ring_depth_ref().store(d)
 // kernel trace it is the WRITER that runs 45 instead of 52 us, the reader takes 24.5 us throughout).  Half of that cache, measured
 // (profiles/r06_kpn_ring_bytes.txt): 2^24-sample messages through dev::fft run at 107 % of the bare launches (which rotate four
 // buffers) with one 128 MiB output out, at 92 % with two or four; small messages keep the full depth, which hides the host threads,
-// and so do messages larger than the budget itself (nothing keeps those in the cache; measured equal or 1-3 % better unbounded).
+// and so do messages larger than the cache, i.e. twice the budget (nothing keeps those there; measured equal or 1-3 % better unbounded);
+// a message between the budget and the cache goes out alone.
 inline std::atomic<size_t> &default_ring_bytes_ref()
 {
     static std::atomic<size_t> b{(size_t)128 << 20};
@@ -354,8 +355,10 @@ public:
         std::unique_ptr<Buf> b;
         {
             std::unique_lock<std::mutex> l(s_->m);
-            // a message larger than the whole budget cannot be kept in the cache whatever the order: holding its producer back gains nothing
-            const auto in_budget = [&] { return s_->out == 0 || (s_->out < s_->depth && (bytes > s_->budget || s_->out_bytes + bytes <= s_->budget)); };
+            // a message larger than the cache (twice the budget) cannot be kept there whatever the order: holding its producer back gains
+            // nothing; one between the budget and the cache goes alone
+            const bool too_big = s_->budget != (size_t)-1 && bytes / 2 > s_->budget;
+            const auto in_budget = [&] { return s_->out == 0 || (s_->out < s_->depth && (too_big || s_->out_bytes + bytes <= s_->budget)); };
             while (!in_budget()) {
                 if (s_->out >= s_->depth) s_->cv.wait(l); // no credit: the bound
                 // (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer follows; wait_for goes through
@@ -402,7 +405,7 @@ public:
         if (first_fill_) { // the ring's first message: the other buffers of its size class now, so that a graph allocates during its
             first_fill_ = false; // first message and never after (a fourth buffer first needed deep into a run would be a late hipMalloc).
             // As many as the byte budget lets out at this message size, and one to spare for lengths that wobble
-            const size_t want = bytes > s_->budget ? s_->depth : std::min(s_->depth, s_->budget / std::max<size_t>(bytes, 1) + 1);
+            const size_t want = bytes / 2 > s_->budget ? s_->depth : std::min(s_->depth, s_->budget / std::max<size_t>(bytes, 1) + 1 + (bytes > s_->budget));
             for (size_t i = 1; i < want; ++i) {
                 std::unique_ptr<Buf> extra(new Buf);
                 if (extra->grow(b->cap) != REDIO_OK) break; // the ring then holds fewer buffers until a later acquire can allocate

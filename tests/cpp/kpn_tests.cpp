@@ -145,10 +145,20 @@ static int ring_logic()
         a = dev::View<uint8_t>();
         t.join();
         CHECK(got.load() == 1 && pb == pa && fake::mallocs.load() == m0 + 2);
-        { // larger than the whole budget: the cache cannot hold it anyway, so only the depth bounds it
+        { // larger than the cache (twice the budget): it cannot be kept there anyway, so only the depth bounds it
             auto big = ring.acquire<uint8_t>(5000, sA);
             auto big2 = ring.acquire<uint8_t>(5000, sA);
             CHECK(big.len == 5000 && big2.data() != big.data());
+        }
+        { // between the budget and the cache: goes out alone
+            auto mid = ring.acquire<uint8_t>(1500, sA);
+            std::atomic<int> got2{0};
+            std::thread t2([&] { auto m2 = ring.acquire<uint8_t>(1500, sA); got2 = 1; });
+            std::this_thread::sleep_for(std::chrono::milliseconds(30));
+            CHECK(got2.load() == 0);
+            mid = dev::View<uint8_t>();
+            t2.join();
+            CHECK(got2.load() == 1);
         }
         std::vector<dev::View<uint8_t>> held;
         for (int i = 0; i < 4; ++i) held.push_back(ring.acquire<uint8_t>(200, sA)); // 800 bytes out: within the budget, the full depth
@@ -1177,7 +1187,7 @@ static int bench_block(const std::string &kind, int log2_msg, size_t nmsg)
     using clk = std::chrono::steady_clock;
     const size_t R = 4;
     nmsg = (nmsg + R - 1) / R * R;
-    size_t msg = (size_t)1 << log2_msg;
+    size_t msg = log2_msg > 40 ? (size_t)log2_msg / 1024 * 1024 : (size_t)1 << log2_msg; // above 40: a sample count (whole 1024-point blocks)
     if (kind == "ovsave") msg = 65536 + ((msg - 65536) / 57344) * 57344; // whole blocks: nothing of a message is dropped
     auto big = dev::make<cf>(R * msg);
     dev::check(redio_synth_iq(big.data(), 0x5EED0004u, 0, R * msg, nullptr));
